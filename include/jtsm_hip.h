@@ -1,0 +1,142 @@
+/*
+ * jtsm_hip.h — C ABI of libjtsm_hip.so: the MI355X (gfx950) hot path of JTSM.
+ *
+ * Every entry point takes plain device pointers, sizes and a hipStream_t passed as
+ * void* (NULL = the null stream).  No torch/ATen types cross this boundary.  The
+ * library never allocates device memory: outputs and workspaces are caller-owned,
+ * exactly sized as documented; inputs are never written.  All launches are
+ * asynchronous on `stream`; nothing here synchronises the device (the reference's
+ * forward does a cudaDeviceSynchronize, ROIAlign_cuda.cu:364 — deliberately not kept).
+ *
+ * Return value: 0 on success, a negative JTSM_E* code otherwise;
+ * jtsm_last_error() gives the message of the calling thread's last failure.  The
+ * reference reports the same conditions as C++ exceptions -> Python RuntimeError
+ * (AT_ASSERTM / TORCH_CHECK, e.g. ROIAlign_cuda.cu:318-324); the Python host layer
+ * (jtsm_amd/_lib.py) turns a non-zero return into RuntimeError to keep that behaviour.
+ *
+ * Each group cites the reference interface it replaces (paths relative to the
+ * reference tree).  `layout` selects how 4-D feature tensors are stored:
+ * JTSM_NCHW is what the reference FFI uses; JTSM_NHWC is the layout the MI355X path
+ * keeps activations in (channels across the 64 lanes of a wavefront -> coalesced
+ * 1 KiB rows).  Pooled outputs / gradients use the same layout as the feature map:
+ * (M,C,PH,PW) for NCHW, (M,PH,PW,C) for NHWC.
+ */
+#ifndef JTSM_HIP_H_
+#define JTSM_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JTSM_OK 0
+#define JTSM_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported combination) */
+#define JTSM_ELAUNCH (-2)  /* HIP runtime reported a launch / API error */
+#define JTSM_ENODEV (-3)   /* no gfx950 device / code object not loadable */
+
+#define JTSM_NCHW 0
+#define JTSM_NHWC 1
+
+const char* jtsm_last_error(void);
+/* "jtsm_hip <version> gfx950" — also proves the shared object is the HIP build. */
+const char* jtsm_version(void);
+/* Number of visible HIP devices (<0 on error).  Does not create a context. */
+int jtsm_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * ROIAlign — replaces detectron2/layers/csrc/ROIAlign/ROIAlign.h:7-27
+ *   ROIAlign_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, aligned)
+ *   ROIAlign_backward(grad, rois, spatial_scale, pooled_h, pooled_w, B, C, H, W,
+ *                     sampling_ratio, aligned)
+ * bound at detectron2/layers/csrc/vision.cpp:96-97, called from
+ * detectron2/layers/roi_align.py:22-59.
+ * rois: (M,5) [batch_idx, x0, y0, x1, y1], same dtype as input.
+ * backward: grad is dense in `layout`; grad_input (B,C,H,W in `layout`) is zero-filled
+ * by the call and then accumulated with float atomics.
+ * ------------------------------------------------------------------------- */
+int jtsm_roi_align_forward_f32(const float* input, const float* rois, float* output, int B,
+                               int C, int H, int W, int M, float spatial_scale, int pooled_h,
+                               int pooled_w, int sampling_ratio, int aligned, int layout,
+                               void* stream);
+int jtsm_roi_align_backward_f32(const float* grad, const float* rois, float* grad_input, int B,
+                                int C, int H, int W, int M, float spatial_scale, int pooled_h,
+                                int pooled_w, int sampling_ratio, int aligned, int layout,
+                                void* stream);
+int jtsm_roi_align_forward_f64(const double* input, const double* rois, double* output, int B,
+                               int C, int H, int W, int M, double spatial_scale, int pooled_h,
+                               int pooled_w, int sampling_ratio, int aligned, int layout,
+                               void* stream);
+int jtsm_roi_align_backward_f64(const double* grad, const double* rois, double* grad_input,
+                                int B, int C, int H, int W, int M, double spatial_scale,
+                                int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                                int layout, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * ROIAlignRotated — replaces detectron2/layers/csrc/ROIAlignRotated/ROIAlignRotated.h:7-27
+ * (bound at vision.cpp:99-106, called from detectron2/layers/roi_align_rotated.py:10-47).
+ * rois: (M,6) [batch_idx, cx, cy, w, h, angle_degrees]; always "aligned".
+ * ------------------------------------------------------------------------- */
+int jtsm_roi_align_rotated_forward_f32(const float* input, const float* rois, float* output,
+                                       int B, int C, int H, int W, int M, float spatial_scale,
+                                       int pooled_h, int pooled_w, int sampling_ratio,
+                                       int layout, void* stream);
+int jtsm_roi_align_rotated_backward_f32(const float* grad, const float* rois, float* grad_input,
+                                        int B, int C, int H, int W, int M, float spatial_scale,
+                                        int pooled_h, int pooled_w, int sampling_ratio,
+                                        int layout, void* stream);
+int jtsm_roi_align_rotated_forward_f64(const double* input, const double* rois, double* output,
+                                       int B, int C, int H, int W, int M, double spatial_scale,
+                                       int pooled_h, int pooled_w, int sampling_ratio,
+                                       int layout, void* stream);
+int jtsm_roi_align_rotated_backward_f64(const double* grad, const double* rois,
+                                        double* grad_input, int B, int C, int H, int W, int M,
+                                        double spatial_scale, int pooled_h, int pooled_w,
+                                        int sampling_ratio, int layout, void* stream);
+
+/* The "bit-exact ROI bin indices" contract made observable: for each of the M rois write
+ * grid[2m..] = {gh, gw} and, for the first `cap` samples in (ph, pw, iy, ix) order,
+ * pos[(m*cap+s)*4..] (flat y*W+x of the 4 taps, -1 when the sample is out of range) and
+ * w[(m*cap+s)*4..].  Uses the very device functions the pooling kernels use.
+ * rotated=0: rois (M,5) with `aligned`; rotated=1: rois (M,6). */
+int jtsm_roi_sample_table_f32(const float* rois, int rotated, int M, int H, int W,
+                              float spatial_scale, int pooled_h, int pooled_w,
+                              int sampling_ratio, int aligned, int* grid, int* pos, float* w,
+                              int cap, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * MOIPool — replaces projects/WSL/wsl/layers/csrc/MOIPool/MOIPool.h:7-47
+ *   MOIPool_forward(input, rois, spatial_scale, pooled_h, pooled_w, oh_labels, superpixels)
+ *       -> (output, argmax)
+ *   MOIPool_backward(grad, rois, argmax, spatial_scale, pooled_h, pooled_w, B, C, H, W)
+ * bound at projects/WSL/wsl/layers/csrc/vision.cpp:23-24, called from
+ * projects/WSL/wsl/layers/moi_pool.py:10-33.
+ * rois (M,5); oh_labels (M,L) int32; superpixels (B,Hs,Ws) int32 with ids in [0,L)
+ * (ids outside that range never match — the reference reads out of bounds there).
+ * argmax holds the flat h*W+w of the winning cell (-1 = empty bin), stored in `layout`
+ * like output.  The reference's (M,H,W) int32 `mois` temporary (MOIPool_cuda.cu:394) is
+ * replaced by two bit sets kept in `workspace`: one per feature cell (which superpixels
+ * lie under it) and one per roi (which superpixels are labelled 1).
+ * workspace: jtsm_moi_pool_workspace_bytes(...) bytes, 16-byte aligned, contents
+ * undefined on entry and exit.
+ * ------------------------------------------------------------------------- */
+size_t jtsm_moi_pool_workspace_bytes(int B, int H, int W, int M, int L);
+int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32_t* oh_labels,
+                              const int32_t* superpixels, float* output, int32_t* argmax,
+                              void* workspace, int B, int C, int H, int W, int M, int L, int Hs,
+                              int Ws, float spatial_scale, int pooled_h, int pooled_w,
+                              int layout, void* stream);
+int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32_t* argmax,
+                               float* grad_input, int B, int C, int H, int W, int M,
+                               int pooled_h, int pooled_w, int layout, void* stream);
+/* mois (M,H,W) int32 exactly as MoIForward (MOIPool_cuda.cu:138-215) would write it;
+ * test/diagnostic entry, same workspace contract as the forward. */
+int jtsm_moi_mask_f32(const float* rois, const int32_t* oh_labels, const int32_t* superpixels,
+                      int32_t* mois, void* workspace, int B, int H, int W, int M, int L, int Hs,
+                      int Ws, float spatial_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JTSM_HIP_H_ */

@@ -1,0 +1,73 @@
+"""ctypes binding of libjtsm_hip.so — the only way jtsm_amd reaches the GPU kernels.
+
+There is no CPU fallback and no alternative backend: if the shared object is missing or a
+call fails, a RuntimeError is raised (the reference raises RuntimeError from its C++
+checks too, e.g. detectron2/layers/csrc/ROIAlign/ROIAlign.h:72-74 "Not compiled with GPU
+support").  PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libjtsm_hip.so")
+_lib = None
+
+NCHW, NHWC = 0, 1
+
+
+def lib():
+    """Load (once) and return the CDLL.  Loading does not need a GPU; compute calls do."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "jtsm_amd: %s not found — build it with `python -m jtsm_amd.build` "
+                "(there is no fallback path)" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.jtsm_last_error.restype = C.c_char_p
+        _lib.jtsm_version.restype = C.c_char_p
+        _lib.jtsm_moi_pool_workspace_bytes.restype = C.c_size_t
+        for name in ("jtsm_conv_workspace_bytes",):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_size_t
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().jtsm_last_error().decode("utf-8", "replace")
+        raise RuntimeError("jtsm_hip %s failed (%d): %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL for None) as c_void_p."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "jtsm_amd operators run only on the HIP device (got a %s tensor); "
+                "there is no CPU path in the product" % t.device)
+
+
+def f32(x):
+    return C.c_float(float(x))
+
+
+def f64(x):
+    return C.c_double(float(x))
+
+
+def is_nhwc(t):
+    """True when a logical NCHW tensor is stored channels-last (and not also plain-contiguous
+    in a way that makes the two layouts coincide ambiguously for C==1 / H*W==1)."""
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not (
+        t.is_contiguous() and t.shape[1] != 1 and t.shape[2] * t.shape[3] != 1)

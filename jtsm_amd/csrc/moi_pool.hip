@@ -1,0 +1,381 @@
+// MOIPool for gfx950 — JTSM's masked ROI max-pool (box pooler of JTSMROIHeads).
+//
+// Replaces MOIPool_forward/backward (projects/WSL/wsl/layers/csrc/MOIPool/MOIPool.h:7-47),
+// whose only implementation is CUDA: MoIForward + MoIPoolForward2 + RoIPoolBackward
+// (MOIPool_cuda.cu:138-338).  Behaviour contract: SURVEY.md Appendix A.3.
+//
+// The reference materialises mois[M,H,W] (int32; 524 MB at M=8000, 128x128) by letting every
+// (roi, cell) thread walk the stride x stride image block under the cell, chasing
+// superpixels[..] -> oh_labels[n, id] one pixel at a time, and then re-reads that mask once
+// per channel.  Here the test "does some superpixel under cell (h,w) carry label 1 for roi
+// n" is factored into two bit sets over the L superpixel ids:
+//     cell_bits[b,h,w]  : ids occurring under the cell      (built once per image, all rois share it)
+//     roi_bits[n]       : ids whose oh_labels[n,id] == 1
+//     mois[n,h,w] = inside_box(n,h,w) && any(cell_bits[b,h,w] & roi_bits[n])
+// which is exact (same set semantics), needs no M*H*W temporary and turns the per-pixel
+// pointer chase into one coalesced row of words per cell.
+//
+// Pool kernel (NHWC): one wavefront per (roi, bin); lanes hold the roi's label words, test the
+// bin's cells one by one (coalesced word row + wave ballot), and for every surviving cell
+// gather their own channels (VEC floats per lane, 1 KiB per 256-channel row).  Scan order is
+// h outer / w inner with a strict '>' so ties and argmax are bit-identical to the reference.
+#include <cfloat>
+
+#include "common.h"
+
+namespace jtsm {
+namespace {
+
+#pragma clang fp contract(off)
+
+struct IBox { int b, x0, y0, x1, y1; };
+
+// CUDA/HIP round(): half away from zero (roundf), MOIPool_cuda.cu:159-162.
+__device__ __forceinline__ IBox round_box(const float* __restrict__ roi, float scale) {
+#pragma clang fp contract(off)
+  IBox r;
+  r.b = (int)roi[0];
+  r.x0 = (int)roundf(roi[1] * scale);
+  r.y0 = (int)roundf(roi[2] * scale);
+  r.x1 = (int)roundf(roi[3] * scale);
+  r.y1 = (int)roundf(roi[4] * scale);
+  return r;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// cell_bits[(b*H+h)*W+w][words]: one wave per cell, lanes sweep the image block under it
+// (MOIPool_cuda.cu:175-186 bounds), OR-ing id bits into an LDS row, then store the row.
+__global__ __launch_bounds__(256) void moi_cell_bits_kernel(const int* __restrict__ superpixels,
+                                                            unsigned* __restrict__ cell_bits,
+                                                            int B, int H, int W, int Hs, int Ws,
+                                                            int L, int words) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned* row = smem + wv * words;
+  const long cell = (long)blockIdx.x * 4 + wv;
+  const bool on = cell < (long)B * H * W;
+  for (int i = lane; i < words; i += 64) row[i] = 0u;
+  __syncthreads();
+  if (on) {
+    const int w = (int)(cell % W), h = (int)((cell / W) % H), b = (int)(cell / W / H);
+    const float s = (float)(1.0 * H / Hs);
+    int hs = (int)floorf((float)h / s), ws = (int)floorf((float)w / s);
+    int he = (int)ceilf((float)(h + 1) / s), we = (int)ceilf((float)(w + 1) / s);
+    hs = clampi(hs, 0, Hs); he = clampi(he, 0, Hs);
+    ws = clampi(ws, 0, Ws); we = clampi(we, 0, Ws);
+    const int bw = we - ws, npix = (he - hs) * bw;
+    const int* __restrict__ spp = superpixels + (size_t)b * Hs * Ws;
+    for (int p = lane; p < npix; p += 64) {
+      const int hh = hs + p / bw, ww = ws + p % bw;
+      const int id = spp[(size_t)hh * Ws + ww];
+      if (id >= 0 && id < L) atomicOr(&row[id >> 5], 1u << (id & 31));
+    }
+  }
+  __syncthreads();
+  if (on)
+    for (int i = lane; i < words; i += 64) cell_bits[cell * words + i] = row[i];
+}
+
+// roi_bits[n][words]: bit id set iff oh_labels[n,id] == 1 (exactly 1, MOIPool_cuda.cu:198).
+__global__ __launch_bounds__(256) void moi_roi_bits_kernel(const int* __restrict__ oh_labels,
+                                                           unsigned* __restrict__ roi_bits,
+                                                           long total_words, int L, int words) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total_words) return;
+  const long n = idx / words;
+  const int wd = (int)(idx - n * words);
+  const int* __restrict__ rowp = oh_labels + n * L;
+  unsigned bits = 0u;
+  const int base = wd * 32;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i)
+    if (base + i < L && rowp[base + i] == 1) bits |= 1u << i;
+  roi_bits[idx] = bits;
+}
+
+struct BinRange { int hs, he, ws, we; };
+
+__device__ __forceinline__ BinRange bin_range(const IBox& r, int ph, int pw, int PH, int PW,
+                                              int H, int W) {
+#pragma clang fp contract(off)
+  const int rw = max(r.x1 - r.x0 + 1, 1), rh = max(r.y1 - r.y0 + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+  BinRange q;
+  q.hs = clampi((int)floorf((float)ph * bh) + r.y0, 0, H);
+  q.he = clampi((int)ceilf((float)(ph + 1) * bh) + r.y0, 0, H);
+  q.ws = clampi((int)floorf((float)pw * bw) + r.x0, 0, W);
+  q.we = clampi((int)ceilf((float)(pw + 1) * bw) + r.x0, 0, W);
+  return q;
+}
+
+// any(cell_bits & roi_bits) for one cell, evaluated by the whole wave.
+__device__ __forceinline__ bool cell_hit(const unsigned* __restrict__ cell_row,
+                                         const unsigned* __restrict__ roi_row, unsigned mine,
+                                         int words, int lane) {
+  unsigned hit = (lane < words) ? (cell_row[lane] & mine) : 0u;
+  for (int i = 64 + lane; i < words; i += 64) hit |= cell_row[i] & roi_row[i];
+  return __ballot(hit != 0u) != 0ull;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void moi_pool_fwd_nhwc(
+    const float* __restrict__ in, const float* __restrict__ rois,
+    const unsigned* __restrict__ cell_bits, const unsigned* __restrict__ roi_bits,
+    float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, int M, int words,
+    float scale, int PH, int PW) {
+  const int lane = threadIdx.x & 63;
+  const int nbins = PH * PW;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= (long)M * nbins) return;
+  const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const IBox r = round_box(rois + (size_t)n * 5, scale);
+  const BinRange q = bin_range(r, ph, pw, PH, PW, H, W);
+  const unsigned* __restrict__ rrow = roi_bits + (size_t)n * words;
+  const unsigned mine = lane < words ? rrow[lane] : 0u;
+  const float* __restrict__ plane = in + (size_t)r.b * H * W * C;
+  const unsigned* __restrict__ cplane = cell_bits + (size_t)r.b * H * W * words;
+  float* __restrict__ orow = out + ((size_t)n * nbins + bin) * C;
+  int* __restrict__ arow = argmax + ((size_t)n * nbins + bin) * C;
+
+  for (int cb = 0; cb < C; cb += 64 * VEC) {
+    const int c = cb + lane * VEC;
+    const bool live = c < C;
+    float best[VEC];
+    int at[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) { best[v] = -FLT_MAX; at[v] = -1; }
+    for (int h = q.hs; h < q.he; ++h)
+      for (int w = q.ws; w < q.we; ++w) {
+        // inside the rounded (inclusive) box?  wave-uniform
+        if (!(w >= r.x0 && w <= r.x1 && h >= r.y0 && h <= r.y1)) continue;
+        const int cell = h * W + w;
+        if (!cell_hit(cplane + (size_t)cell * words, rrow, mine, words, lane)) continue;
+        if (live) {
+          const float* p = plane + (size_t)cell * C + c;
+          float x[VEC];
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            x[0] = t.x; x[1 % VEC] = t.y; x[2 % VEC] = t.z; x[3 % VEC] = t.w;
+          } else {
+            x[0] = p[0];
+          }
+#pragma unroll
+          for (int v = 0; v < VEC; ++v)
+            if (x[v] > best[v]) { best[v] = x[v]; at[v] = cell; }
+        }
+      }
+    if (live) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        orow[c + v] = at[v] == -1 ? 0.f : best[v];
+        arow[c + v] = at[v];
+      }
+    }
+  }
+}
+
+// NCHW (reference layout): one thread per output element; cell test done per thread.
+__global__ __launch_bounds__(256) void moi_pool_fwd_nchw(
+    const float* __restrict__ in, const float* __restrict__ rois,
+    const unsigned* __restrict__ cell_bits, const unsigned* __restrict__ roi_bits,
+    float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, long total, int words,
+    float scale, int PH, int PW) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH);
+    const int c = (int)((idx / PW / PH) % C), n = (int)(idx / PW / PH / C);
+    const IBox r = round_box(rois + (size_t)n * 5, scale);
+    const BinRange q = bin_range(r, ph, pw, PH, PW, H, W);
+    const unsigned* __restrict__ rrow = roi_bits + (size_t)n * words;
+    const float* __restrict__ plane = in + ((size_t)r.b * C + c) * H * W;
+    const unsigned* __restrict__ cplane = cell_bits + (size_t)r.b * H * W * words;
+    float best = -FLT_MAX;
+    int at = -1;
+    for (int h = q.hs; h < q.he; ++h)
+      for (int w = q.ws; w < q.we; ++w) {
+        if (!(w >= r.x0 && w <= r.x1 && h >= r.y0 && h <= r.y1)) continue;
+        const int cell = h * W + w;
+        const unsigned* crow = cplane + (size_t)cell * words;
+        unsigned hit = 0u;
+        for (int i = 0; i < words && !hit; ++i) hit = crow[i] & rrow[i];
+        if (!hit) continue;
+        const float x = plane[cell];
+        if (x > best) { best = x; at = cell; }
+      }
+    out[idx] = at == -1 ? 0.f : best;
+    argmax[idx] = at;
+  }
+}
+
+__global__ __launch_bounds__(256) void moi_mask_kernel(const float* __restrict__ rois,
+                                                       const unsigned* __restrict__ cell_bits,
+                                                       const unsigned* __restrict__ roi_bits,
+                                                       int* __restrict__ mois, int H, int W,
+                                                       long total, int words, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int w = (int)(idx % W), h = (int)((idx / W) % H), n = (int)(idx / W / H);
+  const IBox r = round_box(rois + (size_t)n * 5, scale);
+  int v = 0;
+  if (w >= r.x0 && w <= r.x1 && h >= r.y0 && h <= r.y1) {
+    const unsigned* crow = cell_bits + ((size_t)r.b * H * W + (size_t)h * W + w) * words;
+    const unsigned* rrow = roi_bits + (size_t)n * words;
+    unsigned hit = 0u;
+    for (int i = 0; i < words && !hit; ++i) hit = crow[i] & rrow[i];
+    v = hit != 0u;
+  }
+  mois[idx] = v;
+}
+
+// Backward: grad_input[b, argmax] += grad (RoIPoolBackward, MOIPool_cuda.cu:296-338).
+template <bool NHWC>
+__global__ __launch_bounds__(256) void moi_pool_bwd(const float* __restrict__ grad,
+                                                    const float* __restrict__ rois,
+                                                    const int* __restrict__ argmax,
+                                                    float* __restrict__ gin, int C, int H, int W,
+                                                    long total, int PH, int PW) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int a = argmax[idx];
+    if (a == -1) continue;
+    int c, n;
+    if (NHWC) {
+      c = (int)(idx % C);
+      n = (int)(idx / C / PW / PH);
+    } else {
+      c = (int)((idx / PW / PH) % C);
+      n = (int)(idx / PW / PH / C);
+    }
+    const int b = (int)rois[(size_t)n * 5];
+    float* dst = NHWC ? gin + ((size_t)b * H * W + a) * C + c : gin + ((size_t)b * C + c) * H * W + a;
+    atomicAdd(dst, grad[idx]);
+  }
+}
+
+inline int bit_words(int L) { return (L + 31) / 32; }
+
+struct Workspace { unsigned* cell; unsigned* roi; };
+
+inline Workspace carve(void* ws, int B, int H, int W, int L) {
+  Workspace k;
+  k.cell = reinterpret_cast<unsigned*>(ws);
+  size_t cell_bytes = (size_t)B * H * W * bit_words(L) * sizeof(unsigned);
+  cell_bytes = (cell_bytes + 15) & ~(size_t)15;
+  k.roi = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + cell_bytes);
+  return k;
+}
+
+int build_bits(const int* oh_labels, const int* superpixels, const Workspace& k, int B, int H,
+               int W, int M, int L, int Hs, int Ws, hipStream_t st) {
+  const int words = bit_words(L);
+  const long cells = (long)B * H * W;
+  hipLaunchKernelGGL(moi_cell_bits_kernel, dim3(ceil_div(cells, 4)), dim3(256),
+                     4 * words * sizeof(unsigned), st, superpixels, k.cell, B, H, W, Hs, Ws, L,
+                     words);
+  JTSM_CHECK_LAUNCH("moi_cell_bits");
+  const long tw = (long)M * words;
+  hipLaunchKernelGGL(moi_roi_bits_kernel, dim3(ceil_div(tw, 256)), dim3(256), 0, st, oh_labels,
+                     k.roi, tw, L, words);
+  JTSM_CHECK_LAUNCH("moi_roi_bits");
+  return JTSM_OK;
+}
+
+}  // namespace
+}  // namespace jtsm
+
+using namespace jtsm;
+
+extern "C" {
+
+size_t jtsm_moi_pool_workspace_bytes(int B, int H, int W, int M, int L) {
+  if (B < 0 || H < 0 || W < 0 || M < 0 || L < 0) return 0;
+  size_t cell = (size_t)B * H * W * bit_words(L) * sizeof(unsigned);
+  cell = (cell + 15) & ~(size_t)15;
+  return cell + (size_t)M * bit_words(L) * sizeof(unsigned) + 16;
+}
+
+int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32_t* oh_labels,
+                              const int32_t* superpixels, float* output, int32_t* argmax,
+                              void* workspace, int B, int C, int H, int W, int M, int L, int Hs,
+                              int Ws, float spatial_scale, int pooled_h, int pooled_w, int layout,
+                              void* stream) {
+  JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && L >= 0 && pooled_h > 0 && pooled_w > 0,
+               "moi_pool: negative size");
+  JTSM_REQUIRE(layout == JTSM_NCHW || layout == JTSM_NHWC, "moi_pool: unknown layout %d", layout);
+  if ((long)M * C * pooled_h * pooled_w == 0) return JTSM_OK;
+  JTSM_REQUIRE(input && rois && oh_labels && superpixels && output && argmax && workspace,
+               "moi_pool: null pointer");
+  JTSM_REQUIRE(B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && L > 0,
+               "moi_pool: empty feature map / superpixel map / label table");
+  JTSM_REQUIRE(((uintptr_t)workspace & 15) == 0, "moi_pool: workspace must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const Workspace k = carve(workspace, B, H, W, L);
+  int rc = build_bits(oh_labels, superpixels, k, B, H, W, M, L, Hs, Ws, st);
+  if (rc) return rc;
+  const int words = bit_words(L);
+  if (layout == JTSM_NHWC) {
+    const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
+    if (C % 4 == 0 && ((uintptr_t)input & 15) == 0)
+      hipLaunchKernelGGL(moi_pool_fwd_nhwc<4>, dim3(blocks), dim3(256), 0, st, input, rois, k.cell,
+                         k.roi, output, argmax, C, H, W, M, words, spatial_scale, pooled_h,
+                         pooled_w);
+    else
+      hipLaunchKernelGGL(moi_pool_fwd_nhwc<1>, dim3(blocks), dim3(256), 0, st, input, rois, k.cell,
+                         k.roi, output, argmax, C, H, W, M, words, spatial_scale, pooled_h,
+                         pooled_w);
+  } else {
+    const long total = (long)M * C * pooled_h * pooled_w;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(moi_pool_fwd_nchw, dim3(blocks), dim3(256), 0, st, input, rois, k.cell, k.roi,
+                       output, argmax, C, H, W, total, words, spatial_scale, pooled_h, pooled_w);
+  }
+  JTSM_CHECK_LAUNCH("moi_pool forward");
+  return JTSM_OK;
+}
+
+int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32_t* argmax,
+                               float* grad_input, int B, int C, int H, int W, int M, int pooled_h,
+                               int pooled_w, int layout, void* stream) {
+  JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0,
+               "moi_pool backward: negative size");
+  JTSM_REQUIRE(layout == JTSM_NCHW || layout == JTSM_NHWC, "moi_pool: unknown layout %d", layout);
+  hipStream_t st = as_stream(stream);
+  const size_t in_elems = (size_t)B * C * H * W;
+  if (in_elems == 0) return JTSM_OK;
+  JTSM_REQUIRE(grad_input, "moi_pool backward: null grad_input");
+  JTSM_CHECK_HIP(hipMemsetAsync(grad_input, 0, in_elems * sizeof(float), st));
+  const long total = (long)M * C * pooled_h * pooled_w;
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(grad && rois && argmax, "moi_pool backward: null pointer");
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  if (layout == JTSM_NHWC)
+    hipLaunchKernelGGL(moi_pool_bwd<true>, dim3(blocks), dim3(256), 0, st, grad, rois, argmax,
+                       grad_input, C, H, W, total, pooled_h, pooled_w);
+  else
+    hipLaunchKernelGGL(moi_pool_bwd<false>, dim3(blocks), dim3(256), 0, st, grad, rois, argmax,
+                       grad_input, C, H, W, total, pooled_h, pooled_w);
+  JTSM_CHECK_LAUNCH("moi_pool backward");
+  return JTSM_OK;
+}
+
+int jtsm_moi_mask_f32(const float* rois, const int32_t* oh_labels, const int32_t* superpixels,
+                      int32_t* mois, void* workspace, int B, int H, int W, int M, int L, int Hs,
+                      int Ws, float spatial_scale, void* stream) {
+  JTSM_REQUIRE(B > 0 && H > 0 && W > 0 && M >= 0 && L > 0 && Hs > 0 && Ws > 0, "moi_mask: bad sizes");
+  if (M == 0) return JTSM_OK;
+  JTSM_REQUIRE(rois && oh_labels && superpixels && mois && workspace, "moi_mask: null pointer");
+  hipStream_t st = as_stream(stream);
+  const Workspace k = carve(workspace, B, H, W, L);
+  int rc = build_bits(oh_labels, superpixels, k, B, H, W, M, L, Hs, Ws, st);
+  if (rc) return rc;
+  const long total = (long)M * H * W;
+  hipLaunchKernelGGL(moi_mask_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, rois, k.cell,
+                     k.roi, mois, H, W, total, bit_words(L), spatial_scale);
+  JTSM_CHECK_LAUNCH("moi_mask");
+  return JTSM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,251 @@
+"""GPU suite (pytest -m gpu): the HIP pooling kernels, called through the C ABI via the
+jtsm_amd.layers mirrors, against the oracle and the committed reference vectors.
+
+Bar: integer results (sample grid, tap indices, argmax, mois) bit-exact; forward VALUES are
+also required bit-exact (same summation order, contraction off); backward uses float atomics
+(order-dependent rounding) -> rtol 1e-5 / atol 1e-6 in fp32, 1e-12 in fp64.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_cases
+from oracle import pooling as P
+
+pytestmark = pytest.mark.gpu
+
+from jtsm_amd import _lib as L  # noqa: E402
+from jtsm_amd.layers import MOIPool, ROIAlign, ROIAlignRotated  # noqa: E402
+
+KAT = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "kat_reference_tests.npz"))
+
+
+def dev(a, cuda, channels_last=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+    if channels_last:
+        t = t.contiguous(memory_format=torch.channels_last)
+    return t
+
+
+def run_align(x, rois, scale, PH, PW, sr, aligned, cuda, nhwc, g=None, rotated=False):
+    xt = dev(x, cuda, nhwc).requires_grad_(g is not None)
+    op = ROIAlignRotated((PH, PW), scale, sr) if rotated else ROIAlign((PH, PW), scale, sr, aligned)
+    y = op(xt, dev(rois, cuda))
+    if nhwc and y.numel():
+        assert y.is_contiguous(memory_format=torch.channels_last)
+    gx = None
+    if g is not None:
+        y.backward(dev(g, cuda, nhwc))
+        gx = xt.grad.cpu().numpy()
+    return y.detach().cpu().numpy(), gx
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_kat_tables(cuda, nhwc):
+    img = KAT["image5x5"][None, None]
+    box = np.array([[0, *KAT["box"]]], np.float32)
+    y, _ = run_align(img, box, 1.0, 4, 4, 0, False, cuda, nhwc)
+    assert np.allclose(y[0, 0], KAT["legacy_4x4"])
+    y, _ = run_align(img, box, 1.0, 4, 4, 0, True, cuda, nhwc)
+    assert np.allclose(y[0, 0], KAT["aligned_4x4"])
+    b = KAT["box"]
+    for i in range(4):
+        r = np.array([[0, (b[0] + b[2]) / 2, (b[1] + b[3]) / 2, b[2] - b[0], b[3] - b[1], 90 * i]], np.float32)
+        y, _ = run_align(img, r, 1.0, 4, 4, 0, True, cuda, nhwc, rotated=True)
+        exp = KAT["aligned_4x4"]
+        for _ in range((-i) % 4):
+            exp = exp.T[::-1]
+        assert np.allclose(y[0, 0], exp), i
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_empty_box_and_empty_batch(cuda, nhwc):
+    img = np.random.default_rng(0).random((1, 1, 5, 5)).astype(np.float32)
+    y, gx = run_align(img, np.array([[0, *KAT["empty_box"]]], np.float32), 1.0, 7, 7, 0, True, cuda, nhwc,
+                      g=np.ones((1, 1, 7, 7), np.float32))
+    assert (y == 0).all() and (gx == 0).all()
+    y, _ = run_align(img, np.array([[0, *KAT["rotated_empty_box"]]], np.float32), 1.0, 7, 7, 0, True, cuda,
+                     nhwc, rotated=True)
+    assert (y == 0).all()
+    op = ROIAlign((7, 7), 1.0, 0, aligned=True)
+    out = op(torch.zeros(0, 3, 10, 10, device=cuda), torch.zeros(0, 5, device=cuda))
+    assert out.shape == (0, 3, 7, 7)
+    out = op(torch.zeros(2, 3, 10, 10, device=cuda), torch.zeros(0, 5, device=cuda))
+    assert out.shape == (0, 3, 7, 7)
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("case", sorted(load_cases("roi_align_ref.npz")))
+def test_roi_align_vs_reference_vectors(cuda, case, nhwc):
+    c = load_cases("roi_align_ref.npz")[case]
+    scale, PH, PW, sr, al = c["meta"]
+    y, gx = run_align(c["x"], c["rois"], float(scale), int(PH), int(PW), int(sr), bool(al), cuda, nhwc,
+                      g=c["g"])
+    assert np.array_equal(y, c["y"]), np.abs(y - c["y"]).max()
+    tol = dict(rtol=1e-5, atol=1e-5) if c["x"].dtype == np.float32 else dict(rtol=1e-12, atol=1e-12)
+    assert np.allclose(gx, c["gx"], **tol), np.abs(gx - c["gx"]).max()
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("case", sorted(load_cases("roi_align_rotated_ref.npz")))
+def test_roi_align_rotated_vs_reference_vectors(cuda, case, nhwc):
+    c = load_cases("roi_align_rotated_ref.npz")[case]
+    scale, PH, PW, sr = c["meta"]
+    y, gx = run_align(c["x"], c["rois"], float(scale), int(PH), int(PW), int(sr), True, cuda, nhwc,
+                      g=c["g"], rotated=True)
+    assert np.array_equal(y, c["y"]), np.abs(y - c["y"]).max()
+    tol = dict(rtol=1e-5, atol=1e-5) if c["x"].dtype == np.float32 else dict(rtol=1e-12, atol=1e-12)
+    assert np.allclose(gx, c["gx"], **tol)
+
+
+def _fpn_like_rois(rng, M, B, size):
+    x0, y0 = rng.uniform(0, size * 0.75, M), rng.uniform(0, size * 0.75, M)
+    w = np.exp(rng.uniform(np.log(16), np.log(size / 2), M))
+    h = np.exp(rng.uniform(np.log(16), np.log(size / 2), M))
+    return np.stack([rng.integers(0, B, M), x0, y0, np.minimum(x0 + w, size), np.minimum(y0 + h, size)],
+                    1).astype(np.float32)
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+def test_sample_tables_bit_exact(cuda, rotated):
+    """The 'bit-exact ROI bin indices' contract: grid sizes, the 4 tap indices and the 4 weights of
+    every sample equal the oracle's, for boxes spanning all FPN scales incl. borders."""
+    rng = np.random.default_rng(1234)
+    H, W, scale, PH, PW = 64, 80, 1.0 / 16, 7, 7
+    M = 256
+    r = _fpn_like_rois(rng, M, 1, 1024)
+    r[:8, 1:] = [[-40, -40, 30, 30], [1000, 990, 1300, 1400], [0, 0, 1280, 1024], [5, 5, 5, 5],
+                 [100.5, 200.25, 100.5, 900], [16, 16, 32, 32], [15.999, 16.001, 240, 33], [3, 4, 5, 4]]
+    if rotated:
+        r = np.concatenate([r[:, :1], (r[:, 1:3] + r[:, 3:5]) / 2, r[:, 3:5] - r[:, 1:3],
+                            rng.uniform(-180, 180, (M, 1)).astype(np.float32)], 1).astype(np.float32)
+        r[:4, 5] = [0, 90, 180, 270]
+    cap = 7 * 7 * 36
+    grid = torch.empty(M, 2, dtype=torch.int32, device=cuda)
+    pos = torch.empty(M, cap, 4, dtype=torch.int32, device=cuda)
+    w = torch.empty(M, cap, 4, dtype=torch.float32, device=cuda)
+    L.check(L.lib().jtsm_roi_sample_table_f32(L.ptr(dev(r, cuda)), int(rotated), M, H, W, L.f32(scale), PH,
+                                              PW, 0, 1, L.ptr(grid), L.ptr(pos), L.ptr(w), cap, L.stream()))
+    grid, pos, w = grid.cpu().numpy(), pos.cpu().numpy(), w.cpu().numpy()
+    checked = 0
+    for m in range(M):
+        g0, p0, w0 = P.roi_sample_table(r[m], rotated, H, W, scale, PH, PW, 0, True)
+        assert np.array_equal(grid[m], g0), (m, grid[m], g0)
+        n = min(len(p0), cap)
+        assert np.array_equal(pos[m, :n], p0[:n]), m
+        assert np.array_equal(w[m, :n].view(np.uint32), w0[:n].view(np.uint32)), m
+        checked += n
+    assert checked > 50000
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_config2_shape_forward_bit_exact_and_backward_close(cuda, nhwc):
+    """BASELINE configs[1] geometry on one FPN level (p3: 128x128, C=256) with 64 rois:
+    values bit-exact vs the oracle, 7x7 and 14x14."""
+    rng = np.random.default_rng(99)
+    B, Cc, H, W = 2, 256, 128, 128
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    r = _fpn_like_rois(rng, 64, B, 1024)
+    for res in (7, 14):
+        g = rng.standard_normal((64, Cc, res, res)).astype(np.float32)
+        y, gx = run_align(x, r, 0.125, res, res, 0, True, cuda, nhwc, g=g)
+        y0 = P.roi_align_forward(x, r, 0.125, res, res, 0, True)
+        assert np.array_equal(y, y0)
+        gx0 = P.roi_align_backward(g, r, 0.125, res, res, B, Cc, H, W, 0, True)
+        assert np.allclose(gx, gx0, rtol=1e-4, atol=1e-4), np.abs(gx - gx0).max()
+
+
+def test_full_size_properties(cuda):
+    """configs[1] at full size (8 x 256 x 256 x 256 NHWC, 512 rois): properties that need no oracle.
+    (1) linearity in the input, (2) a constant map pools to that constant where all samples are
+    inside, (3) NHWC and NCHW kernels agree bit for bit, (4) sum(backward(1)) == #valid samples /
+    count per bin == number of non-empty bins."""
+    rng = np.random.default_rng(5)
+    B, Cc, H, W, M = 8, 256, 256, 256, 512
+    gen = torch.Generator(device=cuda).manual_seed(0)
+    x = torch.randn(B, Cc, H, W, device=cuda, generator=gen).contiguous(memory_format=torch.channels_last)
+    r_np = _fpn_like_rois(rng, M, B, 1024)
+    r = torch.from_numpy(r_np).to(cuda)
+    op = ROIAlign((7, 7), 0.25, 0, aligned=True)
+    y = op(x, r)
+    y2 = op(2.5 * x, r)
+    assert torch.allclose(y2, 2.5 * y, rtol=1e-5, atol=1e-5)
+    ones = torch.ones_like(x)
+    yc = op(ones, r)
+    inside = (r[:, 1] > 4) & (r[:, 2] > 4) & (r[:, 3] < 1016) & (r[:, 4] < 1016)
+    assert torch.allclose(yc[inside], torch.ones_like(yc[inside]), atol=1e-5)
+    sub = slice(0, 64)
+    y_nchw = op(x.contiguous(), r[sub])
+    assert torch.equal(y_nchw, y[sub].contiguous())
+    xg = torch.ones(1, 4, H, W, device=cuda).contiguous(memory_format=torch.channels_last).requires_grad_()
+    r1 = r.clone()
+    r1[:, 0] = 0
+    op(xg, r1).sum().backward()
+    per_roi_bins = 49.0
+    assert abs(xg.grad.sum().item() / 4 - M * per_roi_bins) < 1e-2 * M
+
+
+# ----------------------------------------------------------------------------- MOIPool
+def run_moi(c, cuda, nhwc, scale, PH, PW, g=None):
+    x = dev(c["x"], cuda, nhwc).requires_grad_(g is not None)
+    op = MOIPool((PH, PW), scale)
+    y, a = op(x, dev(c["rois"], cuda), dev(c["oh"], cuda), dev(c["sp"], cuda))
+    gx = None
+    if g is not None:
+        y.backward(dev(g, cuda, nhwc))
+        gx = x.grad.cpu().numpy()
+    return y.detach().cpu().numpy(), a.cpu().numpy(), gx
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+@pytest.mark.parametrize("case", sorted(load_cases("moi_pool_oracle.npz")))
+def test_moi_pool_vs_oracle_vectors(cuda, case, nhwc):
+    c = load_cases("moi_pool_oracle.npz")[case]
+    scale, PH, PW = c["meta"]
+    y, a, gx = run_moi(c, cuda, nhwc, float(scale), int(PH), int(PW), g=c["g"])
+    assert np.array_equal(a, c["argmax"])
+    assert np.array_equal(y, c["y"])
+    assert np.allclose(gx, c["gx"], rtol=1e-5, atol=1e-5)
+
+
+def test_moi_mask_bit_exact(cuda):
+    c = load_cases("moi_pool_oracle.npz")["a_stride4"]
+    B, Cc, H, W = c["x"].shape
+    M, Lw = c["oh"].shape
+    Hs, Ws = c["sp"].shape[1:]
+    mois = torch.empty(M, H, W, dtype=torch.int32, device=cuda)
+    ws = torch.empty(L.lib().jtsm_moi_pool_workspace_bytes(B, H, W, M, Lw), dtype=torch.uint8, device=cuda)
+    L.check(L.lib().jtsm_moi_mask_f32(L.ptr(dev(c["rois"], cuda)), L.ptr(dev(c["oh"], cuda)),
+                                      L.ptr(dev(c["sp"], cuda)), L.ptr(mois), L.ptr(ws), B, H, W, M, Lw, Hs,
+                                      Ws, L.f32(0.25), L.stream()))
+    assert np.array_equal(mois.cpu().numpy(), P.moi_mask(c["rois"], c["oh"], c["sp"], H, W, 0.25))
+
+
+@pytest.mark.parametrize("nhwc", [False, True])
+def test_moi_pool_jtsm_shape(cuda, nhwc):
+    """configs[2] geometry on one level (p3, C=256, 1024 superpixels of 32x32 px, 200 rois):
+    argmax and values bit-exact vs the oracle; >32 label words exercises the multi-word path."""
+    rng = np.random.default_rng(77)
+    B, Cc, H, W, stride = 2, 256, 64, 64, 8
+    Hs = Ws = H * stride
+    ids = (np.arange(Hs)[:, None] // 16) * (Ws // 16) + (np.arange(Ws)[None, :] // 16)
+    sp = np.stack([ids, np.roll(ids, (5, 9), (0, 1))]).astype(np.int32)
+    Lw = int(ids.max()) + 1
+    assert Lw == 1024
+    M = 200
+    r = _fpn_like_rois(rng, M, B, Hs)
+    cy, cx = (np.arange(Hs // 16) * 16 + 8), (np.arange(Ws // 16) * 16 + 8)
+    oh = np.zeros((M, Lw), np.int32)
+    for m in range(M):
+        iny = (cy >= r[m, 2]) & (cy <= r[m, 4])
+        inx = (cx >= r[m, 1]) & (cx <= r[m, 3])
+        oh[m] = (iny[:, None] & inx[None, :]).ravel()
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    c = dict(x=x, rois=r, oh=oh, sp=sp)
+    g = rng.standard_normal((M, Cc, 7, 7)).astype(np.float32)
+    y, a, gx = run_moi(c, cuda, nhwc, 1.0 / stride, 7, 7, g=g)
+    y0, a0 = P.moi_pool_forward(x, r, 1.0 / stride, 7, 7, oh, sp)
+    assert np.array_equal(a, a0) and np.array_equal(y, y0)
+    gx0 = P.moi_pool_backward(g, r, a0, 1.0 / stride, 7, 7, B, Cc, H, W)
+    assert np.allclose(gx, gx0, rtol=1e-4, atol=1e-4)
+    assert (a0 >= 0).mean() > 0.3  # the case is not degenerate
