@@ -136,6 +136,60 @@ int jtsm_moi_mask_f32(const float* rois, const int32_t* oh_labels, const int32_t
                       int32_t* mois, void* workspace, int B, int H, int W, int M, int L, int Hs,
                       int Ws, float spatial_scale, void* stream);
 
+
+/* ---------------------------------------------------------------------------
+ * Convolution / linear layers on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+ * The reference has no source for these: it calls ATen/cuDNN through F.conv2d /
+ * nn.Linear at detectron2/layers/wrappers.py:76-78 (Conv2d.forward),
+ * detectron2/modeling/backbone/resnet.py:195-211,355-359, fpn.py:127-152,
+ * projects/WSL/wsl/modeling/roi_heads/box_head.py:90-93, mask_head.py:339-343,
+ * detectron2/modeling/meta_arch/semantic_seg.py:170-177.  These entry points replace that
+ * call and fuse what the reference runs as separate passes behind it (FrozenBatchNorm2d
+ * affine, batch_norm.py:45-66; shortcut add and ReLU, resnet.py:203-210).
+ *
+ * Layouts: activations NHWC (batch, h, w, c) dense; weights OHWI = [out_c][kh][kw][in_c]
+ * dense (a torch (O,I,kh,kw) weight stored channels_last is exactly this).  nn.Linear's
+ * [out][in] weight is the 1x1 case with in_h = in_w = 1, batch = rows.
+ * in_c must be a multiple of 4 (pad RGB to 4 channels); backward also needs out_c % 4 == 0.
+ * All pointers 16-byte aligned.
+ * ------------------------------------------------------------------------- */
+typedef struct jtsm_conv_shape {
+  int batch, in_h, in_w, in_c; /* input  (batch, in_h, in_w, in_c)            */
+  int out_c;                   /* output (batch, out_h, out_w, out_c)          */
+  int kernel_h, kernel_w;      /* out_h = (in_h + 2*pad - dilation*(kernel_h-1) - 1)/stride + 1 */
+  int stride, pad, dilation;
+} jtsm_conv_shape;
+
+int jtsm_conv_out_size(const jtsm_conv_shape* s, int* out_h, int* out_w);
+
+/* y = relu?( conv(x, w) * scale[c] + bias[c] + residual ).  scale, bias, residual may be NULL;
+ * residual has y's shape and may alias y. */
+int jtsm_conv2d_forward_f32(const float* x, const float* w, float* y, const jtsm_conv_shape* s,
+                            const float* scale, const float* bias, const float* residual,
+                            int relu, void* stream);
+/* dx = conv_transpose(dy * kscale[out_c], w) (+ accumulate), then zeroed where
+ * relu_mask <= 0.  kscale (per out_c; the FrozenBN scale of this conv), accumulate and
+ * relu_mask (both dx-shaped; accumulate may alias dx) may be NULL. */
+int jtsm_conv2d_backward_data_f32(const float* dy, const float* w, float* dx,
+                                  const jtsm_conv_shape* s, const float* kscale,
+                                  const float* accumulate, const float* relu_mask, void* stream);
+/* dw[o][kh][kw][i] (+)= row_scale[o] * sum_pixels dy[p][o] * x[pix(p,kh,kw)][i].
+ * zero_dw != 0 clears dw first; otherwise the result is added to what dw holds.  Split over
+ * the pixel axis with float atomics: the last bits depend on arrival order. */
+int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
+                                    const jtsm_conv_shape* s, const float* row_scale, int zero_dw,
+                                    void* stream);
+
+
+/* ---------------------------------------------------------------------------
+ * Bandwidth-bound helpers (no reference source: torch elementwise ops behind
+ * F.relu_ / autograd, e.g. detectron2/modeling/backbone/resnet.py:196-210).
+ * ------------------------------------------------------------------------- */
+/* g[i] = y[i] > 0 ? dy[i] : 0   (y = the ReLU's output). */
+int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, void* stream);
+/* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
+int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+"""GPU suite: fp32-MFMA implicit-GEMM convolution / linear kernels vs the torch-CPU oracle
+(oracle/nnref.py).  Bar (BASELINE.json): fp32 convs within 1e-4 relative.  The metric used is
+max|a-b| / max|b| per tensor (<= 1e-4), plus an element-wise allclose with rtol 1e-4 and an atol
+scaled to the tensor's magnitude.  Products are exact fp32 in both; only summation order differs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nnref
+
+pytestmark = pytest.mark.gpu
+
+from jtsm_amd.layers import conv as K  # noqa: E402
+from jtsm_amd.layers.elementwise import channel_sum, relu_backward  # noqa: E402
+
+CL = torch.channels_last
+REL = 1e-4
+
+
+def close(a, b, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    ref = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= REL * ref, "%s: max err %.3e vs max ref %.3e (rel %.2e)" % (what, err, ref, err / ref)
+
+
+CASES = [
+    # name,            N, C,  H,  W,  O,  k, s, p, d
+    ("1x1",            2, 64, 20, 24, 256, 1, 1, 0, 1),
+    ("1x1_s2",         2, 256, 21, 18, 128, 1, 2, 0, 1),
+    ("3x3",            2, 64, 19, 23, 64, 3, 1, 1, 1),
+    ("3x3_wide",       1, 128, 16, 16, 128, 3, 1, 1, 1),
+    ("3x3_dil2",       1, 64, 17, 15, 128, 3, 1, 2, 2),
+    ("3x3_s2",         1, 32, 17, 18, 96, 3, 2, 1, 1),
+    ("stem7x7",        2, 4, 37, 41, 64, 7, 2, 3, 1),
+    ("ntail80",        3, 256, 14, 14, 80, 1, 1, 0, 1),
+    ("ntail54",        1, 128, 32, 32, 54, 1, 1, 0, 1),
+    ("small_k",        1, 8, 9, 9, 12, 3, 1, 1, 1),
+]
+
+
+def make(case, seed=0):
+    _, N, C_, H, W, O, k, s, p, d = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, C_, H, W, generator=g)
+    w = torch.randn(O, C_, k, k, generator=g) * (2.0 / (C_ * k * k)) ** 0.5
+    return x, w, s, p, d
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_forward_plain_and_fused(cuda, case):
+    x, w, s, p, d = make(case)
+    O = w.shape[0]
+    g = torch.Generator().manual_seed(1)
+    scale, bias = torch.rand(O, generator=g) + 0.5, torch.randn(O, generator=g)
+    y0 = nnref.conv_bn_act(x, w, s, p, d)
+    res = torch.randn(y0.shape, generator=g)
+    xd, wd = x.to(cuda).contiguous(memory_format=CL), w.to(cuda).contiguous(memory_format=CL)
+    y = K.conv2d_forward(xd, wd, s, p, d)
+    assert y.is_contiguous(memory_format=CL)
+    close(y, y0, "plain")
+    y = K.conv2d_forward(xd, wd, s, p, d, scale.to(cuda), bias.to(cuda), res.to(cuda), True)
+    close(y, nnref.conv_bn_act(x, w, s, p, d, scale, bias, res, True), "fused")
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[5] % 4 == 0], ids=[c[0] for c in CASES if c[5] % 4 == 0])
+def test_conv_backward_data_and_weight(cuda, case):
+    x, w, s, p, d = make(case)
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    O = w.shape[0]
+    g = torch.Generator().manual_seed(2)
+    scale = torch.rand(O, generator=g) + 0.5
+    y0 = nnref.conv_bn_act(x, w, s, p, d, scale)
+    dy = torch.randn(y0.shape, generator=g)
+    y0.backward(dy)
+    dyd = dy.to(cuda).contiguous(memory_format=CL)
+    xd, wd = x.detach().to(cuda).contiguous(memory_format=CL), w.detach().to(cuda).contiguous(memory_format=CL)
+    dx = K.conv2d_backward_data(dyd, wd, tuple(x.shape), s, p, d, kscale=scale.to(cuda))
+    close(dx, x.grad, "dgrad")
+    dw = K.conv2d_backward_weight(dyd, xd, tuple(w.shape), s, p, d, row_scale=scale.to(cuda))
+    assert dw.is_contiguous(memory_format=CL)
+    close(dw, w.grad, "wgrad")
+    # accumulate + relu gate epilogue of dgrad
+    acc = torch.randn(x.shape, generator=g)
+    gate = torch.randn(x.shape, generator=g)
+    dx2 = K.conv2d_backward_data(dyd, wd, tuple(x.shape), s, p, d, kscale=scale.to(cuda),
+                                 accumulate=acc.to(cuda), relu_mask=gate.to(cuda))
+    close(dx2, (x.grad + acc) * (gate > 0), "dgrad+acc+gate")
+
+
+def test_autograd_bottleneck_like_chain(cuda):
+    """conv1x1-bn-relu -> conv3x3-bn-relu -> conv1x1-bn (+shortcut) relu, all through
+    conv2d_fused, gradients vs torch-CPU autograd of the same graph."""
+    g = torch.Generator().manual_seed(3)
+    N, C0, C1, H, W = 2, 64, 32, 14, 12
+    x = torch.randn(N, C0, H, W, generator=g, requires_grad=True)
+    ws = [torch.randn(C1, C0, 1, 1, generator=g) * 0.2, torch.randn(C1, C1, 3, 3, generator=g) * 0.1,
+          torch.randn(C0, C1, 1, 1, generator=g) * 0.2]
+    for t in ws:
+        t.requires_grad_(True)
+    sb = [(torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1) for c in (C1, C1, C0)]
+    o = nnref.conv_bn_act(x, ws[0], 1, 0, 1, *sb[0], None, True)
+    o = nnref.conv_bn_act(o, ws[1], 1, 1, 1, *sb[1], None, True)
+    y0 = nnref.conv_bn_act(o, ws[2], 1, 0, 1, *sb[2], x, True)
+    dy = torch.randn(y0.shape, generator=g)
+    y0.backward(dy)
+
+    xd = x.detach().to(cuda).contiguous(memory_format=CL).requires_grad_(True)
+    wd = [t.detach().to(cuda).contiguous(memory_format=CL).requires_grad_(True) for t in ws]
+    sbd = [(a.to(cuda), b.to(cuda)) for a, b in sb]
+    o = K.conv2d_fused(xd, wd[0], *sbd[0], None, 1, 0, 1, True)
+    o = K.conv2d_fused(o, wd[1], *sbd[1], None, 1, 1, 1, True)
+    y = K.conv2d_fused(o, wd[2], *sbd[2], xd, 1, 0, 1, True)
+    close(y, y0, "fwd")
+    y.backward(dy.to(cuda))
+    close(xd.grad, x.grad, "dx")
+    for i in range(3):
+        close(wd[i].grad, ws[i].grad, "dw%d" % i)
+
+
+def test_linear_dan_shape_slice(cuda):
+    """DAN fc1 geometry (K = 256*7*7 = 12544 -> 2048) on a slice of rows, + bias + relu + grads."""
+    g = torch.Generator().manual_seed(4)
+    R, Kd, O = 192, 12544, 256
+    x = torch.randn(R, Kd, generator=g, requires_grad=True)
+    w = (torch.randn(O, Kd, generator=g) * 0.005).requires_grad_(True)
+    b = torch.full((O,), 0.1, requires_grad=True)
+    y0 = nnref.linear(x, w, b, True)
+    dy = torch.randn(y0.shape, generator=g)
+    y0.backward(dy)
+    xd = x.detach().to(cuda).requires_grad_(True)
+    wd = w.detach().to(cuda).requires_grad_(True)
+    bd = b.detach().to(cuda).requires_grad_(True)
+    y = K.linear_fused(xd, wd, bd, True)
+    close(y, y0, "fc fwd")
+    y.backward(dy.to(cuda))
+    close(xd.grad, x.grad, "fc dx")
+    close(wd.grad, w.grad, "fc dw")
+    close(bd.grad, b.grad, "fc db")
+
+
+def test_backbone_layer_shapes_vs_torch_gpu(cuda):
+    """Full-size layers of R50-FPN at 2 x 1024^2 (res3 3x3, res4 1x1, FPN output 3x3 at p3) against
+    torch's own GPU convolution on the same NHWC tensors (fp32)."""
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    for (C_, O, HW, k, s, p) in [(128, 128, 128, 3, 1, 1), (1024, 256, 64, 1, 1, 0), (256, 256, 128, 3, 1, 1),
+                                  (512, 1024, 128, 1, 2, 0)]:
+        x = torch.randn(2, C_, HW, HW, device=cuda, generator=gen).contiguous(memory_format=CL)
+        w = (torch.randn(O, C_, k, k, device=cuda, generator=gen) * (2.0 / (C_ * k * k)) ** 0.5).contiguous(memory_format=CL)
+        y = K.conv2d_forward(x, w, s, p, 1)
+        y0 = torch.nn.functional.conv2d(x.double(), w.double(), None, s, p)
+        close(y, y0, "fwd %s" % ((C_, O, HW, k),))
+        dy = torch.randn(y.shape, device=cuda, generator=gen).contiguous(memory_format=CL)
+        dx0, dw0 = torch.autograd.grad(
+            torch.nn.functional.conv2d(x.double().requires_grad_(), w.double().requires_grad_(), None, s, p),
+            [], dy.double(), allow_unused=True) if False else (None, None)
+        xr, wr = x.double().requires_grad_(), w.double().requires_grad_()
+        torch.nn.functional.conv2d(xr, wr, None, s, p).backward(dy.double())
+        close(K.conv2d_backward_data(dy, w, tuple(x.shape), s, p, 1), xr.grad, "dgrad")
+        close(K.conv2d_backward_weight(dy, x, tuple(w.shape), s, p, 1), wr.grad, "wgrad")
+
+
+def test_relu_backward_and_channel_sum(cuda):
+    g = torch.Generator().manual_seed(6)
+    y = torch.randn(3, 20, 7, 9, generator=g).to(cuda).contiguous(memory_format=CL)
+    dy = torch.randn(3, 20, 7, 9, generator=g).to(cuda).contiguous(memory_format=CL)
+    assert torch.equal(relu_backward(dy, y), dy * (y > 0))
+    close(channel_sum(dy), dy.sum((0, 2, 3)), "channel_sum")
+    m = torch.randn(1000, 133, generator=g).to(cuda)
+    close(channel_sum(m), m.sum(0), "channel_sum 2d")
