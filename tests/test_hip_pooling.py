@@ -124,7 +124,8 @@ def test_sample_tables_bit_exact(cuda, rotated):
     grid = torch.empty(M, 2, dtype=torch.int32, device=cuda)
     pos = torch.empty(M, cap, 4, dtype=torch.int32, device=cuda)
     w = torch.empty(M, cap, 4, dtype=torch.float32, device=cuda)
-    L.check(L.lib().jtsm_roi_sample_table_f32(L.ptr(dev(r, cuda)), int(rotated), M, H, W, L.f32(scale), PH,
+    rd = dev(r, cuda)  # keep alive: a temporary would hand its block back to the allocator
+    L.check(L.lib().jtsm_roi_sample_table_f32(L.ptr(rd), int(rotated), M, H, W, L.f32(scale), PH,
                                               PW, 0, 1, L.ptr(grid), L.ptr(pos), L.ptr(w), cap, L.stream()))
     grid, pos, w = grid.cpu().numpy(), pos.cpu().numpy(), w.cpu().numpy()
     checked = 0
@@ -215,9 +216,9 @@ def test_moi_mask_bit_exact(cuda):
     Hs, Ws = c["sp"].shape[1:]
     mois = torch.empty(M, H, W, dtype=torch.int32, device=cuda)
     ws = torch.empty(L.lib().jtsm_moi_pool_workspace_bytes(B, H, W, M, Lw), dtype=torch.uint8, device=cuda)
-    L.check(L.lib().jtsm_moi_mask_f32(L.ptr(dev(c["rois"], cuda)), L.ptr(dev(c["oh"], cuda)),
-                                      L.ptr(dev(c["sp"], cuda)), L.ptr(mois), L.ptr(ws), B, H, W, M, Lw, Hs,
-                                      Ws, L.f32(0.25), L.stream()))
+    rd, ohd, spd = dev(c["rois"], cuda), dev(c["oh"], cuda), dev(c["sp"], cuda)  # keep alive
+    L.check(L.lib().jtsm_moi_mask_f32(L.ptr(rd), L.ptr(ohd), L.ptr(spd), L.ptr(mois), L.ptr(ws), B, H, W, M,
+                                      Lw, Hs, Ws, L.f32(0.25), L.stream()))
     assert np.array_equal(mois.cpu().numpy(), P.moi_mask(c["rois"], c["oh"], c["sp"], H, W, 0.25))
 
 
