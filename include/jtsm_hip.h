@@ -190,6 +190,67 @@ int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, vo
 /* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);
 
+
+/* NHWC spatial helpers, C % 4 == 0 (no reference source; torch ops at
+ * detectron2/modeling/backbone/resnet.py:358 (max_pool2d 3,2,1), fpn.py:133-136
+ * (interpolate nearest x2 + add), fpn.py:173-185 (max_pool2d 1,2,0)). */
+int jtsm_maxpool3x3s2_forward_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* gx is zero-filled by the call; the gradient goes to the first maximum of each window. */
+int jtsm_maxpool3x3s2_backward_f32(const float* x, const float* gy, float* gx, int N, int H, int W,
+                                   int C, void* stream);
+/* out(N,H,W,C) = lateral(N,H,W,C) + top(N,H/2,W/2,C) repeated 2x2. */
+int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, int N, int H, int W,
+                           int C, void* stream);
+/* out(N,Ht,Wt,C) = sum over the 2x2 blocks of g(N,2Ht,2Wt,C): backward of the x2 upsample. */
+int jtsm_sum2x2_f32(const float* g, float* out, int N, int Ht, int Wt, int C, void* stream);
+/* scatter=0: dst(N,Ho,Wo,C) = src(N,H,W,C)[:, ::2, ::2]; scatter=1: dst(N,H,W,C) zero-filled, then
+ * dst[:, ::2, ::2] = src(N,Ho,Wo,C).  Ho = (H-1)/2+1. */
+int jtsm_subsample2_f32(const float* src, float* dst, int N, int H, int W, int C, int scatter,
+                        void* stream);
+
+
+/* ---------------------------------------------------------------------------
+ * Multiple-instance-learning losses of projects/WSL, fused forward + analytic backward.
+ * No native reference: they replace PyTorch arithmetic at
+ *   fast_rcnn_tsm.py:573-586 (scores = softmax(C,1) * per-image softmax(D,0)),
+ *   :840-854 / :346-379 (image probabilities = clamp(sum over the image's proposals), BCE)
+ *   fast_rcnn_oicr.py:282-298 (weighted CE / #valid), :350-380 (weighted L1 on the gt-class
+ *   deltas / R, Box2BoxTransform weights (10,10,5,5), detectron2/modeling/box_regression.py:38-71)
+ * (all under projects/WSL/wsl/modeling/roi_heads/).  Rows of image i are
+ * [bag_offsets[i], bag_offsets[i+1]).  Logit matrices are row-major with leading dimension
+ * `ld*` (columns of a wider fused predictor output are fine).  nc, num_cls <= 192.
+ * ------------------------------------------------------------------------- */
+size_t jtsm_mil_workspace_bytes(int nbags, int max_bag_rows, int nc);
+/* scores (R,nc) dense; img_probs (nbags,nc) clamped to [1e-6, 1-1e-6]; loss: 1 float
+ * (mean over nbags*nc when mean_loss, else sum/nbags).  labels (nbags,nc) float 0/1.
+ * The workspace keeps what the backward needs and must stay untouched until then. */
+int jtsm_mil_forward_f32(const float* cls_logits, const float* det_logits, int ld, int nc,
+                         const int32_t* bag_offsets, int nbags, int max_bag_rows,
+                         const float* labels, int mean_loss, float* scores, float* img_probs,
+                         float* loss, void* workspace, void* stream);
+/* d_cls/d_det (R, nc) with leading dimension ld_grad = upstream[0] * dloss/dlogits
+ * (upstream NULL = 1). */
+int jtsm_mil_backward_f32(const float* cls_logits, const float* det_logits, int ld, int nc,
+                          const int32_t* bag_offsets, int nbags, int max_bag_rows,
+                          const float* upstream, float* d_cls, float* d_det, int ld_grad,
+                          const void* workspace, void* stream);
+
+size_t jtsm_oicr_workspace_bytes(void);
+/* labels (R) int32 in [-1, num_cls-1] (num_cls-1 = background, -1 = ignored); weights (R);
+ * proposals / gt_boxes (R,4) xyxy.  box_deltas (R, 4*(num_cls-1)) may be NULL (no box branch).
+ * losses[0] = loss_cls, losses[1] = loss_box_reg, losses[2] = #rows with weight > 1e-12. */
+int jtsm_oicr_forward_f32(const float* cls_logits, int ld_cls, int num_cls, const float* box_deltas,
+                          int ld_box, const int32_t* labels, const float* weights,
+                          const float* proposals, const float* gt_boxes, int R, float* losses,
+                          void* workspace, void* stream);
+/* d_cls (R,num_cls) with leading dimension ld_dcls, d_box (R,4*(num_cls-1)) with ld_dbox (may be NULL);
+ * up_cls / up_box: device scalars (NULL = 1); `losses` is the forward's output. */
+int jtsm_oicr_backward_f32(const float* cls_logits, int ld_cls, int num_cls, const float* box_deltas,
+                           int ld_box, const int32_t* labels, const float* weights,
+                           const float* proposals, const float* gt_boxes, int R, const float* losses,
+                           const float* up_cls, const float* up_box, float* d_cls, int ld_dcls,
+                           float* d_box, int ld_dbox, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

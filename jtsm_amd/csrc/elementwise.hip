@@ -1,4 +1,6 @@
 // Bandwidth-bound helpers around the contraction kernels (all NHWC, fp32, 16 B per lane).
+#include <cfloat>
+
 #include "common.h"
 
 namespace jtsm {
@@ -44,6 +46,117 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   if (wv == 0 && c < C) atomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
 }
 
+
+// ---- NHWC spatial helpers (C % 4 == 0: one float4 = 4 channels of one pixel) ---------------------
+__device__ __forceinline__ float4 f4max(float4 a, float4 b) {
+  return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// max_pool2d(kernel 3, stride 2, padding 1)  — BasicStem (resnet.py:355-359)
+__global__ __launch_bounds__(256) void maxpool3s2_fwd(const float4* __restrict__ x,
+                                                      float4* __restrict__ y, int N, int H, int W,
+                                                      int C4, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        m = f4max(m, x[((long)(n * H + ih) * W + iw) * C4 + c]);
+      }
+    }
+    y[i] = m;
+  }
+}
+// backward: recompute the first maximum of each window and add the gradient there
+__global__ __launch_bounds__(256) void maxpool3s2_bwd(const float* __restrict__ x,
+                                                      const float* __restrict__ gy,
+                                                      float* __restrict__ gx, int N, int H, int W,
+                                                      int C, int Ho, int Wo) {
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float m = -FLT_MAX;
+    long at = -1;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = oh * 2 - 1 + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = ow * 2 - 1 + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const long o = ((long)(n * H + ih) * W + iw) * C + c;
+        const float v = x[o];
+        if (v > m || at < 0) { m = v; at = o; }
+      }
+    }
+    if (at >= 0) atomicAdd(gx + at, gy[i]);
+  }
+}
+
+// out = lateral + nearest_upsample_x2(top)      (FPN top-down path, fpn.py:133-136)
+__global__ __launch_bounds__(256) void upsample2_add_fwd(const float4* __restrict__ top,
+                                                         const float4* __restrict__ lat,
+                                                         float4* __restrict__ out, int N, int H,
+                                                         int W, int C4) {
+  const long total = (long)N * H * W * C4;
+  const int Ht = H / 2, Wt = W / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    out[i] = f4add(lat[i], top[((long)(n * Ht + h / 2) * Wt + w / 2) * C4 + c]);
+  }
+}
+// d_top[n,h,w] = sum of the 2x2 block of g
+__global__ __launch_bounds__(256) void sum2x2_kernel(const float4* __restrict__ g,
+                                                     float4* __restrict__ out, int N, int Ht, int Wt,
+                                                     int C4) {
+  const long total = (long)N * Ht * Wt * C4;
+  const int W = Wt * 2, H = Ht * 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % Wt); t /= Wt;
+    const int h = (int)(t % Ht);
+    const int n = (int)(t / Ht);
+    const long b = ((long)(n * H + 2 * h) * W + 2 * w) * C4 + c;
+    out[i] = f4add(f4add(g[b], g[b + C4]), f4add(g[b + (long)W * C4], g[b + (long)W * C4 + C4]));
+  }
+}
+// y[n,h,w] = x[n,2h,2w]  (max_pool2d kernel 1 stride 2 = LastLevelMaxPool, fpn.py:173-185);
+// scatter=1 runs it backwards: x[n,2h,2w] = y[n,h,w] into a zero-filled x.
+__global__ __launch_bounds__(256) void subsample2_kernel(const float4* __restrict__ src,
+                                                         float4* __restrict__ dst, int N, int H, int W,
+                                                         int C4, int Ho, int Wo, int scatter) {
+  const long total = (long)N * Ho * Wo * C4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % Wo); t /= Wo;
+    const int h = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const long big = ((long)(n * H + 2 * h) * W + 2 * w) * C4 + c;
+    if (scatter) dst[big] = src[i]; else dst[i] = src[big];
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -85,6 +198,72 @@ int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* str
   hipLaunchKernelGGL(channel_sum_kernel, dim3(cgroups, (unsigned)((rows + rpb - 1) / rpb)), dim3(256),
                      0, st, g, out, rows, C, rpb);
   JTSM_CHECK_LAUNCH("channel_sum");
+  return JTSM_OK;
+}
+
+static inline int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
+
+int jtsm_maxpool3x3s2_forward_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "maxpool: bad sizes (C %% 4 != 0?)");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && y, "maxpool: null pointer");
+  hipLaunchKernelGGL(maxpool3s2_fwd, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const float4*)x, (float4*)y, N, H, W, C / 4, Ho, Wo);
+  JTSM_CHECK_LAUNCH("maxpool forward");
+  return JTSM_OK;
+}
+
+int jtsm_maxpool3x3s2_backward_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C,
+                                   void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0, "maxpool backward: bad sizes");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipStream_t st = as_stream(stream);
+  if ((long)N * H * W * C == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && gy && gx, "maxpool backward: null pointer");
+  JTSM_CHECK_HIP(hipMemsetAsync(gx, 0, (size_t)N * H * W * C * sizeof(float), st));
+  const long total = (long)N * Ho * Wo * C;
+  hipLaunchKernelGGL(maxpool3s2_bwd, dim3(grid_for(total)), dim3(256), 0, st, x, gy, gx, N, H, W, C, Ho, Wo);
+  JTSM_CHECK_LAUNCH("maxpool backward");
+  return JTSM_OK;
+}
+
+int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, int N, int H, int W, int C,
+                           void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0,
+               "upsample2_add: need even H, W and C %% 4 == 0");
+  const long total = (long)N * H * W * (C / 4);
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(top && lateral && out, "upsample2_add: null pointer");
+  hipLaunchKernelGGL(upsample2_add_fwd, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
+                     (const float4*)top, (const float4*)lateral, (float4*)out, N, H, W, C / 4);
+  JTSM_CHECK_LAUNCH("upsample2_add");
+  return JTSM_OK;
+}
+
+int jtsm_sum2x2_f32(const float* g, float* out, int N, int Ht, int Wt, int C, void* stream) {
+  JTSM_REQUIRE(N >= 0 && Ht > 0 && Wt > 0 && C > 0 && C % 4 == 0, "sum2x2: bad sizes");
+  const long total = (long)N * Ht * Wt * (C / 4);
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(g && out, "sum2x2: null pointer");
+  hipLaunchKernelGGL(sum2x2_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream), (const float4*)g,
+                     (float4*)out, N, Ht, Wt, C / 4);
+  JTSM_CHECK_LAUNCH("sum2x2");
+  return JTSM_OK;
+}
+
+int jtsm_subsample2_f32(const float* src, float* dst, int N, int H, int W, int C, int scatter, void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "subsample2: bad sizes");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const long total = (long)N * Ho * Wo * (C / 4);
+  hipStream_t st = as_stream(stream);
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(src && dst, "subsample2: null pointer");
+  if (scatter) JTSM_CHECK_HIP(hipMemsetAsync(dst, 0, (size_t)N * H * W * C * sizeof(float), st));
+  hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float4*)src,
+                     (float4*)dst, N, H, W, C / 4, Ho, Wo, scatter);
+  JTSM_CHECK_LAUNCH("subsample2");
   return JTSM_OK;
 }
 

@@ -37,3 +37,88 @@ def channel_sum(g):
     out = torch.empty(ch, dtype=g.dtype, device=g.device)
     L.check(L.lib().jtsm_channel_sum_f32(L.ptr(g), L.ptr(out), C.c_long(rows), ch, L.stream()), "channel_sum")
     return out
+
+
+def _cl4(x):
+    if x.dim() != 4 or x.shape[1] % 4:
+        raise RuntimeError("jtsm_amd spatial helpers need a (N,C,H,W) tensor with C %% 4 == 0, got %s" % (tuple(x.shape),))
+    L.require_gpu(x)
+    return x.contiguous(memory_format=CL)
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl4(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=CL)
+        L.check(L.lib().jtsm_maxpool3x3s2_forward_f32(L.ptr(x), L.ptr(y), n, h, w, c, L.stream()), "maxpool")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        gy = gy.contiguous(memory_format=CL)
+        gx = torch.empty_like(x)
+        L.check(L.lib().jtsm_maxpool3x3s2_backward_f32(L.ptr(x), L.ptr(gy), L.ptr(gx), n, h, w, c, L.stream()),
+                "maxpool backward")
+        return gx
+
+
+def max_pool_3x3_s2(x):
+    """F.max_pool2d(x, kernel_size=3, stride=2, padding=1) on a channels_last tensor."""
+    return _MaxPool3s2.apply(x)
+
+
+class _Upsample2Add(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, top, lateral):
+        top, lateral = _cl4(top), _cl4(lateral)
+        n, c, h, w = lateral.shape
+        if top.shape != (n, c, h // 2, w // 2) or h % 2 or w % 2:
+            raise RuntimeError("upsample2_add: lateral %s is not 2x top %s" % (tuple(lateral.shape), tuple(top.shape)))
+        out = torch.empty_like(lateral)
+        L.check(L.lib().jtsm_upsample2_add_f32(L.ptr(top), L.ptr(lateral), L.ptr(out), n, h, w, c, L.stream()),
+                "upsample2_add")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous(memory_format=CL)
+        n, c, h, w = g.shape
+        gt = None
+        if ctx.needs_input_grad[0]:
+            gt = torch.empty((n, c, h // 2, w // 2), dtype=g.dtype, device=g.device, memory_format=CL)
+            L.check(L.lib().jtsm_sum2x2_f32(L.ptr(g), L.ptr(gt), n, h // 2, w // 2, c, L.stream()), "sum2x2")
+        return gt, (g if ctx.needs_input_grad[1] else None)
+
+
+def upsample2_add(top, lateral):
+    """lateral + F.interpolate(top, scale_factor=2, mode="nearest")."""
+    return _Upsample2Add.apply(top, lateral)
+
+
+class _Subsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl4(x)
+        n, c, h, w = x.shape
+        ctx.shape = (n, c, h, w)
+        y = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=x.dtype, device=x.device, memory_format=CL)
+        L.check(L.lib().jtsm_subsample2_f32(L.ptr(x), L.ptr(y), n, h, w, c, 0, L.stream()), "subsample2")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, c, h, w = ctx.shape
+        g = g.contiguous(memory_format=CL)
+        gx = torch.empty((n, c, h, w), dtype=g.dtype, device=g.device, memory_format=CL)
+        L.check(L.lib().jtsm_subsample2_f32(L.ptr(g), L.ptr(gx), n, h, w, c, 1, L.stream()), "subsample2 scatter")
+        return gx
+
+
+def subsample2(x):
+    """F.max_pool2d(x, kernel_size=1, stride=2, padding=0)."""
+    return _Subsample2.apply(x)

@@ -1,0 +1,6 @@
+"""Data ABI between model components (detectron2/structures): the subset the JTSM path touches."""
+from .boxes import Boxes, pairwise_iou
+from .image_list import ImageList
+from .instances import Instances
+
+__all__ = ["Boxes", "pairwise_iou", "ImageList", "Instances"]

@@ -171,3 +171,40 @@ def test_relu_backward_and_channel_sum(cuda):
     close(channel_sum(dy), dy.sum((0, 2, 3)), "channel_sum")
     m = torch.randn(1000, 133, generator=g).to(cuda)
     close(channel_sum(m), m.sum(0), "channel_sum 2d")
+
+
+def test_spatial_helpers_match_torch(cuda):
+    """max_pool 3x3/s2/p1, nearest-x2 + add, stride-2 subsample: bit-exact vs torch's own ops
+    (same arithmetic, no rounding freedom) incl. backward."""
+    import torch.nn.functional as F
+
+    from jtsm_amd.layers.elementwise import max_pool_3x3_s2, subsample2, upsample2_add
+
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 8, 13, 18, generator=g)
+    xd = x.to(cuda).contiguous(memory_format=CL).requires_grad_()
+    xr = x.clone().requires_grad_()
+    y, y0 = max_pool_3x3_s2(xd), F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(y.cpu(), y0)
+    gy = torch.randn(y0.shape, generator=g)
+    y.backward(gy.to(cuda)); y0.backward(gy)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, atol=1e-6)
+
+    top = torch.randn(2, 8, 5, 7, generator=g)
+    lat = torch.randn(2, 8, 10, 14, generator=g)
+    td, ld_ = top.to(cuda).requires_grad_(), lat.to(cuda).requires_grad_()
+    tr, lr = top.clone().requires_grad_(), lat.clone().requires_grad_()
+    o, o0 = upsample2_add(td, ld_), lr + F.interpolate(tr, scale_factor=2.0, mode="nearest")
+    assert torch.equal(o.cpu(), o0)
+    go = torch.randn(o0.shape, generator=g)
+    o.backward(go.to(cuda)); o0.backward(go)
+    assert torch.allclose(td.grad.cpu(), tr.grad, atol=1e-6) and torch.equal(ld_.grad.cpu(), lr.grad)
+
+    for hw in ((32, 32), (7, 9)):
+        x = torch.randn(1, 4, *hw, generator=g)
+        xd, xr = x.to(cuda).requires_grad_(), x.clone().requires_grad_()
+        s, s0 = subsample2(xd), F.max_pool2d(xr, 1, 2, 0)
+        assert torch.equal(s.cpu(), s0)
+        gs = torch.randn(s0.shape, generator=g)
+        s.backward(gs.to(cuda)); s0.backward(gs)
+        assert torch.equal(xd.grad.cpu(), xr.grad)

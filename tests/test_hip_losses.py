@@ -1,0 +1,78 @@
+"""GPU suite: fused MIL / OICR loss kernels vs the torch-CPU oracle (oracle/model.py) — values and
+gradients, ragged bags, strided (fused-GEMM) inputs, ignored rows.  Bar: 1e-4 relative."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+
+from jtsm_amd.layers.wsl_losses import mil_loss, oicr_loss  # noqa: E402
+
+
+def rel_close(a, b, tol=1e-4, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    ref = b.abs().max().item() + 1e-30
+    err = (a - b).abs().max().item()
+    assert err <= tol * ref, "%s: err %.3e ref %.3e" % (what, err, ref)
+
+
+@pytest.mark.parametrize("counts", [[2000, 2000], [37, 5, 120], [1], [700, 0, 3]])
+@pytest.mark.parametrize("mean_loss", [True, False])
+def test_mil_forward_backward(cuda, counts, mean_loss):
+    g = torch.Generator().manual_seed(7)
+    R, nc, B = sum(counts), OM.NUM_MIL, len(counts)
+    wide = torch.randn(R, 2 * nc + 30, generator=g) * 2        # C and D are column ranges of one matrix
+    y = (torch.rand(B, nc, generator=g) < 0.05).float()
+    Cc, Dc = wide[:, :nc].clone().requires_grad_(), wide[:, nc:2 * nc].clone().requires_grad_()
+    s0 = OM.mil_scores(Cc, Dc, counts)
+    p0 = OM.mil_image_probs(s0, counts)
+    l0 = F.binary_cross_entropy(p0, y, reduction="mean" if mean_loss else "sum")
+    if not mean_loss:
+        l0 = l0 / B
+    (l0 * 1.7).backward()
+    wd = wide.to(cuda).requires_grad_()
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=cuda)
+    loss, scores, probs = mil_loss(wd[:, :nc], wd[:, nc:2 * nc], off, y.to(cuda), mean_loss, max(counts))
+    rel_close(scores, s0, what="scores")
+    rel_close(probs, p0, what="probs")
+    rel_close(loss, l0, what="loss")
+    (loss * 1.7).backward()
+    rel_close(wd.grad[:, :nc], Cc.grad, what="dC")
+    rel_close(wd.grad[:, nc:2 * nc], Dc.grad, what="dD")
+    assert wd.grad[:, 2 * nc:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("R", [4000, 77, 1])
+@pytest.mark.parametrize("with_box", [True, False])
+def test_oicr_forward_backward(cuda, R, with_box):
+    g = torch.Generator().manual_seed(8)
+    K = OM.NUM_THINGS
+    z = (torch.randn(R, K + 1, generator=g) * 2).requires_grad_()
+    d = (torch.randn(R, 4 * K, generator=g) * 0.5).requires_grad_()
+    labels = torch.randint(0, K + 1, (R,), generator=g)
+    labels[torch.rand(R, generator=g) < 0.7] = K
+    if R > 3:
+        labels[:3] = torch.tensor([-1, 0, K - 1])
+    w = torch.rand(R, generator=g)
+    w[torch.rand(R, generator=g) < 0.2] = 0.0
+    if R == 1:
+        w[:] = 0.5
+    prop = torch.rand(R, 4, generator=g) * 200
+    prop[:, 2:] += prop[:, :2] + 4
+    gt = prop + torch.randn(R, 4, generator=g) * 3
+    gt[:, 2:] = torch.max(gt[:, 2:], gt[:, :2] + 2)
+    lab = dict(classes=labels, boxes=gt, weights=w)
+    lc0, lb0 = OM.oicr_losses(z, d, prop, lab)
+    (lc0 * 0.7 + (lb0 * 1.3 if with_box else 0)).backward()
+    zd, dd = z.detach().to(cuda).requires_grad_(), d.detach().to(cuda).requires_grad_()
+    lc, lb = oicr_loss(zd, dd if with_box else None, labels.to(cuda), w.to(cuda),
+                       prop.to(cuda) if with_box else None, gt.to(cuda) if with_box else None)
+    rel_close(lc, lc0, what="loss_cls")
+    if with_box:
+        rel_close(lb, lb0, what="loss_box")
+    (lc * 0.7 + (lb * 1.3 if with_box else 0)).backward()
+    rel_close(zd.grad, z.grad, what="dz")
+    if with_box:
+        rel_close(dd.grad, d.grad, what="dd")

@@ -1,0 +1,93 @@
+"""CPU suite: pins the torch-CPU loss restatements in oracle/model.py.
+
+The reference holds one usable known answer on this arithmetic: tests/modeling/test_fast_rcnn.py:18-45
+(loss_cls = 1.7951188087, loss_box_reg = 4.0357131958 at torch.manual_seed(132)) — CE over K+1 logits and
+L1 (smooth-L1 with beta 0) on the gt-class deltas divided by R, with Box2BoxTransform (10,10,5,5).  The
+OICR branch loss is the same arithmetic with per-row weights, so with weights = 1 it must reproduce
+those numbers.  MIL (fast_rcnn_tsm.py) has no reference test: "parity unpinned", checked against an
+independent loop formulation and its analytic gradient against autograd.
+"""
+import torch
+import torch.nn.functional as F
+
+from oracle import model as OM
+
+
+def test_oicr_loss_reproduces_reference_fast_rcnn_pin():
+    torch.manual_seed(132)
+    cls_score = torch.nn.Linear(8, 6)      # construction order and RNG draws as in FastRCNNOutputLayers.__init__
+    bbox_pred = torch.nn.Linear(8, 20)
+    torch.nn.init.normal_(cls_score.weight, std=0.01)
+    torch.nn.init.normal_(bbox_pred.weight, std=0.001)
+    torch.nn.init.constant_(cls_score.bias, 0)
+    torch.nn.init.constant_(bbox_pred.bias, 0)
+    feat = torch.rand(2, 8)
+    z, d = cls_score(feat), bbox_pred(feat)
+    prop = torch.tensor([[0.8, 1.1, 3.2, 2.8], [2.3, 2.5, 7, 8]])
+    gt = torch.tensor([[1, 1, 3, 3], [2, 2, 6, 6.0]])
+    lab = dict(classes=torch.tensor([1, 2]), boxes=gt, weights=torch.ones(2))
+    old = OM.NUM_THINGS
+    OM.NUM_THINGS = 5
+    try:
+        lc, lb = OM.oicr_losses(z, d, prop, lab)
+    finally:
+        OM.NUM_THINGS = old
+    assert torch.allclose(lc, torch.tensor(1.7951188087))
+    assert torch.allclose(lb, torch.tensor(4.0357131958))
+
+
+def test_apply_deltas_inverts_get_deltas():
+    g = torch.Generator().manual_seed(0)
+    src = torch.rand(50, 4, generator=g) * 50
+    src[:, 2:] += src[:, :2] + 1
+    tgt = torch.rand(50, 4, generator=g) * 50
+    tgt[:, 2:] += tgt[:, :2] + 1
+    assert torch.allclose(OM.apply_deltas(OM.box_deltas(src, tgt), src), tgt, atol=1e-3)
+
+
+def _mil_loops(C, D, counts, y):
+    """Literal per-image, per-class loops of SURVEY Appendix B (float64)."""
+    C, D = C.double(), D.double()
+    out, probs, r0 = torch.zeros_like(C), [], 0
+    for n in counts:
+        c, d = C[r0:r0 + n], D[r0:r0 + n]
+        a = torch.exp(c - c.max(1, keepdim=True).values)
+        a = a / a.sum(1, keepdim=True)
+        b = torch.exp(d - d.max(0, keepdim=True).values)
+        b = b / b.sum(0, keepdim=True)
+        out[r0:r0 + n] = a * b
+        probs.append((a * b).sum(0).clamp(1e-6, 1 - 1e-6))
+        r0 += n
+    p = torch.stack(probs)
+    loss = -(y * p.log() + (1 - y) * (1 - p).log()).mean()
+    return out, p, loss
+
+
+def test_mil_restated_matches_loops_and_analytic_gradient():
+    g = torch.Generator().manual_seed(1)
+    counts = [37, 5, 120]
+    R, nc = sum(counts), OM.NUM_MIL
+    C = (torch.randn(R, nc, generator=g) * 2).requires_grad_()
+    D = (torch.randn(R, nc, generator=g) * 2).requires_grad_()
+    y = (torch.rand(3, nc, generator=g) < 0.1).float()
+    s = OM.mil_scores(C, D, counts)
+    p = OM.mil_image_probs(s, counts)
+    loss = F.binary_cross_entropy(p, y)
+    s2, p2, l2 = _mil_loops(C.detach(), D.detach(), counts, y.double())
+    assert torch.allclose(s.double(), s2, atol=1e-7) and torch.allclose(p.double(), p2, atol=1e-6)
+    assert abs(loss.item() - l2.item()) < 1e-5
+    loss.backward()
+    # analytic gradient of Appendix B
+    Cd, Dd = C.detach().double(), D.detach().double()
+    gC, gD, r0 = torch.zeros_like(Cd), torch.zeros_like(Dd), 0
+    for i, n in enumerate(counts):
+        a = F.softmax(Cd[r0:r0 + n], 1)
+        b = F.softmax(Dd[r0:r0 + n], 0)
+        sc = a * b
+        ps = sc.sum(0)
+        pc = ps.clamp(1e-6, 1 - 1e-6)
+        gp = (pc - y[i].double()) / (pc * (1 - pc)) / (3 * nc) * ((ps >= 1e-6) & (ps <= 1 - 1e-6))
+        gC[r0:r0 + n] = gp * sc - a * (gp * sc).sum(1, keepdim=True)
+        gD[r0:r0 + n] = gp * (sc - b * ps)
+        r0 += n
+    assert torch.allclose(C.grad.double(), gC, atol=1e-7) and torch.allclose(D.grad.double(), gD, atol=1e-7)
