@@ -251,6 +251,33 @@ int jtsm_oicr_backward_f32(const float* cls_logits, int ld_cls, int num_cls, con
                            const float* up_cls, const float* up_box, float* d_cls, int ld_dcls,
                            float* d_box, int ld_dbox, void* stream);
 
+
+/* ---------------------------------------------------------------------------
+ * FPN-level variants (NHWC only) — what ROIPooler.forward does with nonzero + index +
+ * scatter per level (detectron2/modeling/poolers.py:236-247,
+ * projects/WSL/wsl/modeling/poolers.py:300-320), without the host synchronisation: every
+ * level's launch walks ALL M rois and serves only those with roi_level[m] == level, reading
+ * that level's feature map and writing rows m of the shared (M,PH,PW,C) output (argmax) /
+ * scattering rows m of the shared gradient into that level's grad_input (zero-filled by the
+ * call).  Rows of other levels are left untouched.
+ * ------------------------------------------------------------------------- */
+int jtsm_roi_align_forward_level_f32(const float* input, const float* rois,
+                                     const int32_t* roi_level, int level, float* output, int B,
+                                     int C, int H, int W, int M, float spatial_scale, int pooled_h,
+                                     int pooled_w, int sampling_ratio, int aligned, void* stream);
+int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois,
+                                      const int32_t* roi_level, int level, float* grad_input, int B,
+                                      int C, int H, int W, int M, float spatial_scale, int pooled_h,
+                                      int pooled_w, int sampling_ratio, int aligned, void* stream);
+int jtsm_moi_pool_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
+                                    int level, const int32_t* oh_labels, const int32_t* superpixels,
+                                    float* output, int32_t* argmax, void* workspace, int B, int C,
+                                    int H, int W, int M, int L, int Hs, int Ws, float spatial_scale,
+                                    int pooled_h, int pooled_w, void* stream);
+int jtsm_moi_pool_backward_level_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                     int level, const int32_t* argmax, float* grad_input, int B, int C,
+                                     int H, int W, int M, int pooled_h, int pooled_w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,11 +124,12 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_nhwc(
     const float* __restrict__ in, const float* __restrict__ rois,
     const unsigned* __restrict__ cell_bits, const unsigned* __restrict__ roi_bits,
     float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, int M, int words,
-    float scale, int PH, int PW) {
+    float scale, int PH, int PW, const int* __restrict__ roi_level, int level) {
   const int lane = threadIdx.x & 63;
   const int nbins = PH * PW;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= (long)M * nbins) return;
+  if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level
   const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
   const int ph = bin / PW, pw = bin - ph * PW;
   const IBox r = round_box(rois + (size_t)n * 5, scale);
@@ -236,7 +237,8 @@ __global__ __launch_bounds__(256) void moi_pool_bwd(const float* __restrict__ gr
                                                     const float* __restrict__ rois,
                                                     const int* __restrict__ argmax,
                                                     float* __restrict__ gin, int C, int H, int W,
-                                                    long total, int PH, int PW) {
+                                                    long total, int PH, int PW,
+                                                    const int* __restrict__ roi_level, int level) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
     const int a = argmax[idx];
@@ -249,6 +251,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd(const float* __restrict__ gr
       c = (int)((idx / PW / PH) % C);
       n = (int)(idx / PW / PH / C);
     }
+    if (roi_level && roi_level[n] != level) continue;
     const int b = (int)rois[(size_t)n * 5];
     float* dst = NHWC ? gin + ((size_t)b * H * W + a) * C + c : gin + ((size_t)b * C + c) * H * W + a;
     atomicAdd(dst, grad[idx]);
@@ -297,11 +300,11 @@ size_t jtsm_moi_pool_workspace_bytes(int B, int H, int W, int M, int L) {
   return cell + (size_t)M * bit_words(L) * sizeof(unsigned) + 16;
 }
 
-int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32_t* oh_labels,
-                              const int32_t* superpixels, float* output, int32_t* argmax,
-                              void* workspace, int B, int C, int H, int W, int M, int L, int Hs,
-                              int Ws, float spatial_scale, int pooled_h, int pooled_w, int layout,
-                              void* stream) {
+static int moi_forward_impl(const float* input, const float* rois, const int32_t* oh_labels,
+                            const int32_t* superpixels, float* output, int32_t* argmax,
+                            void* workspace, int B, int C, int H, int W, int M, int L, int Hs,
+                            int Ws, float spatial_scale, int pooled_h, int pooled_w, int layout,
+                            void* stream, const int32_t* roi_level, int level) {
   JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && L >= 0 && pooled_h > 0 && pooled_w > 0,
                "moi_pool: negative size");
   JTSM_REQUIRE(layout == JTSM_NCHW || layout == JTSM_NHWC, "moi_pool: unknown layout %d", layout);
@@ -321,12 +324,13 @@ int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32
     if (C % 4 == 0 && ((uintptr_t)input & 15) == 0)
       hipLaunchKernelGGL(moi_pool_fwd_nhwc<4>, dim3(blocks), dim3(256), 0, st, input, rois, k.cell,
                          k.roi, output, argmax, C, H, W, M, words, spatial_scale, pooled_h,
-                         pooled_w);
+                         pooled_w, roi_level, level);
     else
       hipLaunchKernelGGL(moi_pool_fwd_nhwc<1>, dim3(blocks), dim3(256), 0, st, input, rois, k.cell,
                          k.roi, output, argmax, C, H, W, M, words, spatial_scale, pooled_h,
-                         pooled_w);
+                         pooled_w, roi_level, level);
   } else {
+    JTSM_REQUIRE(!roi_level, "moi_pool: per-level filtering needs the NHWC layout");
     const long total = (long)M * C * pooled_h * pooled_w;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(moi_pool_fwd_nchw, dim3(blocks), dim3(256), 0, st, input, rois, k.cell, k.roi,
@@ -336,9 +340,9 @@ int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32
   return JTSM_OK;
 }
 
-int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32_t* argmax,
-                               float* grad_input, int B, int C, int H, int W, int M, int pooled_h,
-                               int pooled_w, int layout, void* stream) {
+static int moi_backward_impl(const float* grad, const float* rois, const int32_t* argmax,
+                             float* grad_input, int B, int C, int H, int W, int M, int pooled_h,
+                             int pooled_w, int layout, void* stream, const int32_t* roi_level, int level) {
   JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0,
                "moi_pool backward: negative size");
   JTSM_REQUIRE(layout == JTSM_NCHW || layout == JTSM_NHWC, "moi_pool: unknown layout %d", layout);
@@ -353,12 +357,43 @@ int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   if (layout == JTSM_NHWC)
     hipLaunchKernelGGL(moi_pool_bwd<true>, dim3(blocks), dim3(256), 0, st, grad, rois, argmax,
-                       grad_input, C, H, W, total, pooled_h, pooled_w);
+                       grad_input, C, H, W, total, pooled_h, pooled_w, roi_level, level);
   else
     hipLaunchKernelGGL(moi_pool_bwd<false>, dim3(blocks), dim3(256), 0, st, grad, rois, argmax,
-                       grad_input, C, H, W, total, pooled_h, pooled_w);
+                       grad_input, C, H, W, total, pooled_h, pooled_w, roi_level, level);
   JTSM_CHECK_LAUNCH("moi_pool backward");
   return JTSM_OK;
+}
+
+int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32_t* oh_labels,
+                              const int32_t* superpixels, float* output, int32_t* argmax,
+                              void* workspace, int B, int C, int H, int W, int M, int L, int Hs,
+                              int Ws, float spatial_scale, int pooled_h, int pooled_w, int layout,
+                              void* stream) {
+  return moi_forward_impl(input, rois, oh_labels, superpixels, output, argmax, workspace, B, C, H, W, M, L,
+                          Hs, Ws, spatial_scale, pooled_h, pooled_w, layout, stream, nullptr, 0);
+}
+int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32_t* argmax,
+                               float* grad_input, int B, int C, int H, int W, int M, int pooled_h,
+                               int pooled_w, int layout, void* stream) {
+  return moi_backward_impl(grad, rois, argmax, grad_input, B, C, H, W, M, pooled_h, pooled_w, layout,
+                           stream, nullptr, 0);
+}
+int jtsm_moi_pool_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
+                                    int level, const int32_t* oh_labels, const int32_t* superpixels,
+                                    float* output, int32_t* argmax, void* workspace, int B, int C, int H,
+                                    int W, int M, int L, int Hs, int Ws, float spatial_scale, int pooled_h,
+                                    int pooled_w, void* stream) {
+  JTSM_REQUIRE(roi_level || M == 0, "moi_pool level: null roi_level");
+  return moi_forward_impl(input, rois, oh_labels, superpixels, output, argmax, workspace, B, C, H, W, M, L,
+                          Hs, Ws, spatial_scale, pooled_h, pooled_w, JTSM_NHWC, stream, roi_level, level);
+}
+int jtsm_moi_pool_backward_level_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                     int level, const int32_t* argmax, float* grad_input, int B, int C,
+                                     int H, int W, int M, int pooled_h, int pooled_w, void* stream) {
+  JTSM_REQUIRE(roi_level || M == 0, "moi_pool level: null roi_level");
+  return moi_backward_impl(grad, rois, argmax, grad_input, B, C, H, W, M, pooled_h, pooled_w, JTSM_NHWC,
+                           stream, roi_level, level);
 }
 
 int jtsm_moi_mask_f32(const float* rois, const int32_t* oh_labels, const int32_t* superpixels,

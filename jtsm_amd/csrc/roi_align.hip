@@ -57,12 +57,14 @@ __global__ __launch_bounds__(256) void align_fwd_nhwc(const T* __restrict__ in,
                                                       const T* __restrict__ rois,
                                                       T* __restrict__ out, int C, int H, int W,
                                                       int M, T scale, int PH, int PW, int sr,
-                                                      int aligned) {
+                                                      int aligned,
+                                                      const int* __restrict__ roi_level, int level) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int nbins = PH * PW;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= (long)M * nbins) return;  // whole wave leaves together
+  if (wave >= (long)M * nbins) return;
+  if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level  // whole wave leaves together
   const int n = (int)(wave / nbins);
   const int bin = (int)(wave - (long)n * nbins);
   const int ph = bin / PW, pw = bin - ph * PW;
@@ -123,12 +125,14 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
                                                       const T* __restrict__ rois,
                                                       T* __restrict__ gin, int C, int H, int W,
                                                       int M, T scale, int PH, int PW, int sr,
-                                                      int aligned) {
+                                                      int aligned,
+                                                      const int* __restrict__ roi_level, int level) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int nbins = PH * PW;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wave >= (long)M * nbins) return;
+  if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level
   const int n = (int)(wave / nbins);
   const int bin = (int)(wave - (long)n * nbins);
   const int ph = bin / PW, pw = bin - ph * PW;
@@ -265,7 +269,8 @@ template <> struct WideVec<double> { static constexpr int value = 2; };
 
 template <typename T, bool ROT>
 int launch_forward(const T* in, const T* rois, T* out, int B, int C, int H, int W, int M,
-                   T scale, int PH, int PW, int sr, int aligned, int layout, void* stream) {
+                   T scale, int PH, int PW, int sr, int aligned, int layout, void* stream,
+                   const int* roi_level = nullptr, int level = 0) {
   JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && PH > 0 && PW > 0,
                "roi_align: negative size (B=%d C=%d H=%d W=%d M=%d PH=%d PW=%d)", B, C, H, W, M,
                PH, PW);
@@ -280,11 +285,12 @@ int launch_forward(const T* in, const T* rois, T* out, int B, int C, int H, int 
     constexpr int V = WideVec<T>::value;
     if (C % V == 0 && ((uintptr_t)in % (V * sizeof(T))) == 0 && ((uintptr_t)out % (V * sizeof(T))) == 0)
       hipLaunchKernelGGL((align_fwd_nhwc<T, V, ROT>), dim3(blocks), dim3(256), 0, st, in, rois,
-                         out, C, H, W, M, scale, PH, PW, sr, aligned);
+                         out, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level);
     else
       hipLaunchKernelGGL((align_fwd_nhwc<T, 1, ROT>), dim3(blocks), dim3(256), 0, st, in, rois,
-                         out, C, H, W, M, scale, PH, PW, sr, aligned);
+                         out, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level);
   } else {
+    JTSM_REQUIRE(!roi_level, "roi_align: per-level filtering needs the NHWC layout");
     const long total = (long)M * C * PH * PW;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL((align_fwd_nchw<T, ROT>), dim3(blocks), dim3(256), 0, st, in, rois, out, C,
@@ -296,7 +302,8 @@ int launch_forward(const T* in, const T* rois, T* out, int B, int C, int H, int 
 
 template <typename T, bool ROT>
 int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, int W, int M,
-                    T scale, int PH, int PW, int sr, int aligned, int layout, void* stream) {
+                    T scale, int PH, int PW, int sr, int aligned, int layout, void* stream,
+                    const int* roi_level = nullptr, int level = 0) {
   JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && PH > 0 && PW > 0,
                "roi_align backward: negative size");
   JTSM_REQUIRE(layout == JTSM_NCHW || layout == JTSM_NHWC, "roi_align: unknown layout %d", layout);
@@ -313,11 +320,12 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
     constexpr int V = WideVec<T>::value;
     if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(T))) == 0)
       hipLaunchKernelGGL((align_bwd_nhwc<T, V, ROT>), dim3(blocks), dim3(256), 0, st, grad, rois,
-                         gin, C, H, W, M, scale, PH, PW, sr, aligned);
+                         gin, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level);
     else
       hipLaunchKernelGGL((align_bwd_nhwc<T, 1, ROT>), dim3(blocks), dim3(256), 0, st, grad, rois,
-                         gin, C, H, W, M, scale, PH, PW, sr, aligned);
+                         gin, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level);
   } else {
+    JTSM_REQUIRE(!roi_level, "roi_align: per-level filtering needs the NHWC layout");
     const long total = (long)M * C * PH * PW;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL((align_bwd_nchw<T, ROT>), dim3(blocks), dim3(256), 0, st, grad, rois, gin,
@@ -390,6 +398,23 @@ int jtsm_roi_align_rotated_backward_f64(const double* grad, const double* rois, 
                                         void* stream) {
   return launch_backward<double, true>(grad, rois, grad_input, B, C, H, W, M, spatial_scale,
                                        pooled_h, pooled_w, sampling_ratio, 1, layout, stream);
+}
+
+int jtsm_roi_align_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
+                                     int level, float* output, int B, int C, int H, int W, int M,
+                                     float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                     int aligned, void* stream) {
+  JTSM_REQUIRE(roi_level || M == 0, "roi_align level: null roi_level");
+  return launch_forward<float, false>(input, rois, output, B, C, H, W, M, spatial_scale, pooled_h,
+                                      pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, level);
+}
+int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                      int level, float* grad_input, int B, int C, int H, int W, int M,
+                                      float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                      int aligned, void* stream) {
+  JTSM_REQUIRE(roi_level || M == 0, "roi_align level: null roi_level");
+  return launch_backward<float, false>(grad, rois, grad_input, B, C, H, W, M, spatial_scale, pooled_h,
+                                       pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, level);
 }
 
 int jtsm_roi_sample_table_f32(const float* rois, int rotated, int M, int H, int W,

@@ -126,6 +126,21 @@ class _ConvFused(Function):
 
 def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False,
                  bias_needs_grad=False):
+    """Autograd-aware fused convolution.  An output-channel count that is not a multiple of 4 (54 sem-seg
+    classes, the 1870-wide fused predictor) is zero-padded up for the kernels' 16-byte rows and the
+    padding is sliced off the result (its gradient is zero by construction)."""
+    o = w.shape[0]
+    if o % 4:
+        extra = 4 - o % 4
+        w = torch.cat([w, w.new_zeros((extra,) + tuple(w.shape[1:]))]).contiguous(memory_format=CL)
+        if scale is not None:
+            scale = torch.cat([scale, scale.new_ones(extra)])
+        if bias is not None:
+            bias = torch.cat([bias, bias.new_zeros(extra)])
+        if residual is not None:
+            residual = torch.nn.functional.pad(residual, (0, 0, 0, 0, 0, extra))
+        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad)
+        return y[:, :o]
     return _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad)
 
 

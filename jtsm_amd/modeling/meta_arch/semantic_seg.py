@@ -1,0 +1,74 @@
+"""SemSegFPNHead — surface of detectron2/modeling/meta_arch/semantic_seg.py:95-188.
+Per FPN level: [conv3x3 -> GroupNorm(32) -> ReLU (-> bilinear x2)] x log2(stride/4), summed, 1x1
+predictor; loss = CE(bilinear x4 of the logits, target, ignore 255) * LOSS_WEIGHT.
+The 3x3 / 1x1 convolutions are MFMA launches; GroupNorm, the bilinear resampling and the
+cross-entropy currently run as PyTorch-ROCm device ops (listed as not-yet-native in DESIGN.md)."""
+from typing import Dict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ...layers.shape_spec import ShapeSpec
+from ...layers.wrappers import Conv2d
+from ...utils.registry import Registry
+
+SEM_SEG_HEADS_REGISTRY = Registry("SEM_SEG_HEADS")
+
+
+def build_sem_seg_head(cfg, input_shape):
+    return SEM_SEG_HEADS_REGISTRY.get(cfg.MODEL.SEM_SEG_HEAD.NAME)(cfg, input_shape)
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class SemSegFPNHead(nn.Module):
+    def __init__(self, cfg, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        self.in_features = cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES
+        feature_strides = {k: v.stride for k, v in input_shape.items()}
+        feature_channels = {k: v.channels for k, v in input_shape.items()}
+        self.ignore_value = cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE
+        num_classes = cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES
+        conv_dims = cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM
+        self.common_stride = cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE
+        norm = cfg.MODEL.SEM_SEG_HEAD.NORM
+        self.loss_weight = cfg.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT
+        self.scale_heads = []
+        for in_feature in self.in_features:
+            head_ops = []
+            head_length = max(1, int(np.log2(feature_strides[in_feature]) - np.log2(self.common_stride)))
+            for k in range(head_length):
+                conv = Conv2d(feature_channels[in_feature] if k == 0 else conv_dims, conv_dims, kernel_size=3,
+                              stride=1, padding=1, bias=not norm,
+                              norm=nn.GroupNorm(32, conv_dims) if norm == "GN" else None, activation=F.relu)
+                nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+                if conv.bias is not None:
+                    nn.init.constant_(conv.bias, 0)
+                head_ops.append(conv)
+                if feature_strides[in_feature] != self.common_stride:
+                    head_ops.append(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+            self.scale_heads.append(nn.Sequential(*head_ops))
+            self.add_module(in_feature, self.scale_heads[-1])
+        self.predictor = Conv2d(conv_dims, num_classes, kernel_size=1, stride=1, padding=0)
+        nn.init.kaiming_normal_(self.predictor.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.constant_(self.predictor.bias, 0)
+
+    def forward(self, features, targets=None):
+        x = self.layers(features)
+        if self.training:
+            return None, self.losses(x, targets)
+        return F.interpolate(x, scale_factor=self.common_stride, mode="bilinear", align_corners=False), {}
+
+    def layers(self, features):
+        x = None
+        for i, f in enumerate(self.in_features):
+            y = self.scale_heads[i](features[f])
+            x = y if x is None else x + y
+        return self.predictor(x)
+
+    def losses(self, predictions, targets):
+        predictions = F.interpolate(predictions.float(), scale_factor=self.common_stride, mode="bilinear",
+                                    align_corners=False)
+        loss = F.cross_entropy(predictions, targets, reduction="mean", ignore_index=self.ignore_value)
+        return {"loss_sem_seg": loss * self.loss_weight}

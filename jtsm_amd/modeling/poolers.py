@@ -1,0 +1,205 @@
+"""ROIPooler — surface of detectron2/modeling/poolers.py:22-249 and of the WSL variant that adds
+MOIPool and the (oh_labels_list, superpixels) arguments (projects/WSL/wsl/modeling/poolers.py:119-331).
+
+MI355X mapping: the reference finds each level's boxes with `nonzero` (a device->host sync per level),
+gathers them, pools, and scatters the result back.  Here level assignment stays on the device and each
+level is ONE launch over all M boxes that serves only its own (kernel-side filter), writing straight
+into the shared (M,C,P,P) output — no sync, no gather/scatter copies.
+
+Multi-level MOIPool is DEFINED here (the reference's multi-level branch is broken): each
+box is pooled on its assigned level with that level's scale, and both `output` and `argmax` are
+returned for all boxes.
+"""
+import math
+from typing import List
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .. import _lib as L
+from ..layers.moi_pool import MOIPool
+from ..layers.roi_align import ROIAlign
+from ..layers.roi_align_rotated import ROIAlignRotated
+from ..layers.wrappers import cat
+
+CL = torch.channels_last
+
+
+def assign_boxes_to_levels(box_lists, min_level, max_level, canonical_box_size, canonical_level):
+    """floor(canonical_level + log2(sqrt(area) / canonical_box_size + 1e-8)) clamped to
+    [min_level, max_level], returned 0-based (poolers.py:22-58)."""
+    box_sizes = torch.sqrt(cat([boxes.area() for boxes in box_lists]))
+    level_assignments = torch.floor(canonical_level + torch.log2(box_sizes / canonical_box_size + 1e-8))
+    level_assignments = torch.clamp(level_assignments, min=min_level, max=max_level)
+    return level_assignments.to(torch.int64) - min_level
+
+
+def convert_boxes_to_pooler_format(box_lists):
+    """list[Boxes] -> (M,5) [batch index, x0, y0, x1, y1] (poolers.py:61-95)."""
+    def fmt_box_list(box_tensor, batch_index):
+        repeated_index = torch.full((len(box_tensor), 1), batch_index, dtype=box_tensor.dtype,
+                                    device=box_tensor.device)
+        return cat((repeated_index, box_tensor), dim=1)
+
+    return cat([fmt_box_list(box_list.tensor, i) for i, box_list in enumerate(box_lists)], dim=0)
+
+
+def _feat(x):
+    L.require_gpu(x)
+    if x.dtype != torch.float32:
+        raise RuntimeError("jtsm_amd multi-level pooling is float32, got %s" % x.dtype)
+    return x.contiguous(memory_format=CL)
+
+
+class _AlignLevels(Function):
+    @staticmethod
+    def forward(ctx, rois, roi_level, res, sampling_ratio, aligned, scales, *feats):
+        feats = [_feat(f) for f in feats]
+        M, C = rois.shape[0], feats[0].shape[1]
+        out = torch.zeros((M, C, res, res), dtype=torch.float32, device=rois.device).contiguous(memory_format=CL)
+        for lvl, (f, sc) in enumerate(zip(feats, scales)):
+            B, _, H, W = f.shape
+            L.check(L.lib().jtsm_roi_align_forward_level_f32(
+                L.ptr(f), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(out), B, C, H, W, M, L.f32(sc), res, res,
+                sampling_ratio, int(aligned), L.stream()), "roi_align_forward_level")
+        ctx.save_for_backward(rois, roi_level)
+        ctx.cfg = (res, sampling_ratio, aligned, scales, [tuple(f.shape) for f in feats])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        rois, roi_level = ctx.saved_tensors
+        res, sampling_ratio, aligned, scales, shapes = ctx.cfg
+        g = g.contiguous(memory_format=CL)
+        grads = []
+        for lvl, (shape, sc) in enumerate(zip(shapes, scales)):
+            if not ctx.needs_input_grad[6 + lvl]:
+                grads.append(None)
+                continue
+            B, C, H, W = shape
+            gi = torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
+            L.check(L.lib().jtsm_roi_align_backward_level_f32(
+                L.ptr(g), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(gi), B, C, H, W, rois.shape[0], L.f32(sc),
+                res, res, sampling_ratio, int(aligned), L.stream()), "roi_align_backward_level")
+            grads.append(gi)
+        return (None, None, None, None, None, None, *grads)
+
+
+class _MOILevels(Function):
+    @staticmethod
+    def forward(ctx, rois, roi_level, res, scales, oh_labels, superpixels, *feats):
+        feats = [_feat(f) for f in feats]
+        M, C = rois.shape[0], feats[0].shape[1]
+        Lw = oh_labels.shape[1]
+        out = torch.zeros((M, C, res, res), dtype=torch.float32, device=rois.device).contiguous(memory_format=CL)
+        arg = torch.full((M, C, res, res), -1, dtype=torch.int32, device=rois.device).contiguous(memory_format=CL)
+        lib = L.lib()
+        for lvl, (f, sc) in enumerate(zip(feats, scales)):
+            B, _, H, W = f.shape
+            ws = torch.empty(lib.jtsm_moi_pool_workspace_bytes(B, H, W, M, Lw), dtype=torch.uint8, device=f.device)
+            L.check(lib.jtsm_moi_pool_forward_level_f32(
+                L.ptr(f), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(oh_labels), L.ptr(superpixels), L.ptr(out),
+                L.ptr(arg), L.ptr(ws), B, C, H, W, M, Lw, superpixels.shape[1], superpixels.shape[2], L.f32(sc),
+                res, res, L.stream()), "moi_pool_forward_level")
+        ctx.save_for_backward(rois, roi_level, arg)
+        ctx.cfg = (res, [tuple(f.shape) for f in feats])
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g, _ga=None):
+        rois, roi_level, arg = ctx.saved_tensors
+        res, shapes = ctx.cfg
+        g = g.contiguous(memory_format=CL)
+        grads = []
+        for lvl, shape in enumerate(shapes):
+            if not ctx.needs_input_grad[6 + lvl]:
+                grads.append(None)
+                continue
+            B, C, H, W = shape
+            gi = torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
+            L.check(L.lib().jtsm_moi_pool_backward_level_f32(
+                L.ptr(g), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(arg), L.ptr(gi), B, C, H, W, rois.shape[0],
+                res, res, L.stream()), "moi_pool_backward_level")
+            grads.append(gi)
+        return (None, None, None, None, None, None, *grads)
+
+
+class ROIPooler(nn.Module):
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224,
+                 canonical_level=4):
+        super().__init__()
+        if isinstance(output_size, int):
+            output_size = (output_size, output_size)
+        assert len(output_size) == 2 and isinstance(output_size[0], int) and isinstance(output_size[1], int)
+        self.output_size = output_size
+        self.pooler_type = pooler_type
+        self.sampling_ratio = sampling_ratio
+        self.scales = tuple(float(s) for s in scales)
+        if pooler_type == "ROIAlign":
+            self.level_poolers = nn.ModuleList(
+                ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio, aligned=False) for s in scales)
+        elif pooler_type == "ROIAlignV2":
+            self.level_poolers = nn.ModuleList(
+                ROIAlign(output_size, spatial_scale=s, sampling_ratio=sampling_ratio, aligned=True) for s in scales)
+        elif pooler_type == "MOIPool":
+            self.level_poolers = nn.ModuleList(MOIPool(output_size, spatial_scale=s) for s in scales)
+        elif pooler_type == "ROIAlignRotated":
+            self.level_poolers = nn.ModuleList(
+                ROIAlignRotated(output_size, spatial_scale=s, sampling_ratio=sampling_ratio) for s in scales)
+        else:
+            raise ValueError("Unknown pooler type on the JTSM path: {}".format(pooler_type))
+        min_level = -(math.log2(scales[0]))
+        max_level = -(math.log2(scales[-1]))
+        assert math.isclose(min_level, int(min_level)) and math.isclose(max_level, int(max_level)), \
+            "Featuremap stride is not power of 2!"
+        self.min_level = int(min_level)
+        self.max_level = int(max_level)
+        assert len(scales) == self.max_level - self.min_level + 1, \
+            "[ROIPooler] Sizes of input featuremaps do not form a pyramid!"
+        assert 0 <= self.min_level and self.min_level <= self.max_level
+        self.canonical_level = canonical_level
+        assert canonical_box_size > 0
+        self.canonical_box_size = canonical_box_size
+
+    def forward(self, x: List[torch.Tensor], box_lists, level_ids=None, oh_labels_list=None, superpixels=None):
+        """x: per-level (N,C,H,W) maps; box_lists: list[Boxes] per image.  With `superpixels` (an
+        ImageList or (N,Hs,Ws) int tensor) and `oh_labels_list`, MOIPool is used and (output, argmax)
+        is returned; otherwise the (M,C,P,P) output."""
+        num_level_assignments = len(self.level_poolers)
+        assert isinstance(x, list) and isinstance(box_lists, list), "Arguments to pooler must be lists"
+        assert len(x) == num_level_assignments, \
+            "unequal value, num_level_assignments={}, but x is list of {} Tensors".format(num_level_assignments, len(x))
+        assert len(box_lists) == x[0].size(0), \
+            "unequal value, x[0] batch dim 0 is {}, but box_list has length {}".format(x[0].size(0), len(box_lists))
+        if len(box_lists) == 0:
+            return torch.zeros((0, x[0].shape[1]) + self.output_size, device=x[0].device, dtype=x[0].dtype)
+        pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
+        moi = superpixels is not None
+        if moi:
+            sp = superpixels.tensor if hasattr(superpixels, "tensor") else superpixels
+            sp = sp.to(torch.int32).contiguous()
+            max_len = max(l.size(1) for l in oh_labels_list)
+            labels = cat([torch.nn.functional.pad(l.to(torch.int32), (0, max_len - l.size(1))) for l in oh_labels_list])
+            labels = labels.contiguous()
+        if num_level_assignments == 1:
+            if moi:
+                return self.level_poolers[0](x[0], pooler_fmt_boxes, labels, sp)
+            return self.level_poolers[0](x[0], pooler_fmt_boxes)
+        if level_ids is not None:
+            level_assignments = cat(level_ids).to(torch.int64)
+        else:
+            level_assignments = assign_boxes_to_levels(box_lists, self.min_level, self.max_level,
+                                                       self.canonical_box_size, self.canonical_level)
+        roi_level = level_assignments.to(torch.int32).contiguous()
+        rois = pooler_fmt_boxes.to(torch.float32).contiguous()
+        if moi:
+            return _MOILevels.apply(rois, roi_level, self.output_size[0], self.scales, labels, sp, *x)
+        if self.pooler_type == "ROIAlignRotated":
+            raise NotImplementedError("multi-level ROIAlignRotated is outside the JTSM path")
+        return _AlignLevels.apply(rois, roi_level, self.output_size[0], self.sampling_ratio,
+                                  self.pooler_type == "ROIAlignV2", self.scales, *x)

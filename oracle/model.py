@@ -42,9 +42,11 @@ PIXEL_MEAN = (102.9801, 115.9465, 122.7717)
 
 
 # ----------------------------------------------------------------------------- parameters
-def init_params(seed=0, depth=50, dan_dims=(2048, 4096), refine_k=4, random_bn=True):
+def init_params(seed=0, depth=50, dan_dims=(2048, 4096), refine_k=4, random_bn=True, input_gain=1.0):
     """Seeded synthetic weights with the reference's initialisers.
-    random_bn=True perturbs the FrozenBN buffers away from identity so scale/bias paths are exercised."""
+    random_bn=True perturbs the FrozenBN buffers away from identity so scale/bias paths are exercised.
+    input_gain scales the stem convolution: random weights are not matched to 0..255 pixel inputs the way
+    pretrained ones are, and 1/64 keeps activations O(1) so softmaxes do not saturate in parity tests."""
     g = torch.Generator().manual_seed(seed)
     p = {}
 
@@ -68,6 +70,7 @@ def init_params(seed=0, depth=50, dan_dims=(2048, 4096), refine_k=4, random_bn=T
 
     bu = "backbone.bottom_up."
     msra(bu + "stem.conv1.weight", 64, 3, 7)
+    p[bu + "stem.conv1.weight"] *= input_gain
     bn(bu + "stem.conv1.norm", 64)
     cin = 64
     for si, nblocks in enumerate(STAGES[depth]):
