@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the JTSM hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (forward, backward, gradient all-reduce, SGD update) of the R50-FPN
+JTSM panoptic composite on one synthetic batch per rank: BASELINE.json configs[2]
+(2 x 3x1024x1024 images, 2000 proposals and 1024 superpixels per image).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line; `value` is the whole-job
+images/sec (max step time over ranks).  Extra objects: `roofline` (dominant kernel, measured live with
+events on the launch stream in one extra, untimed step) and, at N=1, `cpu_baseline` (the CPU oracle
+timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=1024, help="image side (BASELINE: 1024)")
+    ap.add_argument("--proposals", type=int, default=2000, help="proposals per image (BASELINE: 2000)")
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU (BASELINE: 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build(device):
+    from model_util import jtsm_cfg
+    from jtsm_amd.modeling import build_model
+
+    torch.manual_seed(0)                       # identical random-init weights on every rank
+    model = build_model(jtsm_cfg(str(device)))
+    model.train()
+    # random msra weights are not matched to 0..255 inputs; keep activations O(1) (as in the parity tests)
+    with torch.no_grad():
+        model.backbone.bottom_up.stem.conv1.weight.mul_(1.0 / 64)
+    return model
+
+
+def make_optimizer(model):
+    """SGD as the reference configures it (detectron2/solver/build.py:110-195 with the JTSM config's
+    BASE_LR 0.01, WEIGHT_DECAY 5e-4, BIAS_LR_FACTOR 2, WEIGHT_DECAY_BIAS 0, momentum 0.9)."""
+    decay, bias = [], []
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            (bias if n.endswith(".bias") else decay).append(p)
+    # Random-init weights diverge within a few steps at the reference's BASE_LR (0.01), which would empty
+    # the foreground set and silently shrink the work; the update arithmetic is kept, only lr is tiny.
+    lr = 1e-7
+    return torch.optim.SGD([{"params": decay, "lr": lr, "weight_decay": 5e-4},
+                            {"params": bias, "lr": 2 * lr, "weight_decay": 0.0}], lr=lr, momentum=0.9)
+
+
+def roofline_leg(step_fn):
+    from jtsm_amd.layers import conv
+
+    conv.LAUNCH_LOG = []
+    step_fn()
+    torch.cuda.synchronize()
+    log, conv.LAUNCH_LOG = conv.LAUNCH_LOG, None
+    per = {}
+    for variant, flops, a, b in log:
+        d = per.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        d["launches"] += 1
+        d["flops"] += flops
+        d["ms"] += a.elapsed_time(b)
+    for d in per.values():
+        d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        d["avg_us"] = 1e3 * d["ms"] / d["launches"]
+    dom = max(per, key=lambda k: per[k]["ms"])
+    total_ms = sum(d["ms"] for d in per.values())
+    total_fl = sum(d["flops"] for d in per.values())
+    return {
+        "bound": "mfma", "kernel": dom, "achieved": round(per[dom]["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": round(per[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "launches_per_step": per[dom]["launches"], "avg_launch_us": round(per[dom]["avg_us"], 2),
+        "algorithmic_gflop_per_launch": round(per[dom]["flops"] / per[dom]["launches"] / 1e9, 3),
+        "all_contractions": {"tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2), "ms_per_step": round(total_ms, 3),
+                             "gflop_per_step": round(total_fl / 1e9, 1),
+                             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                               "tflops": round(v["tflops"], 2)} for k, v in sorted(per.items())}},
+    }
+
+
+def cpu_baseline_leg(size, proposals):
+    """The CPU oracle (oracle/model.py, a torch-CPU port of the reference's arithmetic) on a bounded
+    sample: ONE image of the same workload, forward + backward, all host threads."""
+    from oracle import model as OM
+
+    p = OM.init_params(0, input_gain=1.0 / 64)
+    for n in OM.trainable_names(p):
+        p[n].requires_grad_(True)
+    b = OM.synthetic_batch(1234, B=1, size=size, R=proposals, sp_block=32)
+    t0 = time.perf_counter()
+    losses = OM.forward_losses(p, b)
+    sum(losses.values()).backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 training step (fwd+bwd, no optimizer) of the torch-CPU oracle on 1 image %dx%d with %d "
+                      "proposals; pooling ops single-threaded C like the reference (%.1f s)" % (size, size, proposals, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus)
+
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+
+    model = build(device)
+    inputs = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device)
+    net = model
+    if world > 1:
+        # one process per GPU; bucketed RCCL all-reduce of gradients overlapped with the backward
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
+                                                        find_unused_parameters=False, bucket_cap_mb=64,
+                                                        gradient_as_bucket_view=True)
+    opt = make_optimizer(model)
+
+    def step():
+        losses = net(inputs)
+        total = sum(losses.values())
+        total.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return total
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_value = float(last.detach())
+
+    out = None
+    if rank == 0:
+        ims = args.batch * world * args.steps / dt
+        out = {
+            "metric": "images/sec training, R50-FPN JTSM panoptic, 2x1024x1024, 1/2/4/8 GPU",
+            "value": round(ims, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: projects/WSL JTSM panoptic R50-FPN composite, COCO-shaped synthetic, "
+                            "%d x 3x%dx%d per GPU, %d proposals + %d superpixels per image; MIL + 4 OICR refinements + "
+                            "2 mask heads + sem-seg head; fwd + bwd + all-reduce + SGD" % (
+                                args.batch, args.size, args.size, args.proposals, (args.size // 32) ** 2),
+                "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                "substitutions": "grabCut/polygon pseudo-masks -> eroded pseudo-GT rectangles (SURVEY F8, §8d); dropout on",
+                "weights": "random init (msra/xavier as the reference), FrozenBN identity, stem x1/64",
+                "torch_device_ops": ["GroupNorm", "bilinear upsample", "cross_entropy(sem-seg)", "mask BCE",
+                                     "dropout", "pseudo-label mining (topk/IoU)", "SGD", "DDP all-reduce"],
+                "final_loss": round(loss_value, 5), "lr": 1e-7,
+                "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
+            },
+        }
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = roofline_leg(step)
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_leg(args.size, args.proposals)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,26 @@ from .. import _lib as L
 
 CL = torch.channels_last
 
+# Optional per-launch timing (bench.py's roofline leg): when a list, every contraction launch appends
+# (kernel variant, algorithmic FLOPs, start event, stop event), recorded on the launch stream.
+LAUNCH_LOG = None
+
+
+def _timed(variant, flops, call):
+    if LAUNCH_LOG is None:
+        return call()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = call()
+    b.record()
+    LAUNCH_LOG.append((variant, flops, a, b))
+    return rc
+
+
+def _flops(s):
+    oh, ow = out_hw(s)
+    return 2.0 * s.batch * oh * ow * s.out_c * s.in_c * s.kernel_h * s.kernel_w
+
 
 class ConvShape(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("batch", "in_h", "in_w", "in_c", "out_c", "kernel_h",
@@ -57,9 +77,10 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
     if residual is not None:
         residual = _cl(residual)
         assert residual.shape == y.shape
-    L.check(L.lib().jtsm_conv2d_forward_f32(L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale),
-                                            L.ptr(bias), L.ptr(residual), int(bool(relu)), L.stream()),
-            "conv2d_forward")
+    variant = "igemm_kernel<FWD,256,64>" if s.out_c <= 64 else "igemm_kernel<FWD,128,128>"
+    L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_forward_f32(
+        L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
+        L.stream())), "conv2d_forward")
     return y
 
 
@@ -73,9 +94,10 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         accumulate = _cl(accumulate)
     if relu_mask is not None:
         relu_mask = _cl(relu_mask)
-    L.check(L.lib().jtsm_conv2d_backward_data_f32(L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s),
-                                                  L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
-                                                  L.stream()), "conv2d_backward_data")
+    variant = "igemm_kernel<DGRAD,256,64>" if s.in_c <= 64 else "igemm_kernel<DGRAD,128,128>"
+    L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_f32(
+        L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s), L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
+        L.stream())), "conv2d_backward_data")
     return dx
 
 
@@ -83,11 +105,11 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     _check(dy, x, row_scale)
     dy, x = _cl(dy), _cl(x)
     s = _shape(x.shape, w_shape, stride, pad, dil)
-    zero = out is None
+    zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
-        out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL)
-    L.check(L.lib().jtsm_conv2d_backward_weight_f32(L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s),
-                                                    L.ptr(row_scale), int(zero), L.stream()),
+        out = torch.zeros(tuple(w_shape), dtype=x.dtype, device=x.device).contiguous(memory_format=CL)
+    L.check(_timed("igemm_kernel<WGRAD,128,128>", _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
+        L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream())),
             "conv2d_backward_weight")
     return out
 
