@@ -126,22 +126,16 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    from jtsm_amd.engine import dp
+    dp.init_distributed("nccl", device)
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus)
 
     from jtsm_amd.utils.synthetic import synthetic_inputs
 
     model = build(device)
     inputs = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device)
-    net = model
-    if world > 1:
-        # one process per GPU; bucketed RCCL all-reduce of gradients overlapped with the backward
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], broadcast_buffers=False,
-                                                        find_unused_parameters=False, bucket_cap_mb=64,
-                                                        gradient_as_bucket_view=True)
+    # one process per GPU; bucketed RCCL all-reduce of gradients overlapped with the backward
+    net = dp.wrap_data_parallel(model, device)
     opt = make_optimizer(model)
 
     def step():
@@ -153,9 +147,7 @@ def main():
         return total
 
     def fence():
-        if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+        dp.fence(device)
 
     for _ in range(args.warmup):
         step()
@@ -165,10 +157,7 @@ def main():
         last = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dp.max_over_ranks(dt, device)
     loss_value = float(last.detach())
 
     out = None

@@ -161,18 +161,24 @@ typedef struct jtsm_conv_shape {
 } jtsm_conv_shape;
 
 int jtsm_conv_out_size(const jtsm_conv_shape* s, int* out_h, int* out_w);
+/* Bytes of scratch the forward (backward_data = 0) or backward-data (= 1) call of this shape can use
+ * for deterministic split-K (layers with too few output tiles to fill 256 CUs are split along K into
+ * per-slice slabs that a second kernel folds in slice order and finishes with the fused epilogue).
+ * 0 = not split.  Passing a NULL / smaller workspace is allowed: the call then runs unsplit. */
+size_t jtsm_conv_workspace_bytes(const jtsm_conv_shape* s, int backward_data);
 
 /* y = relu?( conv(x, w) * scale[c] + bias[c] + residual ).  scale, bias, residual may be NULL;
  * residual has y's shape and may alias y. */
 int jtsm_conv2d_forward_f32(const float* x, const float* w, float* y, const jtsm_conv_shape* s,
                             const float* scale, const float* bias, const float* residual,
-                            int relu, void* stream);
+                            int relu, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = conv_transpose(dy * kscale[out_c], w) (+ accumulate), then zeroed where
  * relu_mask <= 0.  kscale (per out_c; the FrozenBN scale of this conv), accumulate and
  * relu_mask (both dx-shaped; accumulate may alias dx) may be NULL. */
 int jtsm_conv2d_backward_data_f32(const float* dy, const float* w, float* dx,
                                   const jtsm_conv_shape* s, const float* kscale,
-                                  const float* accumulate, const float* relu_mask, void* stream);
+                                  const float* accumulate, const float* relu_mask, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 /* dw[o][kh][kw][i] (+)= row_scale[o] * sum_pixels dy[p][o] * x[pix(p,kh,kw)][i].
  * zero_dw != 0 clears dw first; otherwise the result is added to what dw holds.  Split over
  * the pixel axis with float atomics: the last bits depend on arrival order. */

@@ -61,7 +61,11 @@ struct Params {
   const float* kscale;  // DGRAD only: per-Cout multiplier folded into W rows, or null
   int M, N, K;
   int ldc;
-  int ktiles_per_split;  // WGRAD split-K
+  int ktiles_per_split;  // split-K: K tiles per grid.y slice
+  float* slab;           // FWD/DGRAD split-K: raw partial tiles go to slab[blockIdx.y][M][ldc]
+  // DGRAD of a strided 1x1 convolution runs as a dense GEMM over the OUTPUT pixels; row m of the result
+  // is scattered to input pixel (b, oh*stride, ow*stride) of a zero-filled dX.
+  int scatter, sc_Ho, sc_Wo, sc_H, sc_W, sc_stride;
   ConvShape s;
   Epilogue e;
 };
@@ -93,9 +97,9 @@ __device__ __forceinline__ PixelRow fwd_pixel(const ConvShape& s, int m, int M) 
   r.w0 = ow * s.stride - s.pad;
   return r;
 }
-__device__ __forceinline__ const float* fwd_a_ptr(const Params& p, const PixelRow& r, int k) {
+__device__ __forceinline__ const float* fwd_a_ptr(const Params& p, const PixelRow& r, int k, int kend) {
   const ConvShape& s = p.s;
-  if (!r.ok || k >= p.K) return nullptr;
+  if (!r.ok || k >= kend) return nullptr;
   const int tap = k / s.Cin, ci = k - tap * s.Cin;
   const int kh = tap / s.KW, kw = tap - kh * s.KW;
   const int ih = r.h0 + kh * s.dil, iw = r.w0 + kw * s.dil;
@@ -115,9 +119,9 @@ __device__ __forceinline__ PixelRow dgrad_pixel(const ConvShape& s, int m, int M
   r.w0 = iw + s.pad;
   return r;
 }
-__device__ __forceinline__ const float* dgrad_a_ptr(const Params& p, const PixelRow& r, int k) {
+__device__ __forceinline__ const float* dgrad_a_ptr(const Params& p, const PixelRow& r, int k, int kend) {
   const ConvShape& s = p.s;
-  if (!r.ok || k >= p.K) return nullptr;
+  if (!r.ok || k >= kend) return nullptr;
   const int tap = k / s.Cout, co = k - tap * s.Cout;
   const int kh = tap / s.KW, kw = tap - kh * s.KW;
   const int th = r.h0 - kh * s.dil, tw = r.w0 - kw * s.dil;
@@ -133,15 +137,15 @@ __device__ __forceinline__ const float* dgrad_a_ptr(const Params& p, const Pixel
 }
 
 // FWD B: W[n][k], K-contiguous.
-__device__ __forceinline__ const float* fwd_b_ptr(const Params& p, int n, int k) {
-  if (n >= p.N || k >= p.K) return nullptr;
+__device__ __forceinline__ const float* fwd_b_ptr(const Params& p, int n, int k, int kend) {
+  if (n >= p.N || k >= kend) return nullptr;
   return p.B + (size_t)n * p.K + k;
 }
 
 // DGRAD B: row k = (tap, co) of W viewed as [K][Cin]; col = ci (contiguous).
-__device__ __forceinline__ const float* dgrad_b_ptr(const Params& p, int k, int col, float* ks) {
+__device__ __forceinline__ const float* dgrad_b_ptr(const Params& p, int k, int col, float* ks, int kend) {
   const ConvShape& s = p.s;
-  if (k >= p.K || col >= p.N) return nullptr;
+  if (k >= kend || col >= p.N) return nullptr;
   const int tap = k / s.Cout, co = k - tap * s.Cout;
   *ks = p.kscale ? p.kscale[co] : 1.f;
   return p.B + ((size_t)co * (s.KH * s.KW) + tap) * s.Cin + col;
@@ -197,10 +201,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
   int kbeg = 0, kend = p.K;
-  if (ROLE == WGRAD) {
+  if (gridDim.y > 1) {
     kbeg = blockIdx.y * p.ktiles_per_split * BK;
     kend = min(p.K, kbeg + p.ktiles_per_split * BK);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend && ROLE == WGRAD) return;  // FWD/DGRAD slices must still write their (zero) slab
   }
 
   // Per-thread chunk coordinates.
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
       const int k = k0 + 4 * (tid & 7);
 #pragma unroll
       for (int j = 0; j < A_CH; ++j) {
-        const float* q = ROLE == FWD ? fwd_a_ptr(p, arow[j], k) : dgrad_a_ptr(p, arow[j], k);
+        const float* q = ROLE == FWD ? fwd_a_ptr(p, arow[j], k, kend) : dgrad_a_ptr(p, arow[j], k, kend);
         ra[j] = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
       const int k = k0 + 4 * (tid & 7);
 #pragma unroll
       for (int j = 0; j < B_CH; ++j) {
-        const float* q = fwd_b_ptr(p, n0 + tid / 8 + 32 * j, k);
+        const float* q = fwd_b_ptr(p, n0 + tid / 8 + 32 * j, k, kend);
         rb[j] = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     } else {
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
       for (int j = 0; j < B_CH; ++j) {
         const int k = k0 + tid / CPR + (256 / CPR) * j;
         float ks = 1.f;
-        const float* q = ROLE == DGRAD ? dgrad_b_ptr(p, k, col, &ks) : wgrad_b_ptr(p, k, col, kend);
+        const float* q = ROLE == DGRAD ? dgrad_b_ptr(p, k, col, &ks, kend) : wgrad_b_ptr(p, k, col, kend);
         float4 v = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (ROLE == DGRAD) { v.x *= ks; v.y *= ks; v.z *= ks; v.w *= ks; }
         rb[j] = v;
@@ -325,8 +329,17 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
       for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
-        const size_t o = (size_t)m * p.ldc + n;
         float v = acc[i][j][r];
+        if (ROLE != WGRAD && gridDim.y > 1) {  // split-K: raw partial into this slice's slab
+          p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v;
+          continue;
+        }
+        size_t o = (size_t)m * p.ldc + n;
+        if (ROLE == DGRAD && p.scatter) {
+          const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
+          const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
+          o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
+        }
         if (ROLE == WGRAD) {
           if (e.scale) v *= e.scale[m];
           atomicAdd(p.C + o, v);
@@ -340,6 +353,63 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
       }
     }
   }
+}
+
+// Fold the split-K slabs in slice order (deterministic) and apply the fused epilogue.
+__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits) {
+  const long total = (long)p.M * p.N;
+  const Epilogue& e = p.e;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % p.N);
+    const long m = i / p.N;
+    float v = 0.f;
+    for (int s = 0; s < splits; ++s) v += p.slab[((size_t)s * p.M + m) * p.ldc + n];
+    size_t o = (size_t)m * p.ldc + n;
+    if (p.scatter) {
+      const int ow = (int)(m % p.sc_Wo);
+      const long t = m / p.sc_Wo;
+      const int oh = (int)(t % p.sc_Ho), b = (int)(t / p.sc_Ho);
+      o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
+    }
+    v = v * (e.scale ? e.scale[n] : 1.f) + (e.bias ? e.bias[n] : 0.f);
+    if (e.residual) v += e.residual[o];
+    if (e.relu) v = fmaxf(v, 0.f);
+    if (e.mask) v = e.mask[o] > 0.f ? v : 0.f;
+    p.C[o] = v;
+  }
+}
+
+// How many K slices for an (ntiles, ktiles) problem: aim at >= 3 workgroups per CU, keep >= 4 K tiles
+// (128 k) per slice, at most 16 slices.
+inline int plan_splits(int ntiles, int ktiles) {
+  if (ntiles >= 512) return 1;
+  int s = ceil_div(768, ntiles);
+  if (s > ktiles / 4) s = ktiles / 4;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+template <int ROLE, int BM, int BN>
+int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const int ntiles = ceil_div(p.N, BN) * ceil_div(p.M, BM);
+  const int ktiles = ceil_div(p.K, BK);
+  int splits = plan_splits(ntiles, ktiles);
+  if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
+  if (splits <= 1) {
+    hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
+    JTSM_CHECK_LAUNCH("igemm");
+    return JTSM_OK;
+  }
+  p.ktiles_per_split = ceil_div(ktiles, splits);
+  splits = ceil_div(ktiles, p.ktiles_per_split);
+  p.slab = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  JTSM_CHECK_LAUNCH("igemm split-K");
+  const long total = (long)p.M * p.N;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(splitk_finish, dim3(blocks), dim3(256), 0, st, p, splits);
+  JTSM_CHECK_LAUNCH("splitk_finish");
+  return JTSM_OK;
 }
 
 template <int ROLE, int BM, int BN>
@@ -388,9 +458,22 @@ int jtsm_conv_out_size(const jtsm_conv_shape* s, int* out_h, int* out_w) {
   return JTSM_OK;
 }
 
+size_t jtsm_conv_workspace_bytes(const jtsm_conv_shape* s, int backward_data) {
+  if (!s || check_shape(s)) return 0;
+  const ConvShape c = to_shape(s);
+  if (c.Ho <= 0 || c.Wo <= 0) return 0;
+  long M, N, K;
+  if (!backward_data) { M = (long)c.Bn * c.Ho * c.Wo; N = c.Cout; K = (long)c.KH * c.KW * c.Cin; }
+  else if (c.KH == 1 && c.KW == 1 && c.pad == 0 && c.stride > 1) { M = (long)c.Bn * c.Ho * c.Wo; N = c.Cin; K = c.Cout; }
+  else { M = (long)c.Bn * c.H * c.W; N = c.Cin; K = (long)c.KH * c.KW * c.Cout; }
+  const int bm = N <= 64 ? 256 : 128, bn = N <= 64 ? 64 : 128;
+  const int splits = plan_splits(ceil_div(N, bn) * ceil_div(M, bm), ceil_div(K, BK));
+  return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
+}
+
 int jtsm_conv2d_forward_f32(const float* x, const float* w, float* y, const jtsm_conv_shape* s,
                             const float* scale, const float* bias, const float* residual, int relu,
-                            void* stream) {
+                            void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -405,13 +488,15 @@ int jtsm_conv2d_forward_f32(const float* x, const float* w, float* y, const jtsm
   p.A = x; p.B = w; p.C = y; p.ldc = p.N;
   p.e.scale = scale; p.e.bias = bias; p.e.residual = residual; p.e.relu = relu;
   hipStream_t st = as_stream(stream);
-  if (p.N <= 64) return launch<FWD, 256, 64>(p, 1, st);
-  return launch<FWD, 128, 128>(p, 1, st);
+  if (!workspace) workspace_bytes = 0;
+  if (p.N <= 64) return launch_split<FWD, 256, 64>(p, workspace, workspace_bytes, st);
+  return launch_split<FWD, 128, 128>(p, workspace, workspace_bytes, st);
 }
 
 int jtsm_conv2d_backward_data_f32(const float* dy, const float* w, float* dx,
                                   const jtsm_conv_shape* s, const float* kscale,
-                                  const float* accumulate, const float* relu_mask, void* stream) {
+                                  const float* accumulate, const float* relu_mask, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -427,8 +512,17 @@ int jtsm_conv2d_backward_data_f32(const float* dy, const float* w, float* dx,
   p.A = dy; p.B = w; p.C = dx; p.ldc = p.N; p.kscale = kscale;
   p.e.residual = accumulate; p.e.mask = relu_mask;
   hipStream_t st = as_stream(stream);
-  if (p.N <= 64) return launch<DGRAD, 256, 64>(p, 1, st);
-  return launch<DGRAD, 128, 128>(p, 1, st);
+  if (!workspace) workspace_bytes = 0;
+  if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask) {
+    // strided 1x1: only every stride-th input pixel receives gradient.  Zero dX, then run the dense
+    // GEMM over the OUTPUT pixels (a 1x1/stride-1 problem on the (Ho,Wo) grid) and scatter its rows.
+    JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
+    p.scatter = 1; p.sc_Ho = p.s.Ho; p.sc_Wo = p.s.Wo; p.sc_H = p.s.H; p.sc_W = p.s.W; p.sc_stride = p.s.stride;
+    p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;
+    p.M = p.s.Bn * p.s.Ho * p.s.Wo;
+  }
+  if (p.N <= 64) return launch_split<DGRAD, 256, 64>(p, workspace, workspace_bytes, st);
+  return launch_split<DGRAD, 128, 128>(p, workspace, workspace_bytes, st);
 }
 
 int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,

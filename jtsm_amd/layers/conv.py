@@ -32,6 +32,14 @@ def _timed(variant, flops, call):
     return rc
 
 
+def _workspace(s, backward_data, device):
+    """Split-K scratch for this shape (None when the layer is not split)."""
+    nbytes = L.lib().jtsm_conv_workspace_bytes(C.byref(s), backward_data)
+    if nbytes == 0:
+        return None, 0
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
+
+
 def _flops(s):
     oh, ow = out_hw(s)
     return 2.0 * s.batch * oh * ow * s.out_c * s.in_c * s.kernel_h * s.kernel_w
@@ -78,9 +86,10 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
         residual = _cl(residual)
         assert residual.shape == y.shape
     variant = "igemm_kernel<FWD,256,64>" if s.out_c <= 64 else "igemm_kernel<FWD,128,128>"
+    ws, nbytes = _workspace(s, 0, x.device)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_forward_f32(
         L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-        L.stream())), "conv2d_forward")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream())), "conv2d_forward")
     return y
 
 
@@ -95,9 +104,10 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     if relu_mask is not None:
         relu_mask = _cl(relu_mask)
     variant = "igemm_kernel<DGRAD,256,64>" if s.in_c <= 64 else "igemm_kernel<DGRAD,128,128>"
+    ws, nbytes = _workspace(s, 1, dy.device)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s), L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
-        L.stream())), "conv2d_backward_data")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream())), "conv2d_backward_data")
     return dx
 
 

@@ -79,6 +79,8 @@ def test_gradients_match(step):
     got = dict(model.named_parameters())
     worst = {}
     for n in names:
+        if n.endswith("box_predictor.det.bias"):
+            continue  # exactly zero in exact arithmetic (softmax over the bag sums to 1): pure rounding noise
         g0, g = params[n].grad, got[n].grad
         assert g is not None, n
         worst[n] = _rel(g, g0)
