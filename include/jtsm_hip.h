@@ -284,6 +284,28 @@ int jtsm_moi_pool_backward_level_f32(const float* grad, const float* rois, const
                                      int level, const int32_t* argmax, float* grad_input, int B, int C,
                                      int H, int W, int M, int pooled_h, int pooled_w, void* stream);
 
+
+/* ---------------------------------------------------------------------------
+ * SemSegFPNHead's non-GEMM layers, NHWC (no reference source: nn.GroupNorm(32, C) applied by
+ * Conv2d.forward, detectron2/layers/wrappers.py:79-82, and nn.Upsample(scale_factor=2, "bilinear",
+ * align_corners=False), detectron2/modeling/meta_arch/semantic_seg.py:126-150).
+ * group_norm: x,y (N, HW, C) with C/G a multiple of 4 and C/4 dividing 256; ReLU optionally folded in
+ * (relu != 0: y = max(.,0), and the backward gates dy by the recomputed sign).  mean/rstd: (N,G) outputs
+ * of the forward, inputs of the backward.  Reductions are two-stage in a fixed order (deterministic).
+ * ------------------------------------------------------------------------- */
+size_t jtsm_group_norm_workspace_bytes(int N, long HW, int C);
+int jtsm_group_norm_forward_f32(const float* x, const float* gamma, const float* beta, float* y,
+                                float* mean, float* rstd, void* workspace, int N, long HW, int C, int G,
+                                float eps, int relu, void* stream);
+int jtsm_group_norm_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, float* dx, float* dgamma,
+                                 float* dbeta, void* workspace, int N, long HW, int C, int G, int relu,
+                                 void* stream);
+/* y (N,2H,2W,C) <- x (N,H,W,C); backward is a gather (no atomics). */
+int jtsm_upsample_bilinear2x_forward_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int jtsm_upsample_bilinear2x_backward_f32(const float* gy, float* gx, int N, int H, int W, int C,
+                                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

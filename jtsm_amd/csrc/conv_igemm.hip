@@ -172,7 +172,7 @@ __device__ __forceinline__ const float* wgrad_b_ptr(const Params& p, int k, int 
 // ---- the kernel ------------------------------------------------------------------------------
 // BM x BN output tile, WM x WN wavefronts (WM*WN == 4), each wavefront 64x64.
 template <int ROLE, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
+__global__ __launch_bounds__(256, 4) void igemm_kernel(const Params p) {
   constexpr int WN = BN / 64;
   static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
   constexpr bool A_T = ROLE != WGRAD;  // A staged transposed (K-contiguous source)?

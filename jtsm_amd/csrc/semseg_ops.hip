@@ -1,0 +1,352 @@
+// NHWC GroupNorm(+ReLU) and bilinear x2 up-sampling — the non-GEMM layers of SemSegFPNHead
+// (detectron2/modeling/meta_arch/semantic_seg.py:126-150: Conv2d(norm=GroupNorm(32, C), activation=relu)
+// followed by nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)).  The reference runs
+// them as ATen ops on NCHW tensors; here they stay channels-last (one float4 = 4 channels of a pixel),
+// ReLU is folded into the normalisation pass, and every reduction is two-stage with a fixed fold order
+// (no float atomics -> deterministic).
+#include "common.h"
+
+namespace jtsm {
+namespace {
+
+constexpr int GN_SLAB_ROWS = 1024;  // pixels per workgroup in the statistics passes
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// ---- forward statistics: part[n][slab][chunk] = (sum, sumsq) over the slab's pixels of the chunk's 4
+// channels.  Requires 256 % (C/4) == 0 so that a thread always visits the same chunk.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, float2* __restrict__ part,
+                                                       int HW, int C, int slabs) {
+  __shared__ float2 red[256];
+  const int C4 = C / 4, n = blockIdx.y, slab = blockIdx.x;
+  const int p0 = slab * GN_SLAB_ROWS, p1 = min(HW, p0 + GN_SLAB_ROWS);
+  const float* base = x + (size_t)n * HW * C;
+  float s = 0.f, q = 0.f;
+  for (long it = (long)p0 * C4 + threadIdx.x; it < (long)p1 * C4; it += 256) {
+    const float4 v = ld4(base + it * 4);
+    s += (v.x + v.y) + (v.z + v.w);
+    q += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  red[threadIdx.x] = make_float2(s, q);
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float2 a = make_float2(0.f, 0.f);
+    for (int t = threadIdx.x; t < 256; t += C4) { a.x += red[t].x; a.y += red[t].y; }
+    part[((size_t)n * slabs + slab) * C4 + threadIdx.x] = a;
+  }
+}
+
+// mean / rstd per (n, group) from the partials, folded in slab order in double.
+__global__ void gn_fold_kernel(const float2* __restrict__ part, float* __restrict__ mean,
+                               float* __restrict__ rstd, int HW, int C, int G, int slabs, float eps) {
+  const int n = blockIdx.x, g = threadIdx.x;
+  if (g >= G) return;
+  const int C4 = C / 4, cpg4 = C4 / G;
+  double s = 0.0, q = 0.0;
+  for (int sl = 0; sl < slabs; ++sl)
+    for (int k = 0; k < cpg4; ++k) {
+      const float2 v = part[((size_t)n * slabs + sl) * C4 + g * cpg4 + k];
+      s += v.x; q += v.y;
+    }
+  const double m = (double)HW * (C / G);
+  const double mu = s / m;
+  double var = q / m - mu * mu;
+  if (var < 0.0) var = 0.0;
+  mean[n * G + g] = (float)mu;
+  rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// y = relu?((x - mean) * rstd * gamma + beta)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y,
+                                                       long HW, int C, int G, int relu, long total4) {
+  const int C4 = C / 4, cpg4 = C4 / G;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long n = i / C4 / HW;
+    const int g = c4 / cpg4;
+    const float mu = mean[n * G + g], rs = rstd[n * G + g];
+    const float4 v = ld4(x + i * 4), ga = ld4(gamma + c4 * 4), be = ld4(beta + c4 * 4);
+    float4 o;
+    o.x = (v.x - mu) * rs * ga.x + be.x;
+    o.y = (v.y - mu) * rs * ga.y + be.y;
+    o.z = (v.z - mu) * rs * ga.z + be.z;
+    o.w = (v.w - mu) * rs * ga.w + be.w;
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4(y + i * 4, o);
+  }
+}
+
+// ---- backward statistics: per (n, slab, channel): A = sum dyr, B = sum dyr * xhat, where
+// dyr = dy gated by the ReLU (z = xhat*gamma+beta > 0).
+__global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           float4* __restrict__ partA, float4* __restrict__ partB,
+                                                           int HW, int C, int G, int slabs, int relu) {
+  __shared__ float4 ra[256], rb[256];
+  const int C4 = C / 4, cpg4 = C4 / G, n = blockIdx.y, slab = blockIdx.x;
+  const int p0 = slab * GN_SLAB_ROWS, p1 = min(HW, p0 + GN_SLAB_ROWS);
+  const size_t base = (size_t)n * HW * C;
+  const int c4 = threadIdx.x % C4;
+  const int g = c4 / cpg4;
+  const float mu = mean[n * G + g], rs = rstd[n * G + g];
+  const float4 ga = ld4(gamma + c4 * 4), be = ld4(beta + c4 * 4);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  for (long it = (long)p0 * C4 + threadIdx.x; it < (long)p1 * C4; it += 256) {
+    const float4 v = ld4(x + base + it * 4);
+    float4 d = ld4(dy + base + it * 4);
+    float4 h;
+    h.x = (v.x - mu) * rs; h.y = (v.y - mu) * rs; h.z = (v.z - mu) * rs; h.w = (v.w - mu) * rs;
+    if (relu) {
+      if (!(h.x * ga.x + be.x > 0.f)) d.x = 0.f;
+      if (!(h.y * ga.y + be.y > 0.f)) d.y = 0.f;
+      if (!(h.z * ga.z + be.z > 0.f)) d.z = 0.f;
+      if (!(h.w * ga.w + be.w > 0.f)) d.w = 0.f;
+    }
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+    b.x += d.x * h.x; b.y += d.y * h.y; b.z += d.z * h.z; b.w += d.w * h.w;
+  }
+  ra[threadIdx.x] = a; rb[threadIdx.x] = b;
+  __syncthreads();
+  if (threadIdx.x < C4) {
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    for (int t = threadIdx.x; t < 256; t += C4) {
+      sa.x += ra[t].x; sa.y += ra[t].y; sa.z += ra[t].z; sa.w += ra[t].w;
+      sb.x += rb[t].x; sb.y += rb[t].y; sb.z += rb[t].z; sb.w += rb[t].w;
+    }
+    partA[((size_t)n * slabs + slab) * C4 + threadIdx.x] = sa;
+    partB[((size_t)n * slabs + slab) * C4 + threadIdx.x] = sb;
+  }
+}
+
+// Fold: per (n, c): A, B totals; per (n, g): S1 = sum gamma*A, S2 = sum gamma*B; dgamma/dbeta per channel.
+// One workgroup, thread = channel.
+__global__ void gn_bwd_fold_kernel(const float* __restrict__ partA, const float* __restrict__ partB,
+                                   const float* __restrict__ gamma, float* __restrict__ s1,
+                                   float* __restrict__ s2, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                   int N, int C, int G, int slabs) {
+  extern __shared__ float sh[];  // [2][C]
+  const int c = threadIdx.x, cpg = C / G;
+  float dg = 0.f, db = 0.f;
+  for (int n = 0; n < N; ++n) {
+    float a = 0.f, b = 0.f;
+    if (c < C)
+      for (int sl = 0; sl < slabs; ++sl) {
+        a += partA[((size_t)n * slabs + sl) * C + c];
+        b += partB[((size_t)n * slabs + sl) * C + c];
+      }
+    dg += b; db += a;
+    __syncthreads();
+    if (c < C) { sh[c] = gamma[c] * a; sh[C + c] = gamma[c] * b; }
+    __syncthreads();
+    if (c < G) {
+      float x1 = 0.f, x2 = 0.f;
+      for (int k = 0; k < cpg; ++k) { x1 += sh[c * cpg + k]; x2 += sh[C + c * cpg + k]; }
+      s1[n * G + c] = x1; s2[n * G + c] = x2;
+    }
+  }
+  if (c < C) { dgamma[c] = dg; dbeta[c] = db; }
+}
+
+// dx = rstd * (gamma * dyr - (S1 + xhat * S2) / m)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ s1,
+                                                           const float* __restrict__ s2, float* __restrict__ dx,
+                                                           long HW, int C, int G, int relu, long total4) {
+  const int C4 = C / 4, cpg4 = C4 / G;
+  const float inv_m = 1.f / ((float)HW * (float)(C / G));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const long n = i / C4 / HW;
+    const int g = c4 / cpg4;
+    const float mu = mean[n * G + g], rs = rstd[n * G + g];
+    const float a = s1[n * G + g] * inv_m, b = s2[n * G + g] * inv_m;
+    const float4 v = ld4(x + i * 4), ga = ld4(gamma + c4 * 4), be = ld4(beta + c4 * 4);
+    float4 d = ld4(dy + i * 4), h, o;
+    h.x = (v.x - mu) * rs; h.y = (v.y - mu) * rs; h.z = (v.z - mu) * rs; h.w = (v.w - mu) * rs;
+    if (relu) {
+      if (!(h.x * ga.x + be.x > 0.f)) d.x = 0.f;
+      if (!(h.y * ga.y + be.y > 0.f)) d.y = 0.f;
+      if (!(h.z * ga.z + be.z > 0.f)) d.z = 0.f;
+      if (!(h.w * ga.w + be.w > 0.f)) d.w = 0.f;
+    }
+    o.x = rs * (ga.x * d.x - a - h.x * b);
+    o.y = rs * (ga.y * d.y - a - h.y * b);
+    o.z = rs * (ga.z * d.z - a - h.z * b);
+    o.w = rs * (ga.w * d.w - a - h.w * b);
+    st4(dx + i * 4, o);
+  }
+}
+
+// ---- bilinear x2 (align_corners = False): src coordinate of dst o is o/2 - 0.25 clamped at 0 -----------
+struct Lerp { int i0, i1; float l; };
+__device__ __forceinline__ Lerp lerp_of(int o, int n_src) {
+  float s = ((float)o + 0.5f) * 0.5f - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lerp r;
+  r.i0 = (int)s;
+  r.i1 = r.i0 < n_src - 1 ? r.i0 + 1 : r.i0;
+  r.l = s - (float)r.i0;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+                                                      int H, int W, int C4, long total4) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const Lerp a = lerp_of(oh, H), b = lerp_of(ow, W);
+    const float* base = x + (size_t)n * H * W * C4 * 4;
+    const float4 v00 = ld4(base + ((size_t)(a.i0 * W + b.i0) * C4 + c) * 4);
+    const float4 v01 = ld4(base + ((size_t)(a.i0 * W + b.i1) * C4 + c) * 4);
+    const float4 v10 = ld4(base + ((size_t)(a.i1 * W + b.i0) * C4 + c) * 4);
+    const float4 v11 = ld4(base + ((size_t)(a.i1 * W + b.i1) * C4 + c) * 4);
+    const float w00 = (1.f - a.l) * (1.f - b.l), w01 = (1.f - a.l) * b.l, w10 = a.l * (1.f - b.l), w11 = a.l * b.l;
+    float4 o;
+    o.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
+    o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
+    o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
+    o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+    st4(y + i * 4, o);
+  }
+}
+
+// backward as a gather: source pixel (h,w) collects from the <= 4x4 destination pixels that sample it.
+__device__ __forceinline__ float weight_on(int o, int n_src, int i) {
+  const Lerp r = lerp_of(o, n_src);
+  return (r.i0 == i ? 1.f - r.l : 0.f) + (r.i1 == i ? r.l : 0.f);
+}
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ gy, float* __restrict__ gx, int N,
+                                                      int H, int W, int C4, long total4) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    const float* base = gy + (size_t)n * Ho * Wo * C4 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int oh = max(2 * h - 1, 0); oh <= min(2 * h + 2, Ho - 1); ++oh) {
+      const float wy = weight_on(oh, H, h);
+      if (wy == 0.f) continue;
+      for (int ow = max(2 * w - 1, 0); ow <= min(2 * w + 2, Wo - 1); ++ow) {
+        const float wx = weight_on(ow, W, w);
+        if (wx == 0.f) continue;
+        const float4 g = ld4(base + ((size_t)(oh * Wo + ow) * C4 + c) * 4);
+        const float ww = wy * wx;
+        acc.x += ww * g.x; acc.y += ww * g.y; acc.z += ww * g.z; acc.w += ww * g.w;
+      }
+    }
+    st4(gx + i * 4, acc);
+  }
+}
+
+inline int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
+inline size_t a16(size_t b) { return (b + 15) & ~(size_t)15; }
+inline int gn_slabs(long HW) { return (int)((HW + GN_SLAB_ROWS - 1) / GN_SLAB_ROWS); }
+
+int gn_check(int N, long HW, int C, int G) {
+  JTSM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && (C / G) % 4 == 0,
+               "group_norm: channels per group must be a multiple of 4 (C=%d G=%d)", C, G);
+  JTSM_REQUIRE(256 % (C / 4) == 0 && C <= 1024, "group_norm: C/4 must divide 256 (C=%d)", C);
+  return JTSM_OK;
+}
+
+}  // namespace
+}  // namespace jtsm
+
+using namespace jtsm;
+
+extern "C" {
+
+size_t jtsm_group_norm_workspace_bytes(int N, long HW, int C) {
+  if (N <= 0 || HW <= 0 || C <= 0) return 16;
+  // forward needs N*slabs*(C/4) float2; backward 2 * N*slabs*C floats + 2*N*G (<= C) floats
+  return a16((size_t)N * gn_slabs(HW) * C * sizeof(float) * 2) + a16((size_t)2 * N * C * sizeof(float)) + 16;
+}
+
+int jtsm_group_norm_forward_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                float* rstd, void* workspace, int N, long HW, int C, int G, float eps, int relu,
+                                void* stream) {
+  int rc = gn_check(N, HW, C, G);
+  if (rc) return rc;
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && gamma && beta && y && mean && rstd && workspace, "group_norm: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int slabs = gn_slabs(HW);
+  float2* part = reinterpret_cast<float2*>(workspace);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, N), dim3(256), 0, st, x, part, (int)HW, C, slabs);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(N), dim3(((G + 63) / 64) * 64), 0, st, part, mean, rstd, (int)HW, C, G,
+                     slabs, eps);
+  const long total4 = (long)N * HW * (C / 4);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, rstd, gamma, beta, y, HW,
+                     C, G, relu, total4);
+  JTSM_CHECK_LAUNCH("group_norm forward");
+  return JTSM_OK;
+}
+
+int jtsm_group_norm_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
+                                 void* workspace, int N, long HW, int C, int G, int relu, void* stream) {
+  int rc = gn_check(N, HW, C, G);
+  if (rc) return rc;
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta && workspace,
+               "group_norm backward: null pointer");
+  hipStream_t st = as_stream(stream);
+  const int slabs = gn_slabs(HW);
+  char* w = reinterpret_cast<char*>(workspace);
+  float* partA = reinterpret_cast<float*>(w);
+  float* partB = partA + (size_t)N * slabs * C;
+  float* s1 = reinterpret_cast<float*>(w + a16((size_t)N * slabs * C * sizeof(float) * 2));
+  float* s2 = s1 + (size_t)N * C;
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(slabs, N), dim3(256), 0, st, x, dy, mean, rstd, gamma, beta,
+                     reinterpret_cast<float4*>(partA), reinterpret_cast<float4*>(partB), (int)HW, C, G, slabs, relu);
+  const int threads = ((C + 63) / 64) * 64;
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(1), dim3(threads), 2 * C * sizeof(float), st, partA, partB, gamma, s1,
+                     s2, dgamma, dbeta, N, C, G, slabs);
+  const long total4 = (long)N * HW * (C / 4);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, dy, mean, rstd, gamma, beta,
+                     s1, s2, dx, HW, C, G, relu, total4);
+  JTSM_CHECK_LAUNCH("group_norm backward");
+  return JTSM_OK;
+}
+
+int jtsm_upsample_bilinear2x_forward_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x: bad sizes");
+  const long total4 = (long)N * 2 * H * 2 * W * (C / 4);
+  if (total4 == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && y, "upsample2x: null pointer");
+  hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, y, N, H, W, C / 4,
+                     total4);
+  JTSM_CHECK_LAUNCH("upsample2x forward");
+  return JTSM_OK;
+}
+
+int jtsm_upsample_bilinear2x_backward_f32(const float* gy, float* gx, int N, int H, int W, int C, void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x backward: bad sizes");
+  const long total4 = (long)N * H * W * (C / 4);
+  if (total4 == 0) return JTSM_OK;
+  JTSM_REQUIRE(gy && gx, "upsample2x backward: null pointer");
+  hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), gy, gx, N, H, W,
+                     C / 4, total4);
+  JTSM_CHECK_LAUNCH("upsample2x backward");
+  return JTSM_OK;
+}
+
+}  // extern "C"

@@ -24,8 +24,17 @@ class FrozenBatchNorm2d(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features) - eps)
 
     def scale_bias(self):
-        scale = self.weight * (self.running_var + self.eps).rsqrt()
-        return scale, self.bias - self.running_mean * scale
+        """(scale, bias) of the affine map; cached until any of the four buffers is written
+        (tensor version counters), so a frozen layer costs no launches per step."""
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.data_ptr(), self.weight.device)
+        cache = self.__dict__.get("_sb_cache")
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + self.eps).rsqrt()
+                cache = (key, scale, self.bias - self.running_mean * scale)
+            self.__dict__["_sb_cache"] = cache
+        return cache[1], cache[2]
 
     def forward(self, x):
         scale, bias = self.scale_bias()

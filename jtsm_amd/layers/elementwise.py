@@ -122,3 +122,67 @@ class _Subsample2(torch.autograd.Function):
 def subsample2(x):
     """F.max_pool2d(x, kernel_size=1, stride=2, padding=0)."""
     return _Subsample2.apply(x)
+
+
+class _GroupNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        x = _cl4(x)
+        n, c, h, w = x.shape
+        lib = L.lib()
+        y = torch.empty_like(x)
+        mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(lib.jtsm_group_norm_workspace_bytes(n, C.c_long(h * w), c), dtype=torch.uint8, device=x.device)
+        L.check(lib.jtsm_group_norm_forward_f32(L.ptr(x), L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(mean),
+                                                L.ptr(rstd), L.ptr(ws), n, C.c_long(h * w), c, groups, L.f32(eps),
+                                                int(relu), L.stream()), "group_norm_forward")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (groups, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        n, c, h, w = x.shape
+        dy = dy.contiguous(memory_format=CL)
+        lib = L.lib()
+        dx = torch.empty_like(x)
+        dg, db = torch.empty_like(gamma), torch.empty_like(beta)
+        ws = torch.empty(lib.jtsm_group_norm_workspace_bytes(n, C.c_long(h * w), c), dtype=torch.uint8, device=x.device)
+        L.check(lib.jtsm_group_norm_backward_f32(L.ptr(x), L.ptr(dy), L.ptr(gamma), L.ptr(beta), L.ptr(mean),
+                                                 L.ptr(rstd), L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), n,
+                                                 C.c_long(h * w), c, groups, int(relu), L.stream()),
+                "group_norm_backward")
+        return dx, dg, db, None, None, None
+
+
+def group_norm_relu(x, gamma, beta, groups, eps=1e-5, relu=True):
+    """F.relu(F.group_norm(x, groups, gamma, beta, eps)) on a channels_last tensor, one fused pass."""
+    return _GroupNormReLU.apply(x, gamma, beta, groups, eps, relu)
+
+
+class _UpBilinear2x(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _cl4(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=CL)
+        L.check(L.lib().jtsm_upsample_bilinear2x_forward_f32(L.ptr(x), L.ptr(y), n, h, w, c, L.stream()), "upsample2x")
+        ctx.shape = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        n, c, h, w = ctx.shape
+        gy = gy.contiguous(memory_format=CL)
+        gx = torch.empty((n, c, h, w), dtype=gy.dtype, device=gy.device, memory_format=CL)
+        L.check(L.lib().jtsm_upsample_bilinear2x_backward_f32(L.ptr(gy), L.ptr(gx), n, h, w, c, L.stream()),
+                "upsample2x backward")
+        return gx
+
+
+def upsample_bilinear2x(x):
+    """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), channels_last."""
+    return _UpBilinear2x.apply(x)

@@ -69,6 +69,14 @@ class Conv2d(nn.Conv2d):
             w = self.weight
         y = conv2d_fused(x, w, scale, bias, residual, self.stride[0], self.padding[0], self.dilation[0], relu,
                          bias_grad)
+        if isinstance(self.norm, nn.GroupNorm) and self.norm.affine and y.is_cuda and y.dtype == torch.float32:
+            # GroupNorm (+ the following ReLU) as one channels-last pass (jtsm_amd/csrc/semseg_ops.hip)
+            from .elementwise import group_norm_relu
+            act_relu = _is_relu(self.activation)
+            y = group_norm_relu(y, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, act_relu)
+            if self.activation is not None and not act_relu:
+                y = self.activation(y)
+            return y
         if self.norm is not None and not fuse_norm:
             y = self.norm(y)
         if self.activation is not None and not relu:

@@ -1,8 +1,9 @@
 """SemSegFPNHead — surface of detectron2/modeling/meta_arch/semantic_seg.py:95-188.
 Per FPN level: [conv3x3 -> GroupNorm(32) -> ReLU (-> bilinear x2)] x log2(stride/4), summed, 1x1
 predictor; loss = CE(bilinear x4 of the logits, target, ignore 255) * LOSS_WEIGHT.
-The 3x3 / 1x1 convolutions are MFMA launches; GroupNorm, the bilinear resampling and the
-cross-entropy currently run as PyTorch-ROCm device ops (listed as not-yet-native in DESIGN.md)."""
+The 3x3 / 1x1 convolutions are MFMA launches, GroupNorm+ReLU and the x2 bilinear up-sampling are
+channels-last HIP kernels (csrc/semseg_ops.hip); the final x4 up-sampling + cross-entropy still run as
+PyTorch-ROCm device ops (listed as not-yet-native in DESIGN.md)."""
 from typing import Dict
 
 import numpy as np
@@ -15,6 +16,14 @@ from ...layers.wrappers import Conv2d
 from ...utils.registry import Registry
 
 SEM_SEG_HEADS_REGISTRY = Registry("SEM_SEG_HEADS")
+
+
+class UpsampleBilinear2x(nn.Module):
+    """nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False) on channels_last tensors."""
+
+    def forward(self, x):
+        from ...layers.elementwise import upsample_bilinear2x
+        return upsample_bilinear2x(x)
 
 
 def build_sem_seg_head(cfg, input_shape):
@@ -47,7 +56,7 @@ class SemSegFPNHead(nn.Module):
                     nn.init.constant_(conv.bias, 0)
                 head_ops.append(conv)
                 if feature_strides[in_feature] != self.common_stride:
-                    head_ops.append(nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False))
+                    head_ops.append(UpsampleBilinear2x())
             self.scale_heads.append(nn.Sequential(*head_ops))
             self.add_module(in_feature, self.scale_heads[-1])
         self.predictor = Conv2d(conv_dims, num_classes, kernel_size=1, stride=1, padding=0)

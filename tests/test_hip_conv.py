@@ -208,3 +208,40 @@ def test_spatial_helpers_match_torch(cuda):
         gs = torch.randn(s0.shape, generator=g)
         s.backward(gs.to(cuda)); s0.backward(gs)
         assert torch.equal(xd.grad.cpu(), xr.grad)
+
+
+def test_group_norm_relu_and_bilinear2x_vs_torch_cpu(cuda):
+    """SemSegFPNHead's non-GEMM layers: fused GroupNorm(32)+ReLU and bilinear x2 (align_corners=False),
+    forward and backward, against the stock torch ops the reference uses (CPU)."""
+    import torch.nn.functional as F
+
+    from jtsm_amd.layers.elementwise import group_norm_relu, upsample_bilinear2x
+
+    g = torch.Generator().manual_seed(10)
+    for (n, c, h, w, relu) in [(2, 128, 33, 40, True), (1, 128, 64, 64, False), (2, 256, 9, 7, True)]:
+        x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+        ga, be = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+        xr, gar, ber = x.clone().requires_grad_(), ga.clone().requires_grad_(), be.clone().requires_grad_()
+        y0 = F.group_norm(xr, 32, gar, ber, 1e-5)
+        y0 = F.relu(y0) if relu else y0
+        dy = torch.randn(y0.shape, generator=g)
+        y0.backward(dy)
+        xd = x.to(cuda).contiguous(memory_format=CL).requires_grad_()
+        gad, bed = ga.to(cuda).requires_grad_(), be.to(cuda).requires_grad_()
+        y = group_norm_relu(xd, gad, bed, 32, 1e-5, relu)
+        close(y, y0, "gn fwd")
+        y.backward(dy.to(cuda))
+        close(xd.grad, xr.grad, "gn dx")
+        close(gad.grad, gar.grad, "gn dgamma")
+        close(bed.grad, ber.grad, "gn dbeta")
+    for (n, c, h, w) in [(2, 128, 16, 20), (1, 8, 1, 5), (1, 4, 7, 1)]:
+        x = torch.randn(n, c, h, w, generator=g)
+        xr = x.clone().requires_grad_()
+        y0 = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=False)
+        dy = torch.randn(y0.shape, generator=g)
+        y0.backward(dy)
+        xd = x.to(cuda).contiguous(memory_format=CL).requires_grad_()
+        y = upsample_bilinear2x(xd)
+        close(y, y0, "up2 fwd")
+        y.backward(dy.to(cuda))
+        close(xd.grad, xr.grad, "up2 bwd")
