@@ -256,6 +256,126 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---- fused bilinear xS up-sampling + softmax cross-entropy (semantic_seg.py:179-188) ------------------
+// The reference materialises the (N, 54, H, W) up-sampled logits (226 MB per 1024^2 image), then
+// log_softmax, then nll_loss — ~0.7 GB of HBM traffic per image forward+backward.  Here the full-resolution
+// logits never exist: every output pixel's logits are interpolated on the fly from the stride-S map
+// (wavefront per pixel, lanes = classes, C <= 64), reduced to a log-sum-exp with wavefront shuffles, and
+// only lse (4 B per pixel) is kept for the backward, which is a GATHER over the <= (2S)^2 output pixels
+// that touch each source pixel (no atomics, deterministic).
+struct LerpS { int i0, i1; float l0, l1; };
+__device__ __forceinline__ LerpS lerp_scale(int o, int n_src, float inv_scale) {
+  float s = ((float)o + 0.5f) * inv_scale - 0.5f;
+  if (s < 0.f) s = 0.f;
+  LerpS r;
+  r.i0 = (int)s;
+  r.i1 = r.i0 < n_src - 1 ? r.i0 + 1 : r.i0;
+  r.l1 = s - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float interp_logit(const float* __restrict__ zn, int Ws, int ldc, const LerpS& a,
+                                              const LerpS& b, int c) {
+  const float v00 = zn[((size_t)a.i0 * Ws + b.i0) * ldc + c], v01 = zn[((size_t)a.i0 * Ws + b.i1) * ldc + c];
+  const float v10 = zn[((size_t)a.i1 * Ws + b.i0) * ldc + c], v11 = zn[((size_t)a.i1 * Ws + b.i1) * ldc + c];
+  return a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11);   // ATen's association
+}
+
+__global__ __launch_bounds__(256) void ce_up_fwd_kernel(const float* __restrict__ z, int ldc, int C,
+                                                        const long* __restrict__ target, float* __restrict__ lse,
+                                                        float* __restrict__ part, int N, int Hs, int Ws, int S,
+                                                        long ignore) {
+  __shared__ float red[4][2];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int H = Hs * S, W = Ws * S;
+  const long npix = (long)N * H * W;
+  const float inv = 1.f / (float)S;
+  float loss = 0.f, cnt = 0.f;
+  for (long p = (long)blockIdx.x * 4 + wv; p < npix; p += (long)gridDim.x * 4) {
+    const long t = target[p];
+    const int ow = (int)(p % W);
+    const long q = p / W;
+    const int oh = (int)(q % H), n = (int)(q / H);
+    const LerpS a = lerp_scale(oh, Hs, inv), b = lerp_scale(ow, Ws, inv);
+    const float* zn = z + (size_t)n * Hs * Ws * ldc;
+    const float v = lane < C ? interp_logit(zn, Ws, ldc, a, b, lane) : -3.0e38f;
+    const float mx = wmax(v);
+    const float sm = wsum(lane < C ? __expf(v - mx) : 0.f);
+    const float l = mx + __logf(sm);
+    if (lane == 0) lse[p] = l;
+    if (t != ignore) {
+      const float vt = __shfl(v, (int)t);
+      loss += l - vt;
+      cnt += 1.f;
+    }
+  }
+  if (lane == 0) { red[wv][0] = loss; red[wv][1] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 2)
+    part[blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[0] = mean loss over non-ignored pixels, out[1] = their count
+__global__ void ce_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double l = 0.0, c = 0.0;
+    for (int b = 0; b < nblocks; ++b) { l += part[2 * b]; c += part[2 * b + 1]; }
+    out[0] = (float)(l / c);
+    out[1] = (float)c;
+  }
+}
+
+// dz[n,h,w,c] = up/count * sum over output pixels o touching (h,w) of weight(o -> (h,w)) * (softmax_o[c] - [c == t_o])
+__global__ __launch_bounds__(256) void ce_up_bwd_kernel(const float* __restrict__ z, int ldc, int C,
+                                                        const long* __restrict__ target,
+                                                        const float* __restrict__ lse, const float* __restrict__ fin,
+                                                        const float* __restrict__ upstream, float* __restrict__ dz,
+                                                        int N, int Hs, int Ws, int S, long ignore) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int H = Hs * S, W = Ws * S;
+  const long nsrc = (long)N * Hs * Ws;
+  const float inv = 1.f / (float)S;
+  const float k = (upstream ? *upstream : 1.f) / fin[1];
+  for (long p = (long)blockIdx.x * 4 + wv; p < nsrc; p += (long)gridDim.x * 4) {
+    const int w = (int)(p % Ws);
+    const long q = p / Ws;
+    const int h = (int)(q % Hs), n = (int)(q / Hs);
+    const float* zn = z + (size_t)n * Hs * Ws * ldc;
+    float acc = 0.f;
+    const int oh0 = max(S * h - S, 0), oh1 = min(S * h + 2 * S, H);   // superset of the rows touching h
+    const int ow0 = max(S * w - S, 0), ow1 = min(S * w + 2 * S, W);
+    for (int oh = oh0; oh < oh1; ++oh) {
+      const LerpS a = lerp_scale(oh, Hs, inv);
+      const float wy = (a.i0 == h ? a.l0 : 0.f) + (a.i1 == h ? a.l1 : 0.f);
+      if (wy == 0.f) continue;
+      for (int ow = ow0; ow < ow1; ++ow) {
+        const LerpS b = lerp_scale(ow, Ws, inv);
+        const float wx = (b.i0 == w ? b.l0 : 0.f) + (b.i1 == w ? b.l1 : 0.f);
+        if (wx == 0.f) continue;
+        const long o = ((long)n * H + oh) * W + ow;
+        const long t = target[o];
+        if (t == ignore) continue;
+        if (lane < C) {
+          const float v = interp_logit(zn, Ws, ldc, a, b, lane);
+          acc += wy * wx * (__expf(v - lse[o]) - (lane == (int)t ? 1.f : 0.f));
+        }
+      }
+    }
+    if (lane < ldc) dz[(size_t)p * ldc + lane] = lane < C ? acc * k : 0.f;
+  }
+}
+
 inline int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
 inline size_t a16(size_t b) { return (b + 15) & ~(size_t)15; }
 inline int gn_slabs(long HW) { return (int)((HW + GN_SLAB_ROWS - 1) / GN_SLAB_ROWS); }
@@ -346,6 +466,49 @@ int jtsm_upsample_bilinear2x_backward_f32(const float* gy, float* gx, int N, int
   hipLaunchKernelGGL(up2_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), gy, gx, N, H, W,
                      C / 4, total4);
   JTSM_CHECK_LAUNCH("upsample2x backward");
+  return JTSM_OK;
+}
+
+#define CE_BLOCKS 2048
+
+size_t jtsm_semseg_ce_workspace_bytes(int N, int Hs, int Ws, int S) {
+  if (N <= 0 || Hs <= 0 || Ws <= 0 || S <= 0) return 16;
+  return a16((size_t)N * Hs * S * Ws * S * sizeof(float)) + a16((size_t)CE_BLOCKS * 2 * sizeof(float)) + 16;
+}
+
+int jtsm_semseg_ce_forward_f32(const float* logits, int ld, int C, const int64_t* target, float* out,
+                               void* workspace, int N, int Hs, int Ws, int S, long ignore_index, void* stream) {
+  JTSM_REQUIRE(N >= 0 && Hs > 0 && Ws > 0 && S > 0 && C > 0 && C <= 64 && ld >= C && ld <= 64,
+               "semseg_ce: need C <= ld <= 64 (C=%d ld=%d)", C, ld);
+  JTSM_REQUIRE(out, "semseg_ce: null out");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(logits && target && workspace, "semseg_ce: null pointer");
+  hipStream_t st = as_stream(stream);
+  float* lse = reinterpret_cast<float*>(workspace);
+  float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
+                                         a16((size_t)N * Hs * S * Ws * S * sizeof(float)));
+  const long npix = (long)N * Hs * S * Ws * S;
+  int blocks = (int)((npix + 3) / 4 < CE_BLOCKS ? (npix + 3) / 4 : CE_BLOCKS);
+  hipLaunchKernelGGL(ce_up_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ld, C, (const long*)target, lse, part,
+                     N, Hs, Ws, S, ignore_index);
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, out);
+  JTSM_CHECK_LAUNCH("semseg_ce forward");
+  return JTSM_OK;
+}
+
+int jtsm_semseg_ce_backward_f32(const float* logits, int ld, int C, const int64_t* target, const float* fwd_out,
+                                const float* upstream, float* dlogits, const void* workspace, int N, int Hs, int Ws,
+                                int S, long ignore_index, void* stream) {
+  JTSM_REQUIRE(N >= 0 && Hs > 0 && Ws > 0 && S > 0 && C > 0 && C <= 64 && ld >= C && ld <= 64,
+               "semseg_ce backward: need C <= ld <= 64");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(logits && target && fwd_out && dlogits && workspace, "semseg_ce backward: null pointer");
+  const float* lse = reinterpret_cast<const float*>(workspace);
+  const long nsrc = (long)N * Hs * Ws;
+  int blocks = (int)((nsrc + 3) / 4 < 8192 ? (nsrc + 3) / 4 : 8192);
+  hipLaunchKernelGGL(ce_up_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), logits, ld, C,
+                     (const long*)target, lse, fwd_out, upstream, dlogits, N, Hs, Ws, S, ignore_index);
+  JTSM_CHECK_LAUNCH("semseg_ce backward");
   return JTSM_OK;
 }
 

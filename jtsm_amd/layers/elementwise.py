@@ -186,3 +186,45 @@ class _UpBilinear2x(torch.autograd.Function):
 def upsample_bilinear2x(x):
     """F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), channels_last."""
     return _UpBilinear2x.apply(x)
+
+
+class _SemSegCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, scale, ignore_index):
+        L.require_gpu(logits, target)
+        n, c, hs, ws = logits.shape
+        # channels-last storage with an arbitrary channel pitch (a [:, :54] slice of a 56-wide map is fine)
+        if not (logits.stride(1) == 1 and logits.stride(3) >= c and logits.stride(2) == ws * logits.stride(3)
+                and logits.stride(0) == hs * logits.stride(2)):
+            logits = logits.contiguous(memory_format=CL)
+        ld = logits.stride(3)
+        target = target.to(torch.int64).contiguous()
+        if tuple(target.shape) != (n, hs * scale, ws * scale):
+            raise RuntimeError("semseg_ce: target %s is not %dx the logits %s" % (tuple(target.shape), scale,
+                                                                                   tuple(logits.shape)))
+        lib = L.lib()
+        out = torch.empty(2, dtype=torch.float32, device=logits.device)
+        wsb = torch.empty(lib.jtsm_semseg_ce_workspace_bytes(n, hs, ws, scale), dtype=torch.uint8, device=logits.device)
+        L.check(lib.jtsm_semseg_ce_forward_f32(L.ptr(logits), ld, c, L.ptr(target), L.ptr(out), L.ptr(wsb), n, hs, ws,
+                                               scale, C.c_long(ignore_index), L.stream()), "semseg_ce_forward")
+        ctx.save_for_backward(logits, target, out, wsb)
+        ctx.cfg = (ld, scale, ignore_index)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, target, out, wsb = ctx.saved_tensors
+        ld, scale, ignore_index = ctx.cfg
+        n, c, hs, ws = logits.shape
+        dfull = torch.empty((n, hs, ws, ld), dtype=torch.float32, device=logits.device)
+        g = g.to(torch.float32).contiguous()
+        L.check(L.lib().jtsm_semseg_ce_backward_f32(L.ptr(logits), ld, c, L.ptr(target), L.ptr(out), L.ptr(g),
+                                                    L.ptr(dfull), L.ptr(wsb), n, hs, ws, scale,
+                                                    C.c_long(ignore_index), L.stream()), "semseg_ce_backward")
+        return dfull.permute(0, 3, 1, 2)[:, :c], None, None, None
+
+
+def semseg_cross_entropy(logits, target, scale=4, ignore_index=255):
+    """F.cross_entropy(F.interpolate(logits, scale_factor=scale, mode="bilinear", align_corners=False),
+    target, reduction="mean", ignore_index=ignore_index) without materialising the up-sampled logits."""
+    return _SemSegCE.apply(logits, target, int(scale), int(ignore_index))

@@ -2,8 +2,8 @@
 Per FPN level: [conv3x3 -> GroupNorm(32) -> ReLU (-> bilinear x2)] x log2(stride/4), summed, 1x1
 predictor; loss = CE(bilinear x4 of the logits, target, ignore 255) * LOSS_WEIGHT.
 The 3x3 / 1x1 convolutions are MFMA launches, GroupNorm+ReLU and the x2 bilinear up-sampling are
-channels-last HIP kernels (csrc/semseg_ops.hip); the final x4 up-sampling + cross-entropy still run as
-PyTorch-ROCm device ops (listed as not-yet-native in DESIGN.md)."""
+channels-last HIP kernels, and the x4 up-sampling + cross-entropy is one fused kernel that never
+materialises the full-resolution logits (all in csrc/semseg_ops.hip)."""
 from typing import Dict
 
 import numpy as np
@@ -77,7 +77,9 @@ class SemSegFPNHead(nn.Module):
         return self.predictor(x)
 
     def losses(self, predictions, targets):
-        predictions = F.interpolate(predictions.float(), scale_factor=self.common_stride, mode="bilinear",
-                                    align_corners=False)
-        loss = F.cross_entropy(predictions, targets, reduction="mean", ignore_index=self.ignore_value)
+        from ...layers.elementwise import semseg_cross_entropy
+        if predictions.is_cuda and predictions.shape[1] <= 64 and self.common_stride == int(self.common_stride):
+            loss = semseg_cross_entropy(predictions.float(), targets, int(self.common_stride), self.ignore_value)
+        else:
+            raise NotImplementedError("semantic loss: <= 64 classes on the HIP device only")
         return {"loss_sem_seg": loss * self.loss_weight}

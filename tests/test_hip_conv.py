@@ -245,3 +245,30 @@ def test_group_norm_relu_and_bilinear2x_vs_torch_cpu(cuda):
         close(y, y0, "up2 fwd")
         y.backward(dy.to(cuda))
         close(xd.grad, xr.grad, "up2 bwd")
+
+
+def test_fused_upsample_cross_entropy_vs_torch_cpu(cuda):
+    """semantic_seg.py:179-188: CE(interpolate(logits, x4, bilinear), target, ignore 255), fused."""
+    import torch.nn.functional as F
+
+    from jtsm_amd.layers.elementwise import semseg_cross_entropy
+
+    g = torch.Generator().manual_seed(11)
+    for (n, c, hs, ws, scale) in [(2, 54, 16, 24, 4), (1, 7, 5, 3, 2), (1, 54, 8, 8, 4)]:
+        z = torch.randn(n, c, hs, ws, generator=g) * 3
+        t = torch.randint(0, c, (n, hs * scale, ws * scale), generator=g)
+        t[:, :2] = 255
+        t[0, 5:, 3] = 255
+        zr = z.clone().requires_grad_()
+        l0 = F.cross_entropy(F.interpolate(zr, scale_factor=scale, mode="bilinear", align_corners=False), t,
+                             reduction="mean", ignore_index=255)
+        (l0 * 0.7).backward()
+        # a [:, :c] slice of a wider channels-last map, like the padded predictor output
+        wide = torch.zeros(n, c + 2, hs, ws).contiguous(memory_format=CL)
+        wide[:, :c] = z
+        wd = wide.to(cuda).requires_grad_()
+        loss = semseg_cross_entropy(wd[:, :c], t.to(cuda), scale, 255)
+        close(loss, l0, "ce loss")
+        (loss * 0.7).backward()
+        close(wd.grad[:, :c], zr.grad, "ce dlogits")
+        assert wd.grad[:, c:].abs().max().item() == 0
