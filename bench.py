@@ -76,7 +76,7 @@ def roofline_leg(step_fn):
     torch.cuda.synchronize()
     log, conv.LAUNCH_LOG = conv.LAUNCH_LOG, None
     per = {}
-    for variant, flops, a, b in log:
+    for variant, flops, a, b, _shape in log:
         d = per.setdefault(variant, {"launches": 0, "flops": 0.0, "ms": 0.0})
         d["launches"] += 1
         d["flops"] += flops

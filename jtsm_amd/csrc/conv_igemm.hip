@@ -78,12 +78,13 @@ __device__ __forceinline__ float4 ldg4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
 }
 
-// ---- operand address generators --------------------------------------------------------------
-// Every operand is fetched in 16-byte chunks; `row` runs over the tile's non-K axis (m or n),
-// `k` is the absolute K index of the chunk's first element (K-contiguous operands), or the
-// chunk's k-row with `col` the first of 4 contiguous non-K elements (row-contiguous operands).
+// ---- operand addressing ------------------------------------------------------------------------
+// Every operand is fetched in 16-byte chunks.  Loads are UNCONDITIONAL (an out-of-range chunk reads the
+// buffer's first 16 bytes and is zeroed by a select afterwards): a conditional load makes hipcc branch
+// around it and wait vmcnt(0) per chunk, which serialises the prefetch.  Index decompositions
+// (k -> tap, channel;  pixel -> b, oh, ow) are advanced incrementally from K tile to K tile instead of
+// being re-divided.
 
-// FWD A: X gathered by output pixel and tap.  k = tap*Cin + ci.
 struct PixelRow { int b, h0, w0; bool ok; };
 
 __device__ __forceinline__ PixelRow fwd_pixel(const ConvShape& s, int m, int M) {
@@ -97,17 +98,6 @@ __device__ __forceinline__ PixelRow fwd_pixel(const ConvShape& s, int m, int M) 
   r.w0 = ow * s.stride - s.pad;
   return r;
 }
-__device__ __forceinline__ const float* fwd_a_ptr(const Params& p, const PixelRow& r, int k, int kend) {
-  const ConvShape& s = p.s;
-  if (!r.ok || k >= kend) return nullptr;
-  const int tap = k / s.Cin, ci = k - tap * s.Cin;
-  const int kh = tap / s.KW, kw = tap - kh * s.KW;
-  const int ih = r.h0 + kh * s.dil, iw = r.w0 + kw * s.dil;
-  if ((unsigned)ih >= (unsigned)s.H || (unsigned)iw >= (unsigned)s.W) return nullptr;
-  return p.A + ((size_t)(r.b * s.H + ih) * s.W + iw) * s.Cin + ci;
-}
-
-// DGRAD A: dY gathered by INPUT pixel and tap.  k = tap*Cout + co.
 __device__ __forceinline__ PixelRow dgrad_pixel(const ConvShape& s, int m, int M) {
   PixelRow r;
   r.ok = m < M;
@@ -119,202 +109,104 @@ __device__ __forceinline__ PixelRow dgrad_pixel(const ConvShape& s, int m, int M
   r.w0 = iw + s.pad;
   return r;
 }
-__device__ __forceinline__ const float* dgrad_a_ptr(const Params& p, const PixelRow& r, int k, int kend) {
-  const ConvShape& s = p.s;
-  if (!r.ok || k >= kend) return nullptr;
-  const int tap = k / s.Cout, co = k - tap * s.Cout;
-  const int kh = tap / s.KW, kw = tap - kh * s.KW;
-  const int th = r.h0 - kh * s.dil, tw = r.w0 - kw * s.dil;
-  if (th < 0 || tw < 0) return nullptr;
+
+// k = (kh*KW + kw)*C + c for a K-contiguous operand whose innermost run has C channels.
+struct TapState { int k, kh, kw, c; };
+__device__ __forceinline__ TapState tap_init(int k, int C, int KW) {
+  TapState t;
+  t.k = k;
+  const int tap = k / C;
+  t.c = k - tap * C;
+  t.kh = tap / KW;
+  t.kw = tap - t.kh * KW;
+  return t;
+}
+__device__ __forceinline__ void tap_advance(TapState& t, int step, int C, int KW) {
+  if (C < step) {  // tiny channel counts (RGB stem): many taps per step
+    t = tap_init(t.k + step, C, KW);
+    return;
+  }
+  t.k += step;
+  t.c += step;
+  while (t.c >= C) {
+    t.c -= C;
+    if (++t.kw == KW) { t.kw = 0; ++t.kh; }
+  }
+}
+
+// element offset of X[pix(row, tap)][c] for FWD, or -1
+__device__ __forceinline__ int fwd_a_off(const ConvShape& s, const PixelRow& r, const TapState& t, int kend) {
+  const int ih = r.h0 + t.kh * s.dil, iw = r.w0 + t.kw * s.dil;
+  const bool ok = r.ok && t.k < kend && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+  return ok ? ((r.b * s.H + ih) * s.W + iw) * s.Cin + t.c : -1;
+}
+// element offset of dY[opix(row, tap)][co] for DGRAD, or -1
+__device__ __forceinline__ int dgrad_a_off(const ConvShape& s, const PixelRow& r, const TapState& t, int kend) {
+  const int th = r.h0 - t.kh * s.dil, tw = r.w0 - t.kw * s.dil;
   int oh = th, ow = tw;
+  bool ok = r.ok && t.k < kend && th >= 0 && tw >= 0;
   if (s.stride != 1) {
     oh = th / s.stride;
     ow = tw / s.stride;
-    if (oh * s.stride != th || ow * s.stride != tw) return nullptr;
+    ok = ok && oh * s.stride == th && ow * s.stride == tw;
   }
-  if (oh >= s.Ho || ow >= s.Wo) return nullptr;
-  return p.A + ((size_t)(r.b * s.Ho + oh) * s.Wo + ow) * s.Cout + co;
+  ok = ok && oh < s.Ho && ow < s.Wo;
+  return ok ? ((r.b * s.Ho + oh) * s.Wo + ow) * s.Cout + t.c : -1;
 }
 
-// FWD B: W[n][k], K-contiguous.
-__device__ __forceinline__ const float* fwd_b_ptr(const Params& p, int n, int k, int kend) {
-  if (n >= p.N || k >= kend) return nullptr;
-  return p.B + (size_t)n * p.K + k;
+// row k = tap*Cout + co of W viewed as [K][Cin] (DGRAD B)
+struct CoState { int k, tap, co; };
+__device__ __forceinline__ CoState co_init(int k, int Cout) {
+  CoState c;
+  c.k = k;
+  c.tap = k / Cout;
+  c.co = k - c.tap * Cout;
+  return c;
+}
+__device__ __forceinline__ void co_advance(CoState& c, int step, int Cout) {
+  if (Cout < step) {
+    c = co_init(c.k + step, Cout);
+    return;
+  }
+  c.k += step;
+  c.co += step;
+  while (c.co >= Cout) { c.co -= Cout; ++c.tap; }
 }
 
-// DGRAD B: row k = (tap, co) of W viewed as [K][Cin]; col = ci (contiguous).
-__device__ __forceinline__ const float* dgrad_b_ptr(const Params& p, int k, int col, float* ks, int kend) {
-  const ConvShape& s = p.s;
-  if (k >= kend || col >= p.N) return nullptr;
-  const int tap = k / s.Cout, co = k - tap * s.Cout;
-  *ks = p.kscale ? p.kscale[co] : 1.f;
-  return p.B + ((size_t)co * (s.KH * s.KW) + tap) * s.Cin + col;
+// output pixel k -> (b, oh, ow) (WGRAD B)
+struct PixState { int k, b, oh, ow; };
+__device__ __forceinline__ PixState pix_init(int k, int Ho, int Wo) {
+  PixState p;
+  p.k = k;
+  p.ow = k % Wo;
+  const int t = k / Wo;
+  p.oh = t % Ho;
+  p.b = t / Ho;
+  return p;
+}
+__device__ __forceinline__ void pix_advance(PixState& p, int step, int Ho, int Wo) {
+  if (Wo < step) {  // narrow maps (nn.Linear: Ho = Wo = 1): many wraps per step, re-divide instead
+    p = pix_init(p.k + step, Ho, Wo);
+    return;
+  }
+  p.k += step;
+  p.ow += step;
+  while (p.ow >= Wo) {
+    p.ow -= Wo;
+    if (++p.oh == Ho) { p.oh = 0; ++p.b; }
+  }
 }
 
-// WGRAD A: dY[pixel k][co], co contiguous.
-__device__ __forceinline__ const float* wgrad_a_ptr(const Params& p, int k, int col, int kend) {
-  if (k >= kend || col >= p.M) return nullptr;
-  return p.A + (size_t)k * p.s.Cout + col;
-}
-// WGRAD B: X[pix(k, tap)][ci]; col = tap*Cin + ci.
-__device__ __forceinline__ const float* wgrad_b_ptr(const Params& p, int k, int col, int kend) {
-  const ConvShape& s = p.s;
-  if (k >= kend || col >= p.N) return nullptr;
-  const int tap = col / s.Cin, ci = col - tap * s.Cin;
-  const int kh = tap / s.KW, kw = tap - kh * s.KW;
-  const int ow = k % s.Wo, t = k / s.Wo;
-  const int oh = t % s.Ho, b = t / s.Ho;
-  const int ih = oh * s.stride - s.pad + kh * s.dil, iw = ow * s.stride - s.pad + kw * s.dil;
-  if ((unsigned)ih >= (unsigned)s.H || (unsigned)iw >= (unsigned)s.W) return nullptr;
-  return p.B + ((size_t)(b * s.H + ih) * s.W + iw) * s.Cin + ci;
+__device__ __forceinline__ float4 load_or_zero(const float* __restrict__ base, int off) {
+  const float4 v = ldg4(base + (off < 0 ? 0 : off));
+  return off < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : v;
 }
 
-// ---- the kernel ------------------------------------------------------------------------------
-// BM x BN output tile, WM x WN wavefronts (WM*WN == 4), each wavefront 64x64.
-template <int ROLE, int BM, int BN>
-__global__ __launch_bounds__(256, 4) void igemm_kernel(const Params p) {
-  constexpr int WN = BN / 64;
-  static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
-  constexpr bool A_T = ROLE != WGRAD;  // A staged transposed (K-contiguous source)?
-  constexpr bool B_T = ROLE == FWD;
-  constexpr int SA = BM + (A_T ? PAD_T : PAD_D);
-  constexpr int SB = BN + (B_T ? PAD_T : PAD_D);
-  constexpr int A_CH = BM * BK / 4 / 256;  // 16-byte chunks per thread per K tile
-  constexpr int B_CH = BN * BK / 4 / 256;
-
-  __shared__ __attribute__((aligned(16))) float lds[BK * SA + BK * SB];
-  float* As = lds;
-  float* Bs = lds + BK * SA;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-
-  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so hand each XCD a
-  // contiguous run of tiles; within a run tiles sweep N first, re-using the A rows.
-  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
-  const int ntiles = ntn * ntm;
-  int tile = blockIdx.x;
-  {
-    const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
-
-  int kbeg = 0, kend = p.K;
-  if (gridDim.y > 1) {
-    kbeg = blockIdx.y * p.ktiles_per_split * BK;
-    kend = min(p.K, kbeg + p.ktiles_per_split * BK);
-    if (kbeg >= kend && ROLE == WGRAD) return;  // FWD/DGRAD slices must still write their (zero) slab
-  }
-
-  // Per-thread chunk coordinates.
-  //   transposed tiles: chunk j -> row = tid/8 + 32*j, kq = tid%8 (k offset 4*kq)
-  //   direct tiles:     chunk j -> krow = tid/(BX/4) + (1024/BX)*j, col = 4*(tid%(BX/4))
-  PixelRow arow[A_T ? A_CH : 1];
-  if (A_T) {
-#pragma unroll
-    for (int j = 0; j < A_CH; ++j) {
-      const int m = m0 + tid / 8 + 32 * j;
-      arow[j] = ROLE == FWD ? fwd_pixel(p.s, m, p.M) : dgrad_pixel(p.s, m, p.M);
-    }
-  }
-
-  float4 ra[A_CH], rb[B_CH];
-  auto fetch = [&](int k0) {
-    if (A_T) {
-      const int k = k0 + 4 * (tid & 7);
-#pragma unroll
-      for (int j = 0; j < A_CH; ++j) {
-        const float* q = ROLE == FWD ? fwd_a_ptr(p, arow[j], k, kend) : dgrad_a_ptr(p, arow[j], k, kend);
-        ra[j] = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-      constexpr int CPR = BM / 4;  // chunks per k-row
-      const int col = m0 + 4 * (tid % CPR);
-#pragma unroll
-      for (int j = 0; j < A_CH; ++j) {
-        const int k = k0 + tid / CPR + (256 / CPR) * j;
-        const float* q = wgrad_a_ptr(p, k, col, kend);
-        ra[j] = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
-    if (B_T) {
-      const int k = k0 + 4 * (tid & 7);
-#pragma unroll
-      for (int j = 0; j < B_CH; ++j) {
-        const float* q = fwd_b_ptr(p, n0 + tid / 8 + 32 * j, k, kend);
-        rb[j] = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    } else {
-      constexpr int CPR = BN / 4;
-      const int col = n0 + 4 * (tid % CPR);
-#pragma unroll
-      for (int j = 0; j < B_CH; ++j) {
-        const int k = k0 + tid / CPR + (256 / CPR) * j;
-        float ks = 1.f;
-        const float* q = ROLE == DGRAD ? dgrad_b_ptr(p, k, col, &ks, kend) : wgrad_b_ptr(p, k, col, kend);
-        float4 v = q ? ldg4(q) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ROLE == DGRAD) { v.x *= ks; v.y *= ks; v.z *= ks; v.w *= ks; }
-        rb[j] = v;
-      }
-    }
-  };
-  auto stage = [&]() {
-    if (A_T) {
-      const int kq = 4 * (tid & 7);
-#pragma unroll
-      for (int j = 0; j < A_CH; ++j) {
-        float* d = As + kq * SA + tid / 8 + 32 * j;
-        d[0] = ra[j].x; d[SA] = ra[j].y; d[2 * SA] = ra[j].z; d[3 * SA] = ra[j].w;
-      }
-    } else {
-      constexpr int CPR = BM / 4;
-#pragma unroll
-      for (int j = 0; j < A_CH; ++j)
-        *reinterpret_cast<float4*>(As + (tid / CPR + (256 / CPR) * j) * SA + 4 * (tid % CPR)) = ra[j];
-    }
-    if (B_T) {
-      const int kq = 4 * (tid & 7);
-#pragma unroll
-      for (int j = 0; j < B_CH; ++j) {
-        float* d = Bs + kq * SB + tid / 8 + 32 * j;
-        d[0] = rb[j].x; d[SB] = rb[j].y; d[2 * SB] = rb[j].z; d[3 * SB] = rb[j].w;
-      }
-    } else {
-      constexpr int CPR = BN / 4;
-#pragma unroll
-      for (int j = 0; j < B_CH; ++j)
-        *reinterpret_cast<float4*>(Bs + (tid / CPR + (256 / CPR) * j) * SB + 4 * (tid % CPR)) = rb[j];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  fetch(kbeg);
-  const float* aw = As + (lane >> 5) * SA + wm * 64 + (lane & 31);
-  const float* bw = Bs + (lane >> 5) * SB + wn * 64 + (lane & 31);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    __syncthreads();  // everyone done reading the previous tile
-    stage();
-    __syncthreads();
-    if (k0 + BK < kend) fetch(k0 + BK);  // in flight during the MFMAs below
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a0 = aw[kk * SA], a1 = aw[kk * SA + 32];
-      const float b0 = bw[kk * SB], b1 = bw[kk * SB + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-    }
-  }
-
+// Write one wavefront's 64x64 accumulator tile with the fused epilogue (or as a raw split-K slab / an
+// atomic WGRAD contribution).
+template <int ROLE>
+__device__ __forceinline__ void store_tile(const Params& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                           int lane) {
   // Epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const Epilogue& e = p.e;
 #pragma unroll
@@ -353,6 +245,452 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const Params p) {
       }
     }
   }
+}
+
+// ---- the kernel ------------------------------------------------------------------------------
+// BM x BN output tile, four wavefronts, each 64x64 (2x2 MFMA tiles of 32x32).
+template <int ROLE, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const Params p) {
+  constexpr int WN = BN / 64;
+  static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
+  constexpr bool A_T = ROLE != WGRAD;  // A staged transposed (K-contiguous source)?
+  constexpr bool B_T = ROLE == FWD;
+  constexpr int SA = BM + (A_T ? PAD_T : PAD_D);
+  constexpr int SB = BN + (B_T ? PAD_T : PAD_D);
+  constexpr int A_CH = BM * BK / 4 / 256;  // 16-byte chunks per thread per K tile
+  constexpr int B_CH = BN * BK / 4 / 256;
+  constexpr int ACPR = BM / 4, BCPR = BN / 4;          // chunks per k-row (row-contiguous operands)
+  constexpr int ARS = 256 / ACPR, BRS = 256 / BCPR;    // k-rows covered per pass
+
+  __shared__ __attribute__((aligned(16))) float lds[BK * SA + BK * SB];
+  float* As = lds;
+  float* Bs = lds + BK * SA;
+
+  const ConvShape& s = p.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so hand each XCD a
+  // contiguous run of tiles; within a run tiles sweep N first, re-using the A rows.
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntiles = ntn * ntm;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  int kbeg = 0, kend = p.K;
+  if (gridDim.y > 1) {
+    kbeg = blockIdx.y * p.ktiles_per_split * BK;
+    kend = min(p.K, kbeg + p.ktiles_per_split * BK);
+    if (kbeg >= kend && ROLE == WGRAD) return;  // FWD/DGRAD slices must still write their (zero) slab
+  }
+
+  // ---- per-thread addressing state
+  PixelRow arow[A_T ? A_CH : 1];
+  TapState atap = {};                      // FWD/DGRAD A: this thread's chunk along K
+  CoState bco[ROLE == DGRAD ? B_CH : 1];   // DGRAD B: one k-row per chunk
+  int wg_k = kbeg;                           // WGRAD: first pixel row of the current K tile
+  int wg_tap_off = 0, wg_kh = 0, wg_kw = 0; bool wg_col_ok = false;  // WGRAD B column (tap, ci)
+  if (A_T) {
+#pragma unroll
+    for (int j = 0; j < A_CH; ++j) {
+      const int m = m0 + tid / 8 + 32 * j;
+      arow[j] = ROLE == FWD ? fwd_pixel(s, m, p.M) : dgrad_pixel(s, m, p.M);
+    }
+    atap = tap_init(kbeg + 4 * (tid & 7), ROLE == FWD ? s.Cin : s.Cout, s.KW);
+  }
+  if (ROLE == DGRAD) {
+#pragma unroll
+    for (int j = 0; j < B_CH; ++j) bco[j] = co_init(kbeg + tid / BCPR + BRS * j, s.Cout);
+  }
+  if (ROLE == WGRAD) {
+    const int col = n0 + 4 * (tid % BCPR);
+    wg_col_ok = col < p.N;
+    const int cc = wg_col_ok ? col : 0;
+    const int tap = cc / s.Cin;
+    wg_tap_off = cc - tap * s.Cin;
+    wg_kh = tap / s.KW;
+    wg_kw = tap - wg_kh * s.KW;
+  }
+  const int bk_fwd = kbeg + 4 * (tid & 7);   // FWD B chunk k (advances by BK)
+  int fwd_k = bk_fwd;
+
+  float4 ra[A_CH], rb[B_CH];
+  auto fetch = [&]() {
+    if (ROLE == FWD) {
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) ra[j] = load_or_zero(p.A, fwd_a_off(s, arow[j], atap, kend));
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j) {
+        const int n = n0 + tid / 8 + 32 * j;
+        rb[j] = load_or_zero(p.B, (n < p.N && fwd_k < kend) ? n * p.K + fwd_k : -1);
+      }
+      tap_advance(atap, BK, s.Cin, s.KW);
+      fwd_k += BK;
+    } else if (ROLE == DGRAD) {
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) ra[j] = load_or_zero(p.A, dgrad_a_off(s, arow[j], atap, kend));
+      const int col = n0 + 4 * (tid % BCPR);
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j) {
+        const bool ok = bco[j].k < kend && col < p.N;
+        float4 v = load_or_zero(p.B, ok ? (bco[j].co * (s.KH * s.KW) + bco[j].tap) * s.Cin + col : -1);
+        if (p.kscale) {
+          const float ks = p.kscale[ok ? bco[j].co : 0];
+          v.x *= ks; v.y *= ks; v.z *= ks; v.w *= ks;
+        }
+        rb[j] = v;
+        co_advance(bco[j], BK, s.Cout);
+      }
+      tap_advance(atap, BK, s.Cout, s.KW);
+    } else {
+      // (conditional loads here: for this role hipcc's branchy form measured ~15 % faster than the
+      //  select form on the short K sweeps that take this kernel — fewer live registers per chunk)
+      const int acol = m0 + 4 * (tid % ACPR);
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        const int k = wg_k + tid / ACPR + ARS * j;
+        ra[j] = (k < kend && acol < p.M) ? ldg4(p.A + (size_t)k * s.Cout + acol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j) {
+        const int k = wg_k + tid / BCPR + BRS * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wg_col_ok && k < kend) {
+          const int ow = k % s.Wo, t = k / s.Wo;
+          const int oh = t % s.Ho, b = t / s.Ho;
+          const int ih = oh * s.stride - s.pad + wg_kh * s.dil, iw = ow * s.stride - s.pad + wg_kw * s.dil;
+          if ((unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W)
+            v = ldg4(p.B + ((size_t)(b * s.H + ih) * s.W + iw) * s.Cin + wg_tap_off);
+        }
+        rb[j] = v;
+      }
+      wg_k += BK;
+    }
+  };
+  auto stage = [&]() {
+    if (A_T) {
+      const int kq = 4 * (tid & 7);
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j) {
+        float* d = As + kq * SA + tid / 8 + 32 * j;
+        d[0] = ra[j].x; d[SA] = ra[j].y; d[2 * SA] = ra[j].z; d[3 * SA] = ra[j].w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_CH; ++j)
+        *reinterpret_cast<float4*>(As + (tid / ACPR + ARS * j) * SA + 4 * (tid % ACPR)) = ra[j];
+    }
+    if (B_T) {
+      const int kq = 4 * (tid & 7);
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j) {
+        float* d = Bs + kq * SB + tid / 8 + 32 * j;
+        d[0] = rb[j].x; d[SB] = rb[j].y; d[2 * SB] = rb[j].z; d[3 * SB] = rb[j].w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_CH; ++j)
+        *reinterpret_cast<float4*>(Bs + (tid / BCPR + BRS * j) * SB + 4 * (tid % BCPR)) = rb[j];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  fetch();
+  const float* aw = As + (lane >> 5) * SA + wm * 64 + (lane & 31);
+  const float* bw = Bs + (lane >> 5) * SB + wn * 64 + (lane & 31);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // everyone done reading the previous tile
+    stage();
+    __syncthreads();
+    if (ROLE != WGRAD || k0 + BK < kend) fetch();  // next tile: in flight during the MFMAs below
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a0 = aw[kk * SA], a1 = aw[kk * SA + 32];
+      const float b0 = bw[kk * SB], b1 = bw[kk * SB + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+  }
+
+  store_tile<ROLE>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ================================================================================================
+// igemm_dma_kernel — the same contraction with direct-to-LDS loads.
+//
+// `global_load_lds_dwordx4` writes 64 lanes x 16 B = 1 KiB of LDS per instruction, lane-linearly, with
+// a free per-lane GLOBAL address; nothing passes through VGPRs, so the 32 staging registers and all
+// ds_write instructions of the register-staged kernel disappear, tiles are double-buffered (the DMA
+// of K tile t+1 flies during the MFMAs of tile t, one barrier per tile), and out-of-range chunks are
+// pointed at a 16-byte zero page instead of being branched around.
+//   K-contiguous operands (FWD/DGRAD activations, FWD weights) keep their [row][32 k] shape in LDS,
+//     16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) — the swizzle is applied to the SOURCE address
+//     (lane l of a DMA writes slot l&7 of row l>>3, so it fetches chunk (l&7) ^ swz) and again on the
+//     read, which is a conflict-free ds_read_b128 of 4 consecutive k.  An MFMA 32x32x2 step takes its
+//     two k from the two half-waves, so half h consumes k = 8q+4h+s in step (q,s): a permutation of
+//     the tile's k order applied identically to A and B.
+//   Row-contiguous operands (DGRAD weights, WGRAD both) are already k-major in memory: rows of 512 B
+//     land unpadded, fragments are conflict-free ds_read_b32 (consecutive lanes, consecutive columns).
+// Requires every K tile to lie inside one filter tap: kernel 1x1, or channels % 32 == 0 (everything on
+// the JTSM path but the RGB stem, which keeps the register-staged kernel).
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16(const float* g, float* lds_uniform_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)lds_uniform_base, 16, 0, 0);
+}
+
+template <int ROLE, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const Params p) {
+  constexpr int WN = BN / 64;
+  static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
+  constexpr bool A_R = ROLE != WGRAD;  // A keeps [row][k] (K-contiguous source)
+  constexpr bool B_R = ROLE == FWD;
+  constexpr int A_FL = BM * BK, B_FL = BN * BK;
+  constexpr int A_INS = BM / 32, B_INS = BN / 32;  // DMA instructions per wavefront per K tile
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FL + B_FL)];
+
+  const ConvShape& s = p.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, li = lane & 31;
+
+  const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+  const int ntiles = ntn * ntm;
+  int tile = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+
+  int kbeg = 0, kend = p.K;
+  if (gridDim.y > 1) {
+    kbeg = blockIdx.y * p.ktiles_per_split * BK;
+    kend = min(p.K, kbeg + p.ktiles_per_split * BK);
+    if (kbeg >= kend && ROLE == WGRAD) return;
+  }
+  const int ntile_k = kbeg < kend ? (kend - kbeg + BK - 1) / BK : 0;
+
+  // ---- addressing state -----------------------------------------------------------------------
+  // K-contiguous operands: per DMA instruction j this lane owns row (wave*INS + j)*8 + lane/8 and the
+  // chunk (lane&7) ^ swz(row) of the K tile.  The tap (kh, kw) and first channel of a K tile are
+  // wave-uniform and advance incrementally.
+  const int Cdim = ROLE == FWD ? s.Cin : s.Cout;   // channels of the K-contiguous activation
+  int t_kh, t_kw, t_c;                             // uniform tap state of the current K tile
+  {
+    const int tap = kbeg / Cdim;
+    t_c = kbeg - tap * Cdim;
+    t_kh = tap / s.KW;
+    t_kw = tap - t_kh * s.KW;
+  }
+  PixelRow arow[A_R ? A_INS : 1];
+  int a_chunk[A_R ? A_INS : 1];
+  if (A_R) {
+#pragma unroll
+    for (int j = 0; j < A_INS; ++j) {
+      const int r = (wave * A_INS + j) * 8 + (lane >> 3);
+      arow[j] = ROLE == FWD ? fwd_pixel(s, m0 + r, p.M) : dgrad_pixel(s, m0 + r, p.M);
+      a_chunk[j] = 4 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+  }
+  int b_off[B_R ? B_INS : 1], b_chunk[B_R ? B_INS : 1];   // FWD weights: n*K, chunk
+  if (B_R) {
+#pragma unroll
+    for (int j = 0; j < B_INS; ++j) {
+      const int r = (wave * B_INS + j) * 8 + (lane >> 3);
+      b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
+      b_chunk[j] = 4 * ((lane & 7) ^ ((r >> 1) & 7));
+    }
+  }
+  // row-contiguous operands: per DMA instruction j this lane owns k-row (wave*INS + j)*RPI + lane/CPR and
+  // columns 4*(lane % CPR) ..+3.
+  constexpr int ACPR = BM / 4, BCPR = BN / 4, ARPI = 64 / (ACPR < 64 ? ACPR : 64), BRPI = 64 / (BCPR < 64 ? BCPR : 64);
+  static_assert(ACPR <= 64 && BCPR <= 64, "tile rows wider than one DMA instruction are not laid out here");
+  PixState bpix[ROLE == WGRAD ? B_INS : 1];
+  int wg_ci = 0, wg_kh = 0, wg_kw = 0;
+  bool wg_col_ok = false;
+  if (ROLE == WGRAD) {
+#pragma unroll
+    for (int j = 0; j < B_INS; ++j)
+      bpix[j] = pix_init(kbeg + (wave * B_INS + j) * BRPI + lane / BCPR, s.Ho, s.Wo);
+    const int col = n0 + 4 * (lane % BCPR);
+    wg_col_ok = col < p.N;
+    const int cc = wg_col_ok ? col : 0;
+    const int tap = cc / s.Cin;
+    wg_ci = cc - tap * s.Cin;
+    wg_kh = tap / s.KW;
+    wg_kw = tap - wg_kh * s.KW;
+  }
+
+  auto issue = [&](int k0, int buf) {
+    float* Ab = lds + buf * (A_FL + B_FL);
+    float* Bb = Ab + A_FL;
+    if (A_R) {
+#pragma unroll
+      for (int j = 0; j < A_INS; ++j) {
+        const PixelRow& r = arow[j];
+        bool ok = r.ok && (k0 + a_chunk[j]) < kend;
+        int off;
+        if (ROLE == FWD) {
+          const int ih = r.h0 + t_kh * s.dil, iw = r.w0 + t_kw * s.dil;
+          ok = ok && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+          off = ((r.b * s.H + ih) * s.W + iw) * s.Cin + t_c + a_chunk[j];
+        } else {
+          const int th = r.h0 - t_kh * s.dil, tw = r.w0 - t_kw * s.dil;
+          int oh = th, ow = tw;
+          ok = ok && th >= 0 && tw >= 0;
+          if (s.stride != 1) {
+            oh = th / s.stride;
+            ow = tw / s.stride;
+            ok = ok && oh * s.stride == th && ow * s.stride == tw;
+          }
+          ok = ok && oh < s.Ho && ow < s.Wo;
+          off = ((r.b * s.Ho + oh) * s.Wo + ow) * s.Cout + t_c + a_chunk[j];
+        }
+        dma16(ok ? p.A + off : g_zero_page, Ab + (wave * A_INS + j) * 256);
+      }
+    } else {  // WGRAD A: dY[pixel k][cout]
+      const int col = m0 + 4 * (lane % ACPR);
+#pragma unroll
+      for (int j = 0; j < A_INS; ++j) {
+        const int k = k0 + (wave * A_INS + j) * ARPI + lane / ACPR;
+        const bool ok = k < kend && col < p.M;
+        dma16(ok ? p.A + k * s.Cout + col : g_zero_page, Ab + (wave * A_INS + j) * 256);
+      }
+    }
+    if (B_R) {
+#pragma unroll
+      for (int j = 0; j < B_INS; ++j) {
+        const bool ok = b_off[j] >= 0 && (k0 + b_chunk[j]) < kend;
+        dma16(ok ? p.B + b_off[j] + k0 + b_chunk[j] : g_zero_page, Bb + (wave * B_INS + j) * 256);
+      }
+    } else if (ROLE == DGRAD) {  // rows k = (tap, co) of W as [K][Cin]
+      const int col = n0 + 4 * (lane % BCPR);
+#pragma unroll
+      for (int j = 0; j < B_INS; ++j) {
+        const int kr = (wave * B_INS + j) * BRPI + lane / BCPR;
+        const bool ok = (k0 + kr) < kend && col < p.N;
+        const int tap = t_kh * s.KW + t_kw;
+        dma16(ok ? p.B + ((t_c + kr) * (s.KH * s.KW) + tap) * s.Cin + col : g_zero_page,
+              Bb + (wave * B_INS + j) * 256);
+      }
+    } else {  // WGRAD B: X[pix(k, tap)][ci]
+#pragma unroll
+      for (int j = 0; j < B_INS; ++j) {
+        const PixState& q = bpix[j];
+        const int ih = q.oh * s.stride - s.pad + wg_kh * s.dil, iw = q.ow * s.stride - s.pad + wg_kw * s.dil;
+        const bool ok = wg_col_ok && q.k < kend && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+        dma16(ok ? p.B + ((q.b * s.H + ih) * s.W + iw) * s.Cin + wg_ci : g_zero_page,
+              Bb + (wave * B_INS + j) * 256);
+        pix_advance(bpix[j], BK, s.Ho, s.Wo);
+      }
+    }
+    if (ROLE != WGRAD) {  // next K tile: same tap or the next one (tiles never straddle taps)
+      t_c += BK;
+      if (t_c >= Cdim) {
+        t_c -= Cdim;
+        if (++t_kw == s.KW) { t_kw = 0; ++t_kh; }
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment read bases
+  int a_row_off[2], a_swz[2], b_row_off[2], b_swz[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ar = wm * 64 + t * 32 + li, br = wn * 64 + t * 32 + li;
+    a_row_off[t] = A_R ? ar * BK : ar;
+    a_swz[t] = (ar >> 1) & 7;
+    b_row_off[t] = B_R ? br * BK : br;
+    b_swz[t] = (br >> 1) & 7;
+  }
+
+  if (ntile_k > 0) issue(kbeg, 0);
+  for (int t = 0; t < ntile_k; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of tile t have landed
+    __syncthreads();                                  // ... everyone's; and buffer (t+1)&1 is free
+    if (t + 1 < ntile_k) issue(kbeg + (t + 1) * BK, (t + 1) & 1);
+    const float* Ab = lds + (t & 1) * (A_FL + B_FL);
+    const float* Bb = Ab + A_FL;
+    if (ROLE == WGRAD) {
+#pragma unroll
+      for (int kk = 0; kk < BK; kk += 2) {
+        const float a0 = Ab[(kk + half) * BM + a_row_off[0]], a1 = Ab[(kk + half) * BM + a_row_off[1]];
+        const float b0 = Bb[(kk + half) * BN + b_row_off[0]], b1 = Bb[(kk + half) * BN + b_row_off[1]];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 2 * q + half;
+        const float4 a0 = *reinterpret_cast<const float4*>(Ab + a_row_off[0] + ((c ^ a_swz[0]) << 2));
+        const float4 a1 = *reinterpret_cast<const float4*>(Ab + a_row_off[1] + ((c ^ a_swz[1]) << 2));
+        float b0[4], b1[4];
+        if (B_R) {
+          const float4 x0 = *reinterpret_cast<const float4*>(Bb + b_row_off[0] + ((c ^ b_swz[0]) << 2));
+          const float4 x1 = *reinterpret_cast<const float4*>(Bb + b_row_off[1] + ((c ^ b_swz[1]) << 2));
+          b0[0] = x0.x; b0[1] = x0.y; b0[2] = x0.z; b0[3] = x0.w;
+          b1[0] = x1.x; b1[1] = x1.y; b1[2] = x1.z; b1[3] = x1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            b0[e] = Bb[(4 * c + e) * BN + b_row_off[0]];
+            b1[e] = Bb[(4 * c + e) * BN + b_row_off[1]];
+          }
+        }
+        const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], b0[e], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[e], b1[e], acc[0][1], 0, 0, 0);
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], b0[e], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[e], b1[e], acc[1][1], 0, 0, 0);
+        }
+      }
+    }
+  }
+  store_tile<ROLE>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// Which kernel?  The direct-to-LDS kernel (64-80 KiB LDS, 2 workgroups per CU, deep prefetch) wins when a
+// workgroup sweeps many K tiles; short sweeps (split-K slices, 1x1 convolutions with few channels) are
+// dominated by prologue/epilogue latency and do better with the register-staged kernel's 3 workgroups
+// per CU.  Measured on MI355X (scratch/bench_conv.py): crossover around 24 K tiles per workgroup.
+constexpr int kDmaMinKTiles = 24;
+
+// Every K tile inside one filter tap?  (kernel 1x1, or channel count a multiple of the K tile.)
+inline bool dma_eligible(int role, const Params& p) {
+  const ConvShape& s = p.s;
+  const int taps = s.KH * s.KW;
+  if (role == WGRAD) return true;
+  if (role == DGRAD && p.kscale) return false;  // the DMA path cannot scale weight rows on the fly
+  const int c = role == FWD ? s.Cin : s.Cout;
+  return taps == 1 || c % BK == 0;
 }
 
 // Fold the split-K slabs in slice order (deterministic) and apply the fused epilogue.
@@ -395,15 +733,18 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
   const int ktiles = ceil_div(p.K, BK);
   int splits = plan_splits(ntiles, ktiles);
   if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
+  const bool dma = dma_eligible(ROLE, p) && ceil_div(ktiles, splits) >= kDmaMinKTiles;
   if (splits <= 1) {
-    hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
+    if (dma) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
     JTSM_CHECK_LAUNCH("igemm");
     return JTSM_OK;
   }
   p.ktiles_per_split = ceil_div(ktiles, splits);
   splits = ceil_div(ktiles, p.ktiles_per_split);
   p.slab = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  if (dma) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm split-K");
   const long total = (long)p.M * p.N;
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
@@ -415,7 +756,10 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
 template <int ROLE, int BM, int BN>
 int launch(const Params& p, int splits, hipStream_t st) {
   const int ntiles = ceil_div(p.N, BN) * ceil_div(p.M, BM);
-  hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  if (dma_eligible(ROLE, p) && p.ktiles_per_split >= kDmaMinKTiles)
+    hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm");
   return JTSM_OK;
 }

@@ -21,15 +21,19 @@ CL = torch.channels_last
 LAUNCH_LOG = None
 
 
-def _timed(variant, flops, call):
+def _timed(variant, flops, call, shape=None):
     if LAUNCH_LOG is None:
         return call()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     rc = call()
     b.record()
-    LAUNCH_LOG.append((variant, flops, a, b))
+    LAUNCH_LOG.append((variant, flops, a, b, shape))
     return rc
+
+
+def _desc(s):
+    return (s.batch, s.in_h, s.in_w, s.in_c, s.out_c, s.kernel_h, s.stride)
 
 
 def _workspace(s, backward_data, device):
@@ -89,7 +93,7 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
     ws, nbytes = _workspace(s, 0, x.device)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_forward_f32(
         L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream())), "conv2d_forward")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_forward")
     return y
 
 
@@ -107,7 +111,7 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     ws, nbytes = _workspace(s, 1, dy.device)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s), L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream())), "conv2d_backward_data")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_data")
     return dx
 
 
@@ -119,7 +123,7 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     if out is None:
         out = torch.zeros(tuple(w_shape), dtype=x.dtype, device=x.device).contiguous(memory_format=CL)
     L.check(_timed("igemm_kernel<WGRAD,128,128>", _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
-        L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream())),
+        L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream()), _desc(s)),
             "conv2d_backward_weight")
     return out
 
@@ -146,7 +150,10 @@ class _ConvFused(Function):
         g = relu_backward(dy, y) if relu else _cl(dy)
         dx = dw = db = dres = None
         if ctx.needs_input_grad[0]:
-            dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale)
+            # fold the FrozenBN scale into the weight rows once (a few MB) so the data-gradient GEMM takes
+            # the direct-to-LDS path, which cannot rescale operands on the fly
+            w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
+            dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
         if ctx.needs_input_grad[1]:
             dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale)
         if bias_needs_grad and ctx.needs_input_grad[3]:
