@@ -85,11 +85,18 @@ def roofline_leg(step_fn):
         d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
         d["avg_us"] = 1e3 * d["ms"] / d["launches"]
     dom = max(per, key=lambda k: per[k]["ms"])
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.isfile(pmc):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command
+        t = json.load(open(pmc)).get("kernels", {}).get(dom)
+        if t:
+            traffic = {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "source": "profiles/pmc_traffic.json",
+                       "note": t.get("note", "")}
     total_ms = sum(d["ms"] for d in per.values())
     total_fl = sum(d["flops"] for d in per.values())
     return {
         "bound": "mfma", "kernel": dom, "achieved": round(per[dom]["tflops"], 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-        "unit": "TFLOP/s", "frac": round(per[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "unit": "TFLOP/s", "frac": round(per[dom]["tflops"] / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
         "launches_per_step": per[dom]["launches"], "avg_launch_us": round(per[dom]["avg_us"], 2),
         "algorithmic_gflop_per_launch": round(per[dom]["flops"] / per[dom]["launches"] / 1e9, 3),
         "all_contractions": {"tflops": round(total_fl / (total_ms * 1e-3) / 1e12, 2), "ms_per_step": round(total_ms, 3),

@@ -815,6 +815,45 @@ size_t jtsm_conv_workspace_bytes(const jtsm_conv_shape* s, int backward_data) {
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
+// What a call of this shape will launch: *kernel = 0 register-staged igemm_kernel, 1 = igemm_dma_kernel;
+// tile and K-split as chosen by the launchers (assuming the caller passes the advertised workspace).
+// role: 0 forward, 1 backward-data, 2 backward-weight.
+int jtsm_conv_plan(const jtsm_conv_shape* s, int role, int has_kscale, int* kernel, int* tile_m, int* tile_n,
+                   int* splits) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  Params p = {};
+  p.s = to_shape(s);
+  JTSM_REQUIRE(p.s.Ho > 0 && p.s.Wo > 0, "conv: kernel larger than padded input");
+  JTSM_REQUIRE(role >= 0 && role <= 2, "conv_plan: role must be 0, 1 or 2");
+  if (role == FWD) { p.M = p.s.Bn * p.s.Ho * p.s.Wo; p.N = p.s.Cout; p.K = p.s.KH * p.s.KW * p.s.Cin; }
+  else if (role == DGRAD) {
+    p.M = p.s.Bn * p.s.H * p.s.W; p.N = p.s.Cin; p.K = p.s.KH * p.s.KW * p.s.Cout;
+    if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1) p.M = p.s.Bn * p.s.Ho * p.s.Wo;
+    if (has_kscale) p.kscale = reinterpret_cast<const float*>(1);
+  } else { p.M = p.s.Cout; p.N = p.s.KH * p.s.KW * p.s.Cin; p.K = p.s.Bn * p.s.Ho * p.s.Wo; }
+  int bm = 128, bn = 128, sp = 1, kps;
+  const int ktiles = ceil_div(p.K, BK);
+  if (role == WGRAD) {
+    const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
+    sp = ceil_div(1024, ntiles);
+    if (sp > ceil_div(ktiles, 8)) sp = ceil_div(ktiles, 8);
+    if (sp < 1) sp = 1;
+    kps = ceil_div(ktiles, sp);
+    sp = ceil_div(ktiles, kps);
+  } else {
+    if (p.N <= 64) { bm = 256; bn = 64; }
+    sp = plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ktiles);
+    kps = ceil_div(ktiles, sp);
+    sp = ceil_div(ktiles, kps);
+  }
+  if (kernel) *kernel = (dma_eligible(role, p) && kps >= kDmaMinKTiles) ? 1 : 0;
+  if (tile_m) *tile_m = bm;
+  if (tile_n) *tile_n = bn;
+  if (splits) *splits = sp;
+  return JTSM_OK;
+}
+
 int jtsm_conv2d_forward_f32(const float* x, const float* w, float* y, const jtsm_conv_shape* s,
                             const float* scale, const float* bias, const float* residual, int relu,
                             void* workspace, size_t workspace_bytes, void* stream) {

@@ -32,6 +32,19 @@ def _timed(variant, flops, call, shape=None):
     return rc
 
 
+_ROLE_NAME = ("FWD", "DGRAD", "WGRAD")
+
+
+def _variant(s, role, has_kscale=False):
+    """Exact kernel instantiation the library will launch for this call (mirrors its dispatch)."""
+    if LAUNCH_LOG is None:
+        return None
+    k, bm, bn, sp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    L.check(L.lib().jtsm_conv_plan(C.byref(s), role, int(has_kscale), C.byref(k), C.byref(bm), C.byref(bn),
+                                   C.byref(sp)), "conv_plan")
+    return "%s<%s,%d,%d>" % ("igemm_dma_kernel" if k.value else "igemm_kernel", _ROLE_NAME[role], bm.value, bn.value)
+
+
 def _desc(s):
     return (s.batch, s.in_h, s.in_w, s.in_c, s.out_c, s.kernel_h, s.stride)
 
@@ -89,7 +102,7 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
     if residual is not None:
         residual = _cl(residual)
         assert residual.shape == y.shape
-    variant = "igemm_kernel<FWD,256,64>" if s.out_c <= 64 else "igemm_kernel<FWD,128,128>"
+    variant = _variant(s, 0)
     ws, nbytes = _workspace(s, 0, x.device)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_forward_f32(
         L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
@@ -107,7 +120,7 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         accumulate = _cl(accumulate)
     if relu_mask is not None:
         relu_mask = _cl(relu_mask)
-    variant = "igemm_kernel<DGRAD,256,64>" if s.in_c <= 64 else "igemm_kernel<DGRAD,128,128>"
+    variant = _variant(s, 1, kscale is not None)
     ws, nbytes = _workspace(s, 1, dy.device)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s), L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
@@ -122,7 +135,7 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
         out = torch.zeros(tuple(w_shape), dtype=x.dtype, device=x.device).contiguous(memory_format=CL)
-    L.check(_timed("igemm_kernel<WGRAD,128,128>", _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
+    L.check(_timed(_variant(s, 2), _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
         L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream()), _desc(s)),
             "conv2d_backward_weight")
     return out
