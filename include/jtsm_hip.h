@@ -167,7 +167,8 @@ int jtsm_conv_out_size(const jtsm_conv_shape* s, int* out_h, int* out_w);
  * 0 = not split.  Passing a NULL / smaller workspace is allowed: the call then runs unsplit. */
 size_t jtsm_conv_workspace_bytes(const jtsm_conv_shape* s, int backward_data);
 /* Introspection for benchmarks/profiles: which kernel a call of this shape launches (kernel 0 =
- * register-staged igemm_kernel, 1 = direct-to-LDS igemm_dma_kernel), its tile and K-split.
+ * register-staged igemm_kernel, 1 = double-buffered direct-to-LDS igemm_dma_kernel<..,2>, 2 = its
+ * single-buffered form igemm_dma_kernel<..,1> used for short K sweeps), its tile and K-split.
  * role: 0 forward, 1 backward-data, 2 backward-weight. */
 int jtsm_conv_plan(const jtsm_conv_shape* s, int role, int has_kscale, int* kernel, int* tile_m,
                    int* tile_n, int* splits);

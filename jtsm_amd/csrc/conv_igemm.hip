@@ -453,15 +453,15 @@ __device__ __forceinline__ void dma16(const float* g, float* lds_uniform_base) {
                                    (__attribute__((address_space(3))) void*)lds_uniform_base, 16, 0, 0);
 }
 
-template <int ROLE, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const Params p) {
+template <int ROLE, int BM, int BN, int NBUF>
+__global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void igemm_dma_kernel(const Params p) {
   constexpr int WN = BN / 64;
   static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
   constexpr bool A_R = ROLE != WGRAD;  // A keeps [row][k] (K-contiguous source)
   constexpr bool B_R = ROLE == FWD;
   constexpr int A_FL = BM * BK, B_FL = BN * BK;
   constexpr int A_INS = BM / 32, B_INS = BN / 32;  // DMA instructions per wavefront per K tile
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_FL + B_FL)];
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * (A_FL + B_FL)];
 
   const ConvShape& s = p.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -627,12 +627,16 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const Params p) {
     b_swz[t] = (br >> 1) & 7;
   }
 
-  if (ntile_k > 0) issue(kbeg, 0);
+  if (NBUF == 2 && ntile_k > 0) issue(kbeg, 0);
   for (int t = 0; t < ntile_k; ++t) {
+    if (NBUF == 1) {  // single buffer (32-40 KiB -> 4 workgroups per CU cover each other's DMA waits)
+      __syncthreads();                                // everyone done reading the previous tile
+      issue(kbeg + t * BK, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMAs of tile t have landed
     __syncthreads();                                  // ... everyone's; and buffer (t+1)&1 is free
-    if (t + 1 < ntile_k) issue(kbeg + (t + 1) * BK, (t + 1) & 1);
-    const float* Ab = lds + (t & 1) * (A_FL + B_FL);
+    if (NBUF == 2 && t + 1 < ntile_k) issue(kbeg + (t + 1) * BK, (t + 1) & 1);
+    const float* Ab = lds + (NBUF == 2 ? (t & 1) : 0) * (A_FL + B_FL);
     const float* Bb = Ab + A_FL;
     if (ROLE == WGRAD) {
 #pragma unroll
@@ -682,6 +686,7 @@ __global__ __launch_bounds__(256, 2) void igemm_dma_kernel(const Params p) {
 // dominated by prologue/epilogue latency and do better with the register-staged kernel's 3 workgroups
 // per CU.  Measured on MI355X (scratch/bench_conv.py): crossover around 24 K tiles per workgroup.
 constexpr int kDmaMinKTiles = 24;
+constexpr bool kShortSweepDma = true;   // short sweeps: single-buffered DMA kernel instead of the register-staged one
 
 // Every K tile inside one filter tap?  (kernel 1x1, or channel count a multiple of the K tile.)
 inline bool dma_eligible(int role, const Params& p) {
@@ -734,8 +739,10 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
   int splits = plan_splits(ntiles, ktiles);
   if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
   const bool dma = dma_eligible(ROLE, p) && ceil_div(ktiles, splits) >= kDmaMinKTiles;
+  const bool dma1 = !dma && dma_eligible(ROLE, p) && kShortSweepDma;
   if (splits <= 1) {
-    if (dma) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
+    if (dma) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 2>), dim3(ntiles, 1), dim3(256), 0, st, p);
+    else if (dma1) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, 1), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
     JTSM_CHECK_LAUNCH("igemm");
     return JTSM_OK;
@@ -743,7 +750,8 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
   p.ktiles_per_split = ceil_div(ktiles, splits);
   splits = ceil_div(ktiles, p.ktiles_per_split);
   p.slab = reinterpret_cast<float*>(workspace);
-  if (dma) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  if (dma) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 2>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  else if (dma1) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm split-K");
   const long total = (long)p.M * p.N;
@@ -757,7 +765,9 @@ template <int ROLE, int BM, int BN>
 int launch(const Params& p, int splits, hipStream_t st) {
   const int ntiles = ceil_div(p.N, BN) * ceil_div(p.M, BM);
   if (dma_eligible(ROLE, p) && p.ktiles_per_split >= kDmaMinKTiles)
-    hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
+    hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 2>), dim3(ntiles, splits), dim3(256), 0, st, p);
+  else if (dma_eligible(ROLE, p) && kShortSweepDma && ROLE != WGRAD)  // WGRAD short sweeps: register-staged is on par
+    hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits), dim3(256), 0, st, p);
   else
     hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm");
@@ -847,7 +857,7 @@ int jtsm_conv_plan(const jtsm_conv_shape* s, int role, int has_kscale, int* kern
     kps = ceil_div(ktiles, sp);
     sp = ceil_div(ktiles, kps);
   }
-  if (kernel) *kernel = (dma_eligible(role, p) && kps >= kDmaMinKTiles) ? 1 : 0;
+  if (kernel) *kernel = !dma_eligible(role, p) ? 0 : (kps >= kDmaMinKTiles ? 1 : ((kShortSweepDma && role != WGRAD) ? 2 : 0));
   if (tile_m) *tile_m = bm;
   if (tile_n) *tile_n = bn;
   if (splits) *splits = sp;

@@ -42,7 +42,9 @@ def _variant(s, role, has_kscale=False):
     k, bm, bn, sp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     L.check(L.lib().jtsm_conv_plan(C.byref(s), role, int(has_kscale), C.byref(k), C.byref(bm), C.byref(bn),
                                    C.byref(sp)), "conv_plan")
-    return "%s<%s,%d,%d>" % ("igemm_dma_kernel" if k.value else "igemm_kernel", _ROLE_NAME[role], bm.value, bn.value)
+    if k.value == 0:
+        return "igemm_kernel<%s,%d,%d>" % (_ROLE_NAME[role], bm.value, bn.value)
+    return "igemm_dma_kernel<%s,%d,%d,%d>" % (_ROLE_NAME[role], bm.value, bn.value, 2 if k.value == 1 else 1)
 
 
 def _desc(s):
