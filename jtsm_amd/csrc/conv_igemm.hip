@@ -686,6 +686,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void igemm_dma_kernel(const
 // dominated by prologue/epilogue latency and do better with the register-staged kernel's 3 workgroups
 // per CU.  Measured on MI355X (scratch/bench_conv.py): crossover around 24 K tiles per workgroup.
 constexpr int kDmaMinKTiles = 24;
+constexpr int kWgradTargetBlocks = 1024;  // WGRAD pixel-axis split: workgroups aimed at (atomic traffic grows with it)
 constexpr bool kShortSweepDma = true;   // short sweeps: single-buffered DMA kernel instead of the register-staged one
 
 // Every K tile inside one filter tap?  (kernel 1x1, or channel count a multiple of the K tile.)
@@ -846,7 +847,7 @@ int jtsm_conv_plan(const jtsm_conv_shape* s, int role, int has_kscale, int* kern
   const int ktiles = ceil_div(p.K, BK);
   if (role == WGRAD) {
     const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
-    sp = ceil_div(1024, ntiles);
+    sp = ceil_div(kWgradTargetBlocks, ntiles);
     if (sp > ceil_div(ktiles, 8)) sp = ceil_div(ktiles, 8);
     if (sp < 1) sp = 1;
     kps = ceil_div(ktiles, sp);
@@ -942,7 +943,7 @@ int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
   // least 8 K tiles (256 pixels) per split so the atomic tail stays small.
   const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
   const int ktiles = ceil_div(p.K, BK);
-  int splits = ceil_div(1024, ntiles);
+  int splits = ceil_div(kWgradTargetBlocks, ntiles);
   if (splits > ceil_div(ktiles, 8)) splits = ceil_div(ktiles, 8);
   if (splits < 1) splits = 1;
   p.ktiles_per_split = ceil_div(ktiles, splits);
