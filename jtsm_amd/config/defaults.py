@@ -1,140 +1,57 @@
-"""Default values of the config keys the JTSM path reads; values as in
-detectron2/config/defaults.py (line refs below) and projects/WSL/wsl/config/defaults.py:7-73."""
+"""Default values for the config keys the JTSM path reads, as one nested literal.  Values are those of
+detectron2/config/defaults.py (e.g. FREEZE_AT :130, RESNETS.NORM :471, STRIDE_IN_1X1 :479,
+DEFORM_ON_PER_STAGE :491) and, for the WSL block, projects/WSL/wsl/config/defaults.py:7-73."""
 from .config import CfgNode as CN
 
-_C = CN()
-_C.VERSION = 2
+_DEFAULTS = {
+    "VERSION": 2,
+    "OUTPUT_DIR": "./output",
+    "VIS_PERIOD": 0,
+    "SEED": -1,
+    "INPUT": {"FORMAT": "BGR", "MASK_FORMAT": "polygon"},
+    "DATASETS": {},
+    "TEST": {"DETECTIONS_PER_IMAGE": 100},
+    "SOLVER": {"MAX_ITER": 40000, "BASE_LR": 0.001, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.0001,
+               "WEIGHT_DECAY_NORM": 0.0, "BIAS_LR_FACTOR": 1.0, "WEIGHT_DECAY_BIAS": 0.0001, "IMS_PER_BATCH": 16},
+    "MODEL": {
+        "LOAD_PROPOSALS": False, "MASK_ON": False, "KEYPOINT_ON": False, "DEVICE": "cuda",
+        "META_ARCHITECTURE": "GeneralizedRCNN", "WEIGHTS": "",
+        "PIXEL_MEAN": [103.530, 116.280, 123.675], "PIXEL_STD": [1.0, 1.0, 1.0],
+        "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 2},
+        "FPN": {"IN_FEATURES": [], "OUT_CHANNELS": 256, "NORM": "", "FUSE_TYPE": "sum"},
+        "PROPOSAL_GENERATOR": {"NAME": "RPN", "MIN_SIZE": 0},
+        "RESNETS": {"DEPTH": 50, "OUT_FEATURES": ["res4"], "NUM_GROUPS": 1, "NORM": "FrozenBN",
+                    "WIDTH_PER_GROUP": 64, "STRIDE_IN_1X1": True, "RES5_DILATION": 1, "RES2_OUT_CHANNELS": 256,
+                    "STEM_OUT_CHANNELS": 64, "DEFORM_ON_PER_STAGE": [False, False, False, False],
+                    "DEFORM_MODULATED": False, "DEFORM_NUM_GROUPS": 1},
+        "ROI_HEADS": {"NAME": "Res5ROIHeads", "NUM_CLASSES": 80, "IN_FEATURES": ["res4"], "IOU_THRESHOLDS": [0.5],
+                      "IOU_LABELS": [0, 1], "BATCH_SIZE_PER_IMAGE": 512, "POSITIVE_FRACTION": 0.25,
+                      "SCORE_THRESH_TEST": 0.05, "NMS_THRESH_TEST": 0.5, "PROPOSAL_APPEND_GT": True},
+        "ROI_BOX_HEAD": {"NAME": "", "BBOX_REG_LOSS_TYPE": "smooth_l1", "BBOX_REG_LOSS_WEIGHT": 1.0,
+                         "BBOX_REG_WEIGHTS": (10.0, 10.0, 5.0, 5.0), "SMOOTH_L1_BETA": 0.0, "POOLER_RESOLUTION": 14,
+                         "POOLER_SAMPLING_RATIO": 0, "POOLER_TYPE": "ROIAlignV2", "NUM_FC": 0, "FC_DIM": 1024,
+                         "NUM_CONV": 0, "CONV_DIM": 256, "NORM": "", "CLS_AGNOSTIC_BBOX_REG": False,
+                         "TRAIN_ON_PRED_BOXES": False},
+        "ROI_MASK_HEAD": {"NAME": "MaskRCNNConvUpsampleHead", "POOLER_RESOLUTION": 14, "POOLER_SAMPLING_RATIO": 0,
+                          "NUM_CONV": 0, "CONV_DIM": 256, "NORM": "", "CLS_AGNOSTIC_MASK": False,
+                          "POOLER_TYPE": "ROIAlignV2"},
+        "SEM_SEG_HEAD": {"NAME": "SemSegFPNHead", "IN_FEATURES": ["p2", "p3", "p4", "p5"], "IGNORE_VALUE": 255,
+                         "NUM_CLASSES": 54, "CONVS_DIM": 128, "COMMON_STRIDE": 4, "NORM": "GN", "LOSS_WEIGHT": 1.0},
+    },
+}
 
-_C.MODEL = CN()
-_C.MODEL.LOAD_PROPOSALS = False
-_C.MODEL.MASK_ON = False
-_C.MODEL.KEYPOINT_ON = False
-_C.MODEL.DEVICE = "cuda"
-_C.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
-_C.MODEL.WEIGHTS = ""
-_C.MODEL.PIXEL_MEAN = [103.530, 116.280, 123.675]          # defaults.py:40-43 (BGR)
-_C.MODEL.PIXEL_STD = [1.0, 1.0, 1.0]
+_WSL_DEFAULTS = {
+    "WSL": {"VIS_TEST": False, "ITER_SIZE": 1, "MEAN_LOSS": True, "SIZE_EPOCH": 5000, "CMIL": False, "USE_OBN": True,
+            "REFINE_NUM": 3, "REFINE_REG": [False, False, False], "HAS_GAM": False, "REFINE_MIST": False,
+            "CLS_AGNOSTIC_BBOX_KNOWN": False, "SAMPLING": {"SAMPLING_ON": False}, "CASCADE_ON": False, "PS_ON": False,
+            "SP_ON": False, "MASK_MINED_TOP_K": 10},
+    "MODEL": {"ROI_BOX_HEAD": {"DAN_DIM": [4096, 4096]},
+              "SEM_SEG_HEAD": {"MASK_SOFTMAX": False, "CONSTRAINT": False}},
+}
 
-_C.INPUT = CN()
-_C.INPUT.FORMAT = "BGR"
-_C.INPUT.MASK_FORMAT = "polygon"
-
-_C.MODEL.BACKBONE = CN()
-_C.MODEL.BACKBONE.NAME = "build_resnet_backbone"
-_C.MODEL.BACKBONE.FREEZE_AT = 2                            # defaults.py:130
-
-_C.MODEL.FPN = CN()
-_C.MODEL.FPN.IN_FEATURES = []
-_C.MODEL.FPN.OUT_CHANNELS = 256
-_C.MODEL.FPN.NORM = ""
-_C.MODEL.FPN.FUSE_TYPE = "sum"
-
-_C.MODEL.PROPOSAL_GENERATOR = CN()
-_C.MODEL.PROPOSAL_GENERATOR.NAME = "RPN"
-_C.MODEL.PROPOSAL_GENERATOR.MIN_SIZE = 0
-
-_C.MODEL.ROI_HEADS = CN()
-_C.MODEL.ROI_HEADS.NAME = "Res5ROIHeads"
-_C.MODEL.ROI_HEADS.NUM_CLASSES = 80
-_C.MODEL.ROI_HEADS.IN_FEATURES = ["res4"]
-_C.MODEL.ROI_HEADS.IOU_THRESHOLDS = [0.5]
-_C.MODEL.ROI_HEADS.IOU_LABELS = [0, 1]
-_C.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 512
-_C.MODEL.ROI_HEADS.POSITIVE_FRACTION = 0.25
-_C.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.05
-_C.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.5
-_C.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT = True
-
-_C.MODEL.ROI_BOX_HEAD = CN()
-_C.MODEL.ROI_BOX_HEAD.NAME = ""
-_C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE = "smooth_l1"
-_C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT = 1.0
-_C.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
-_C.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA = 0.0
-_C.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
-_C.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
-_C.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignV2"
-_C.MODEL.ROI_BOX_HEAD.NUM_FC = 0
-_C.MODEL.ROI_BOX_HEAD.FC_DIM = 1024
-_C.MODEL.ROI_BOX_HEAD.NUM_CONV = 0
-_C.MODEL.ROI_BOX_HEAD.CONV_DIM = 256
-_C.MODEL.ROI_BOX_HEAD.NORM = ""
-_C.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = False
-_C.MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES = False
-
-_C.MODEL.ROI_MASK_HEAD = CN()
-_C.MODEL.ROI_MASK_HEAD.NAME = "MaskRCNNConvUpsampleHead"
-_C.MODEL.ROI_MASK_HEAD.POOLER_RESOLUTION = 14
-_C.MODEL.ROI_MASK_HEAD.POOLER_SAMPLING_RATIO = 0
-_C.MODEL.ROI_MASK_HEAD.NUM_CONV = 0
-_C.MODEL.ROI_MASK_HEAD.CONV_DIM = 256
-_C.MODEL.ROI_MASK_HEAD.NORM = ""
-_C.MODEL.ROI_MASK_HEAD.CLS_AGNOSTIC_MASK = False
-_C.MODEL.ROI_MASK_HEAD.POOLER_TYPE = "ROIAlignV2"
-
-_C.MODEL.SEM_SEG_HEAD = CN()
-_C.MODEL.SEM_SEG_HEAD.NAME = "SemSegFPNHead"
-_C.MODEL.SEM_SEG_HEAD.IN_FEATURES = ["p2", "p3", "p4", "p5"]
-_C.MODEL.SEM_SEG_HEAD.IGNORE_VALUE = 255
-_C.MODEL.SEM_SEG_HEAD.NUM_CLASSES = 54
-_C.MODEL.SEM_SEG_HEAD.CONVS_DIM = 128
-_C.MODEL.SEM_SEG_HEAD.COMMON_STRIDE = 4
-_C.MODEL.SEM_SEG_HEAD.NORM = "GN"
-_C.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT = 1.0
-
-_C.MODEL.RESNETS = CN()
-_C.MODEL.RESNETS.DEPTH = 50
-_C.MODEL.RESNETS.OUT_FEATURES = ["res4"]
-_C.MODEL.RESNETS.NUM_GROUPS = 1
-_C.MODEL.RESNETS.NORM = "FrozenBN"                         # defaults.py:471
-_C.MODEL.RESNETS.WIDTH_PER_GROUP = 64
-_C.MODEL.RESNETS.STRIDE_IN_1X1 = True                      # defaults.py:479
-_C.MODEL.RESNETS.RES5_DILATION = 1
-_C.MODEL.RESNETS.RES2_OUT_CHANNELS = 256
-_C.MODEL.RESNETS.STEM_OUT_CHANNELS = 64
-_C.MODEL.RESNETS.DEFORM_ON_PER_STAGE = [False, False, False, False]   # defaults.py:491
-_C.MODEL.RESNETS.DEFORM_MODULATED = False
-_C.MODEL.RESNETS.DEFORM_NUM_GROUPS = 1
-
-_C.SOLVER = CN()
-_C.SOLVER.MAX_ITER = 40000
-_C.SOLVER.BASE_LR = 0.001
-_C.SOLVER.MOMENTUM = 0.9
-_C.SOLVER.WEIGHT_DECAY = 0.0001
-_C.SOLVER.WEIGHT_DECAY_NORM = 0.0
-_C.SOLVER.BIAS_LR_FACTOR = 1.0
-_C.SOLVER.WEIGHT_DECAY_BIAS = 0.0001
-_C.SOLVER.IMS_PER_BATCH = 16
-
-_C.TEST = CN()
-_C.TEST.DETECTIONS_PER_IMAGE = 100
-_C.DATASETS = CN()
-_C.OUTPUT_DIR = "./output"
-_C.VIS_PERIOD = 0
-_C.SEED = -1
+_C = CN(_DEFAULTS)
 
 
 def add_wsl_config(cfg):
-    """The project keys of projects/WSL/wsl/config/defaults.py:7-73 that the JTSM path reads."""
-    _C = cfg
-    _C.WSL = CN()
-    _C.WSL.VIS_TEST = False
-    _C.WSL.ITER_SIZE = 1
-    _C.WSL.MEAN_LOSS = True
-    _C.WSL.SIZE_EPOCH = 5000
-    _C.WSL.CMIL = False
-    _C.MODEL.ROI_BOX_HEAD.DAN_DIM = [4096, 4096]
-    _C.WSL.USE_OBN = True
-    _C.WSL.REFINE_NUM = 3
-    _C.WSL.REFINE_REG = [False, False, False]
-    _C.WSL.HAS_GAM = False
-    _C.WSL.REFINE_MIST = False
-    _C.WSL.CLS_AGNOSTIC_BBOX_KNOWN = False
-    _C.WSL.SAMPLING = CN()
-    _C.WSL.SAMPLING.SAMPLING_ON = False
-    _C.WSL.CASCADE_ON = False
-    _C.WSL.PS_ON = False
-    _C.WSL.SP_ON = False
-    _C.WSL.MASK_MINED_TOP_K = 10
-    _C.MODEL.SEM_SEG_HEAD.MASK_SOFTMAX = False
-    _C.MODEL.SEM_SEG_HEAD.CONSTRAINT = False
+    """Add the project keys of projects/WSL (add_wsl_config there) to a config node in place."""
+    cfg.merge_from_other_cfg(CN(_WSL_DEFAULTS))

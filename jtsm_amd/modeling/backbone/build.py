@@ -1,4 +1,5 @@
-"""BACKBONE_REGISTRY / build_backbone — detectron2/modeling/backbone/build.py:7-33."""
+"""BACKBONE_REGISTRY and build_backbone(cfg[, input_shape]) — detectron2/modeling/backbone/build.py:7-33.
+Registered builders take (cfg, ShapeSpec of the input image) and return a Backbone."""
 from ...layers.shape_spec import ShapeSpec
 from ...utils.registry import Registry
 from .backbone import Backbone
@@ -7,8 +8,9 @@ BACKBONE_REGISTRY = Registry("BACKBONE")
 
 
 def build_backbone(cfg, input_shape=None):
-    if input_shape is None:
-        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
-    backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, input_shape)
-    assert isinstance(backbone, Backbone)
-    return backbone
+    shape = input_shape if input_shape is not None else ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    builder = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)
+    net = builder(cfg, shape)
+    if not isinstance(net, Backbone):
+        raise TypeError("%s returned %s, expected a Backbone" % (cfg.MODEL.BACKBONE.NAME, type(net).__name__))
+    return net

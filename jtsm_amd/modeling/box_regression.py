@@ -1,4 +1,5 @@
-"""Box2BoxTransform — surface of detectron2/modeling/box_regression.py:21-113."""
+"""Box2BoxTransform — call surface of detectron2/modeling/box_regression.py:21-113 (R-CNN box deltas
+(dx, dy, dw, dh) with per-coordinate weights), written on top of two small xyxy <-> centre/size helpers."""
 import math
 
 import torch
@@ -6,49 +7,37 @@ import torch
 _DEFAULT_SCALE_CLAMP = math.log(1000.0 / 16)
 
 
+def _to_center_size(boxes):
+    """(..., 4) xyxy -> centre (..., 2) and size (..., 2)."""
+    size = boxes[..., 2:] - boxes[..., :2]
+    return boxes[..., :2] + 0.5 * size, size
+
+
 class Box2BoxTransform:
     def __init__(self, weights, scale_clamp: float = _DEFAULT_SCALE_CLAMP):
-        self.weights = weights
-        self.scale_clamp = scale_clamp
+        self.weights = weights          # (wx, wy, ww, wh)
+        self.scale_clamp = scale_clamp  # upper bound of dw, dh before exp()
 
     def get_deltas(self, src_boxes, target_boxes):
-        assert isinstance(src_boxes, torch.Tensor), type(src_boxes)
-        assert isinstance(target_boxes, torch.Tensor), type(target_boxes)
-        src_widths = src_boxes[:, 2] - src_boxes[:, 0]
-        src_heights = src_boxes[:, 3] - src_boxes[:, 1]
-        src_ctr_x = src_boxes[:, 0] + 0.5 * src_widths
-        src_ctr_y = src_boxes[:, 1] + 0.5 * src_heights
-        target_widths = target_boxes[:, 2] - target_boxes[:, 0]
-        target_heights = target_boxes[:, 3] - target_boxes[:, 1]
-        target_ctr_x = target_boxes[:, 0] + 0.5 * target_widths
-        target_ctr_y = target_boxes[:, 1] + 0.5 * target_heights
-        wx, wy, ww, wh = self.weights
-        dx = wx * (target_ctr_x - src_ctr_x) / src_widths
-        dy = wy * (target_ctr_y - src_ctr_y) / src_heights
-        dw = ww * torch.log(target_widths / src_widths)
-        dh = wh * torch.log(target_heights / src_heights)
-        deltas = torch.stack((dx, dy, dw, dh), dim=1)
-        assert (src_widths > 0).all().item(), "Input boxes to Box2BoxTransform are not valid!"
-        return deltas
+        """Deltas that map src_boxes (N,4) onto target_boxes (N,4)."""
+        assert isinstance(src_boxes, torch.Tensor) and isinstance(target_boxes, torch.Tensor)
+        sc, ss = _to_center_size(src_boxes)
+        tc, ts = _to_center_size(target_boxes)
+        assert bool((ss[:, 0] > 0).all()), "Input boxes to Box2BoxTransform are not valid!"
+        w = src_boxes.new_tensor(self.weights)
+        shift = w[:2] * (tc - sc) / ss
+        scale = w[2:] * torch.log(ts / ss)
+        return torch.cat((shift, scale), dim=1)
 
     def apply_deltas(self, deltas, boxes):
+        """deltas (N, k*4) for k classes, boxes (N,4) -> predicted boxes (N, k*4)."""
         boxes = boxes.to(deltas.dtype)
-        widths = boxes[:, 2] - boxes[:, 0]
-        heights = boxes[:, 3] - boxes[:, 1]
-        ctr_x = boxes[:, 0] + 0.5 * widths
-        ctr_y = boxes[:, 1] + 0.5 * heights
-        wx, wy, ww, wh = self.weights
-        dx = deltas[:, 0::4] / wx
-        dy = deltas[:, 1::4] / wy
-        dw = torch.clamp(deltas[:, 2::4] / ww, max=self.scale_clamp)
-        dh = torch.clamp(deltas[:, 3::4] / wh, max=self.scale_clamp)
-        pred_ctr_x = dx * widths[:, None] + ctr_x[:, None]
-        pred_ctr_y = dy * heights[:, None] + ctr_y[:, None]
-        pred_w = torch.exp(dw) * widths[:, None]
-        pred_h = torch.exp(dh) * heights[:, None]
-        pred_boxes = torch.zeros_like(deltas)
-        pred_boxes[:, 0::4] = pred_ctr_x - 0.5 * pred_w
-        pred_boxes[:, 1::4] = pred_ctr_y - 0.5 * pred_h
-        pred_boxes[:, 2::4] = pred_ctr_x + 0.5 * pred_w
-        pred_boxes[:, 3::4] = pred_ctr_y + 0.5 * pred_h
-        return pred_boxes
+        n = deltas.shape[0]
+        d = deltas.reshape(n, -1, 4)
+        centre, size = _to_center_size(boxes)
+        centre, size = centre[:, None, :], size[:, None, :]
+        w = deltas.new_tensor(self.weights)
+        new_centre = d[..., :2] / w[:2] * size + centre
+        new_size = torch.exp(torch.clamp(d[..., 2:] / w[2:], max=self.scale_clamp)) * size
+        out = torch.cat((new_centre - 0.5 * new_size, new_centre + 0.5 * new_size), dim=-1)
+        return out.reshape(n, -1)

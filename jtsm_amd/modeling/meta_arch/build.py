@@ -1,4 +1,5 @@
-"""META_ARCH_REGISTRY / build_model — detectron2/modeling/meta_arch/build.py:6-23."""
+"""META_ARCH_REGISTRY and build_model(cfg) — detectron2/modeling/meta_arch/build.py:6-23: look the class
+named by cfg.MODEL.META_ARCHITECTURE up, construct it from cfg, move it to cfg.MODEL.DEVICE (no weights)."""
 import torch
 
 from ...utils.registry import Registry
@@ -7,9 +8,5 @@ META_ARCH_REGISTRY = Registry("META_ARCH")
 
 
 def build_model(cfg):
-    """Build the meta-architecture named by cfg.MODEL.META_ARCHITECTURE and move it to
-    cfg.MODEL.DEVICE.  No weights are loaded."""
-    meta_arch = cfg.MODEL.META_ARCHITECTURE
-    model = META_ARCH_REGISTRY.get(meta_arch)(cfg)
-    model.to(torch.device(cfg.MODEL.DEVICE))
-    return model
+    arch_cls = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)
+    return arch_cls(cfg).to(torch.device(cfg.MODEL.DEVICE))

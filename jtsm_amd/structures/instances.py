@@ -1,72 +1,89 @@
-"""Instances — surface of detectron2/structures/instances.py: per-image bag of equal-length fields."""
-import itertools
+"""Instances — per-image container of equally long fields (boxes, scores, labels ...) with the call
+surface model code expects from detectron2/structures/instances.py: attribute get/set, has/get/set/remove,
+indexing by int / slice / index or mask tensor, len(), to(), cat()."""
 from typing import Any, Dict, List, Tuple
 
 import torch
 
 
-class Instances:
-    def __init__(self, image_size: Tuple[int, int], **kwargs: Any):
-        self._image_size = image_size
-        self._fields: Dict[str, Any] = {}
-        for k, v in kwargs.items():
-            self.set(k, v)
+def _length(value):
+    return len(value)
 
+
+def _concat(values):
+    head = values[0]
+    if isinstance(head, torch.Tensor):
+        return torch.cat(values, dim=0)
+    if isinstance(head, list):
+        return [x for v in values for x in v]
+    joiner = getattr(type(head), "cat", None)
+    if joiner is None:
+        raise ValueError("Unsupported type {} for concatenation".format(type(head)))
+    return joiner(values)
+
+
+class Instances:
+    __slots__ = ("_image_size", "_fields")
+
+    def __init__(self, image_size: Tuple[int, int], **fields: Any):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_fields", {})
+        for name, value in fields.items():
+            self.set(name, value)
+
+    # ---- field access ---------------------------------------------------------------------------
     @property
-    def image_size(self):
+    def image_size(self) -> Tuple[int, int]:
         return self._image_size
 
-    def __setattr__(self, name, val):
-        if name.startswith("_"):
-            super().__setattr__(name, val)
-        else:
-            self.set(name, val)
-
-    def __getattr__(self, name):
-        if name == "_fields" or name not in self._fields:
-            raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
-        return self._fields[name]
-
-    def set(self, name, value):
-        data_len = len(value)
-        if len(self._fields):
-            assert len(self) == data_len, "Adding a field of length {} to a Instances of length {}".format(
-                data_len, len(self))
+    def set(self, name: str, value: Any) -> None:
+        if self._fields:
+            have, got = len(self), _length(value)
+            assert have == got, "Adding a field of length {} to a Instances of length {}".format(got, have)
         self._fields[name] = value
 
-    def has(self, name):
-        return name in self._fields
-
-    def remove(self, name):
-        del self._fields[name]
-
-    def get(self, name):
+    def get(self, name: str) -> Any:
         return self._fields[name]
 
-    def get_fields(self):
+    def has(self, name: str) -> bool:
+        return name in self._fields
+
+    def remove(self, name: str) -> None:
+        del self._fields[name]
+
+    def get_fields(self) -> Dict[str, Any]:
         return self._fields
 
-    def to(self, *args, **kwargs):
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            if hasattr(v, "to"):
-                v = v.to(*args, **kwargs)
-            ret.set(k, v)
-        return ret
+    def __setattr__(self, name: str, value: Any) -> None:
+        self.set(name, value)
 
-    def __getitem__(self, item):
-        if type(item) == int:
-            if item >= len(self) or item < -len(self):
+    def __getattr__(self, name: str) -> Any:
+        fields = object.__getattribute__(self, "_fields")
+        if name in fields:
+            return fields[name]
+        raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
+
+    # ---- whole-container operations -------------------------------------------------------------
+    def _rebuild(self, fn) -> "Instances":
+        out = Instances(self._image_size)
+        for name, value in self._fields.items():
+            out.set(name, fn(value))
+        return out
+
+    def to(self, *args: Any, **kwargs: Any) -> "Instances":
+        return self._rebuild(lambda v: v.to(*args, **kwargs) if hasattr(v, "to") else v)
+
+    def __getitem__(self, item) -> "Instances":
+        if isinstance(item, int):
+            n = len(self)
+            if not -n <= item < n:
                 raise IndexError("Instances index out of range!")
-            item = slice(item, None, len(self))
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v[item])
-        return ret
+            item = slice(item, None, n)   # keeps the result 1 element long
+        return self._rebuild(lambda v: v[item])
 
-    def __len__(self):
-        for v in self._fields.values():
-            return v.__len__()
+    def __len__(self) -> int:
+        for value in self._fields.values():
+            return _length(value)
         raise NotImplementedError("Empty Instances does not support __len__!")
 
     def __iter__(self):
@@ -74,30 +91,18 @@ class Instances:
 
     @staticmethod
     def cat(instance_lists: List["Instances"]) -> "Instances":
-        assert all(isinstance(i, Instances) for i in instance_lists)
-        assert len(instance_lists) > 0
+        assert len(instance_lists) > 0 and all(isinstance(i, Instances) for i in instance_lists)
+        first = instance_lists[0]
         if len(instance_lists) == 1:
-            return instance_lists[0]
-        ret = Instances(instance_lists[0].image_size)
-        for k in instance_lists[0]._fields.keys():
-            values = [i.get(k) for i in instance_lists]
-            v0 = values[0]
-            if isinstance(v0, torch.Tensor):
-                values = torch.cat(values, dim=0)
-            elif isinstance(v0, list):
-                values = list(itertools.chain(*values))
-            elif hasattr(type(v0), "cat"):
-                values = type(v0).cat(values)
-            else:
-                raise ValueError("Unsupported type {} for concatenation".format(type(v0)))
-            ret.set(k, values)
-        return ret
+            return first
+        out = Instances(first.image_size)
+        for name in first._fields:
+            out.set(name, _concat([inst.get(name) for inst in instance_lists]))
+        return out
 
-    def __str__(self):
-        s = self.__class__.__name__ + "("
-        s += "num_instances={}, image_height={}, image_width={}, fields=[{}])".format(
-            len(self), self._image_size[0], self._image_size[1],
-            ", ".join("{}: {}".format(k, v) for k, v in self._fields.items()))
-        return s
+    def __repr__(self) -> str:
+        body = ", ".join("{}: {}".format(k, v) for k, v in self._fields.items())
+        return "Instances(num_instances={}, image_height={}, image_width={}, fields=[{}])".format(
+            len(self) if self._fields else 0, self._image_size[0], self._image_size[1], body)
 
-    __repr__ = __str__
+    __str__ = __repr__
