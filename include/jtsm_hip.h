@@ -328,6 +328,35 @@ int jtsm_semseg_ce_backward_f32(const float* logits, int ld, int C, const int64_
                                 const void* workspace, int N, int Hs, int Ws, int S, long ignore_index,
                                 void* stream);
 
+
+/* ---------------------------------------------------------------------------
+ * Pseudo-ground-truth mining and proposal labelling (no native reference; PyTorch glue at
+ * projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:1167-1338 (get_pgt_top_k, top_k = 1),
+ * roi_heads.py:264-370 (label_and_sample_proposals: pairwise_iou + Matcher([0.5],[0,1]), no
+ * sub-sampling), fast_rcnn_oicr.py:684-783 (softmax / apply_deltas of the previous branch)).
+ * Proposals of image i are rows [bag_offsets[i], bag_offsets[i+1]); image i has counts[i] <= Gmax
+ * present classes, listed in classes[i*Gmax ..].
+ * ------------------------------------------------------------------------- */
+/* lse[r] = log sum_c exp(logits[r,c]). */
+int jtsm_row_lse_f32(const float* logits, int ld, int ncls, int R, float* lse, void* stream);
+/* For every (image, present class): the row with the highest score[r,class] (score = scores[r,c], or
+ * exp(scores[r,c] - lse[r]) when lse != NULL, i.e. softmax of logits; lowest row wins ties).  Writes the
+ * row (relative to the image), its score, the class's image-level probability as weight, and the box:
+ * the proposal itself, or (deltas != NULL, (R, ld_deltas) class-major 4-tuples) the proposal decoded with
+ * Box2BoxTransform(10,10,5,5).apply_deltas for that class. */
+int jtsm_mine_top1_f32(const float* scores, int ld, const float* lse, const float* proposals,
+                       const float* deltas, int ld_deltas, const int32_t* bag_offsets,
+                       const int32_t* classes, const int32_t* counts, int B, int Gmax,
+                       const float* img_probs, int nprob, int32_t* out_idx, float* out_box,
+                       float* out_score, float* out_weight, void* stream);
+/* For every proposal: IoU against its image's pseudo boxes (first maximum wins), label = that box's
+ * class if IoU >= iou_thresh else bg_label, plus the matched index / box / weight / (optional) score. */
+int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int B, int R,
+                         const float* pgt_box, const int32_t* classes, const int32_t* counts,
+                         const float* pgt_weight, const float* pgt_score, int Gmax, float iou_thresh,
+                         int bg_label, int32_t* labels, int32_t* matched, float* gt_boxes,
+                         float* gt_weights, float* gt_scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,199 @@
+// Pseudo-ground-truth mining and proposal labelling of JTSMROIHeads, fused.
+//
+// Replaces, per refinement round, the chain of ~150 small PyTorch launches (and several host syncs) of
+//   get_pgt_top_k            projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:1167-1338 (top_k = 1)
+//   label_and_sample_proposals  projects/WSL/wsl/modeling/roi_heads/roi_heads.py:264-370
+//     (pairwise_iou detectron2/structures/boxes.py:345-392, Matcher([0.5],[0,1]) modeling/matcher.py:61-103)
+//   predict_probs / predict_boxes  .../fast_rcnn_oicr.py:684-783 (softmax, Box2BoxTransform.apply_deltas
+//     detectron2/modeling/box_regression.py:73-113) — evaluated only where they are consumed
+// by three launches: row log-sum-exp, one block-wide arg-max per (image, present class), and one
+// IoU-match per proposal.  Results are integers (winning rows, labels, matched indices) plus the copied
+// pseudo boxes / weights, in exactly the layout the OICR loss kernel takes.
+// Floating-point steps that decide integers (IoU, box decoding) are evaluated un-contracted, in the
+// reference's operation order.
+#include <cfloat>
+
+#include "common.h"
+
+namespace jtsm {
+namespace {
+
+#pragma clang fp contract(off)
+
+// lse[r] = log(sum_c exp(z[r,c]))   (wavefront per row, any ncls)
+__global__ __launch_bounds__(256) void row_lse_kernel(const float* __restrict__ z, int ld, int ncls, int R,
+                                                      float* __restrict__ lse) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float* row = z + (size_t)r * ld;
+  float mx = -FLT_MAX;
+  for (int c = lane; c < ncls; c += 64) mx = fmaxf(mx, row[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float sm = 0.f;
+  for (int c = lane; c < ncls; c += 64) sm += expf(row[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+  if (lane == 0) lse[r] = mx + logf(sm);
+}
+
+__device__ __forceinline__ void decode_box(const float* __restrict__ p, const float* __restrict__ d, float* out) {
+#pragma clang fp contract(off)
+  // Box2BoxTransform(10,10,5,5).apply_deltas for one (box, class) pair
+  const float w = p[2] - p[0], h = p[3] - p[1];
+  const float cx = p[0] + 0.5f * w, cy = p[1] + 0.5f * h;
+  const float dx = d[0] / 10.f, dy = d[1] / 10.f;
+  const float kClamp = 4.135166556742356f;  // log(1000/16)
+  const float dw = fminf(d[2] / 5.f, kClamp), dh = fminf(d[3] / 5.f, kClamp);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  out[0] = pcx - 0.5f * pw;
+  out[1] = pcy - 0.5f * ph;
+  out[2] = pcx + 0.5f * pw;
+  out[3] = pcy + 0.5f * ph;
+}
+
+// One workgroup per (image, class slot): arg-max over the image's proposals of the class score
+// (score = scores[r,cls], or exp(scores[r,cls] - lse[r]) when lse is given); lowest row wins ties.
+__global__ __launch_bounds__(256) void mine_top1_kernel(const float* __restrict__ scores, int ld,
+                                                        const float* __restrict__ lse,
+                                                        const float* __restrict__ proposals,
+                                                        const float* __restrict__ deltas, int ld_d,
+                                                        const int* __restrict__ bag_off,
+                                                        const int* __restrict__ classes,
+                                                        const int* __restrict__ counts, int Gmax,
+                                                        const float* __restrict__ img_probs, int nprob,
+                                                        int* __restrict__ out_idx, float* __restrict__ out_box,
+                                                        float* __restrict__ out_score,
+                                                        float* __restrict__ out_weight) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int img = blockIdx.x / Gmax, g = blockIdx.x - img * Gmax;
+  if (g >= counts[img]) return;
+  const int cls = classes[img * Gmax + g];
+  const int r0 = bag_off[img], r1 = bag_off[img + 1];
+  float best = -FLT_MAX;
+  int at = 0x7fffffff;
+  for (int r = r0 + threadIdx.x; r < r1; r += 256) {
+    float v = scores[(size_t)r * ld + cls];
+    if (lse) v = expf(v - lse[r]);
+    if (v > best) { best = v; at = r; }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = at;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float v = sv[threadIdx.x + o];
+      const int i = si[threadIdx.x + o];
+      if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && i < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = i; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int r = si[0] == 0x7fffffff ? r0 : si[0];
+    const int o = img * Gmax + g;
+    out_idx[o] = r - r0;
+    out_score[o] = sv[0];
+    out_weight[o] = img_probs[(size_t)img * nprob + cls];
+    if (deltas) decode_box(proposals + 4 * (size_t)r, deltas + (size_t)r * ld_d + 4 * cls, out_box + 4 * o);
+    else for (int k = 0; k < 4; ++k) out_box[4 * o + k] = proposals[4 * (size_t)r + k];
+  }
+}
+
+// One thread per proposal: IoU against the image's pseudo boxes, first maximum wins; label = class of
+// the best box if IoU >= thresh else bg_label; also copies that box / weight / score.
+__global__ __launch_bounds__(256) void match_label_kernel(const float* __restrict__ proposals,
+                                                          const int* __restrict__ bag_off, int B, int R,
+                                                          const float* __restrict__ pgt_box,
+                                                          const int* __restrict__ classes,
+                                                          const int* __restrict__ counts,
+                                                          const float* __restrict__ pgt_weight,
+                                                          const float* __restrict__ pgt_score, int Gmax,
+                                                          float thresh, int bg_label, int* __restrict__ labels,
+                                                          int* __restrict__ matched, float* __restrict__ gt_boxes,
+                                                          float* __restrict__ gt_weights,
+                                                          float* __restrict__ gt_scores) {
+#pragma clang fp contract(off)
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  int img = 0;
+  while (img + 1 < B && r >= bag_off[img + 1]) ++img;
+  const float* p = proposals + 4 * (size_t)r;
+  const float area_p = (p[2] - p[0]) * (p[3] - p[1]);
+  const int n = counts[img];
+  float best = -1.f;
+  int at = 0;
+  for (int g = 0; g < n; ++g) {
+    const float* q = pgt_box + 4 * ((size_t)img * Gmax + g);
+    const float area_q = (q[2] - q[0]) * (q[3] - q[1]);
+    const float w = fmaxf(fminf(q[2], p[2]) - fmaxf(q[0], p[0]), 0.f);
+    const float h = fmaxf(fminf(q[3], p[3]) - fmaxf(q[1], p[1]), 0.f);
+    const float inter = w * h;
+    const float iou = inter > 0.f ? inter / (area_q + area_p - inter) : 0.f;
+    if (iou > best) { best = iou; at = g; }
+  }
+  const int o = img * Gmax + at;
+  if (n == 0) {
+    labels[r] = bg_label;
+    matched[r] = 0;
+    for (int k = 0; k < 4; ++k) gt_boxes[4 * (size_t)r + k] = p[k];
+    gt_weights[r] = 0.f;
+    if (gt_scores) gt_scores[r] = 0.f;
+    return;
+  }
+  labels[r] = best >= thresh ? classes[o] : bg_label;
+  matched[r] = at;
+  for (int k = 0; k < 4; ++k) gt_boxes[4 * (size_t)r + k] = pgt_box[4 * (size_t)o + k];
+  gt_weights[r] = pgt_weight[o];
+  if (gt_scores) gt_scores[r] = pgt_score[o];
+}
+
+}  // namespace
+}  // namespace jtsm
+
+using namespace jtsm;
+
+extern "C" {
+
+int jtsm_row_lse_f32(const float* logits, int ld, int ncls, int R, float* lse, void* stream) {
+  JTSM_REQUIRE(R >= 0 && ncls > 0 && ld >= ncls, "row_lse: bad sizes");
+  if (R == 0) return JTSM_OK;
+  JTSM_REQUIRE(logits && lse, "row_lse: null pointer");
+  hipLaunchKernelGGL(row_lse_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, as_stream(stream), logits, ld, ncls, R, lse);
+  JTSM_CHECK_LAUNCH("row_lse");
+  return JTSM_OK;
+}
+
+int jtsm_mine_top1_f32(const float* scores, int ld, const float* lse, const float* proposals, const float* deltas,
+                       int ld_deltas, const int32_t* bag_offsets, const int32_t* classes, const int32_t* counts,
+                       int B, int Gmax, const float* img_probs, int nprob, int32_t* out_idx, float* out_box,
+                       float* out_score, float* out_weight, void* stream) {
+  JTSM_REQUIRE(B >= 0 && Gmax >= 0, "mine_top1: bad sizes");
+  if (B == 0 || Gmax == 0) return JTSM_OK;
+  JTSM_REQUIRE(scores && proposals && bag_offsets && classes && counts && img_probs && out_idx && out_box &&
+               out_score && out_weight, "mine_top1: null pointer");
+  hipLaunchKernelGGL(mine_top1_kernel, dim3(B * Gmax), dim3(256), 0, as_stream(stream), scores, ld, lse, proposals,
+                     deltas, ld_deltas, bag_offsets, classes, counts, Gmax, img_probs, nprob, out_idx, out_box,
+                     out_score, out_weight);
+  JTSM_CHECK_LAUNCH("mine_top1");
+  return JTSM_OK;
+}
+
+int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int B, int R, const float* pgt_box,
+                         const int32_t* classes, const int32_t* counts, const float* pgt_weight,
+                         const float* pgt_score, int Gmax, float iou_thresh, int bg_label, int32_t* labels,
+                         int32_t* matched, float* gt_boxes, float* gt_weights, float* gt_scores, void* stream) {
+  JTSM_REQUIRE(B > 0 && R >= 0 && Gmax >= 0, "match_label: bad sizes");
+  if (R == 0) return JTSM_OK;
+  JTSM_REQUIRE(proposals && bag_offsets && pgt_box && classes && counts && pgt_weight && labels && matched &&
+               gt_boxes && gt_weights, "match_label: null pointer");
+  hipLaunchKernelGGL(match_label_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, as_stream(stream), proposals,
+                     bag_offsets, B, R, pgt_box, classes, counts, pgt_weight, pgt_score, Gmax, iou_thresh, bg_label,
+                     labels, matched, gt_boxes, gt_weights, gt_scores);
+  JTSM_CHECK_LAUNCH("match_label");
+  return JTSM_OK;
+}
+
+}  // extern "C"

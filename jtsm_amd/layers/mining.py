@@ -1,0 +1,64 @@
+"""Fused pseudo-GT mining / labelling (jtsm_amd/csrc/mining.hip): device-side replacements for the
+get_pgt_top_k + label_and_sample_proposals glue of JTSMROIHeads (no autograd: label generation)."""
+import torch
+
+from .. import _lib as L
+
+
+def pad_class_lists(class_lists, device):
+    """list of per-image int64 class-id tensors -> (classes (B,Gmax) int32, counts (B,) int32, Gmax)."""
+    gmax = max(1, max(int(c.numel()) for c in class_lists))
+    cls = torch.zeros((len(class_lists), gmax), dtype=torch.int32, device=device)
+    for i, c in enumerate(class_lists):
+        cls[i, : c.numel()] = c.to(torch.int32)
+    counts = torch.tensor([int(c.numel()) for c in class_lists], dtype=torch.int32).to(device, non_blocking=True)
+    return cls, counts, gmax
+
+
+@torch.no_grad()
+def row_lse(logits):
+    L.require_gpu(logits)
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    out = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+    L.check(L.lib().jtsm_row_lse_f32(L.ptr(logits), logits.stride(0), logits.shape[1], logits.shape[0], L.ptr(out),
+                                     L.stream()), "row_lse")
+    return out
+
+
+@torch.no_grad()
+def mine_top1(scores, proposals, bag_offsets, classes, counts, img_probs, lse=None, deltas=None):
+    """-> dict(idx (B,G) int32, boxes (B,G,4), scores (B,G), weights (B,G))."""
+    L.require_gpu(scores, proposals)
+    assert scores.stride(1) == 1 and (deltas is None or deltas.stride(1) == 1)
+    B, G = classes.shape
+    dev = scores.device
+    out = dict(idx=torch.zeros((B, G), dtype=torch.int32, device=dev),
+               boxes=torch.zeros((B, G, 4), dtype=torch.float32, device=dev),
+               scores=torch.zeros((B, G), dtype=torch.float32, device=dev),
+               weights=torch.zeros((B, G), dtype=torch.float32, device=dev))
+    proposals = proposals.contiguous()
+    img_probs = img_probs.contiguous()
+    L.check(L.lib().jtsm_mine_top1_f32(
+        L.ptr(scores), scores.stride(0), L.ptr(lse), L.ptr(proposals), L.ptr(deltas),
+        deltas.stride(0) if deltas is not None else 0, L.ptr(bag_offsets), L.ptr(classes), L.ptr(counts), B, G,
+        L.ptr(img_probs), img_probs.shape[1], L.ptr(out["idx"]), L.ptr(out["boxes"]), L.ptr(out["scores"]),
+        L.ptr(out["weights"]), L.stream()), "mine_top1")
+    return out
+
+
+@torch.no_grad()
+def match_label(proposals, bag_offsets, pgt, classes, counts, bg_label, iou_thresh=0.5):
+    """-> dict(labels (R,) int32, matched (R,) int32, boxes (R,4), weights (R,), scores (R,))."""
+    proposals = proposals.contiguous()
+    R, dev = proposals.shape[0], proposals.device
+    B, G = classes.shape
+    out = dict(labels=torch.empty(R, dtype=torch.int32, device=dev), matched=torch.empty(R, dtype=torch.int32, device=dev),
+               boxes=torch.empty((R, 4), dtype=torch.float32, device=dev),
+               weights=torch.empty(R, dtype=torch.float32, device=dev),
+               scores=torch.empty(R, dtype=torch.float32, device=dev))
+    L.check(L.lib().jtsm_match_label_f32(
+        L.ptr(proposals), L.ptr(bag_offsets), B, R, L.ptr(pgt["boxes"]), L.ptr(classes), L.ptr(counts),
+        L.ptr(pgt["weights"]), L.ptr(pgt["scores"]), G, L.f32(iou_thresh), int(bg_label), L.ptr(out["labels"]),
+        L.ptr(out["matched"]), L.ptr(out["boxes"]), L.ptr(out["weights"]), L.ptr(out["scores"]), L.stream()),
+        "match_label")
+    return out

@@ -23,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from ...layers.conv import linear_fused
+from ...layers.mining import match_label, mine_top1, pad_class_lists, row_lse
 from ...layers.roi_align import roi_align
 from ...layers.shape_spec import ShapeSpec
 from ...structures import Boxes, ImageList, Instances
@@ -130,18 +131,35 @@ class JTSMROIHeads(ROIHeads):
 
     @torch.no_grad()
     def get_pgt_sem_seg(self, prev_pred_boxes, prev_pred_scores, proposals, height, width):
+        """Reference-shaped entry (list-of-Instances mining, roi_heads_jtsm.py:2025-2070)."""
         targets = self.get_pgt_top_k(prev_pred_boxes, prev_pred_scores, proposals,
                                      self.num_classes + self.num_classes_stuff - 1, self.gt_classes_img_int_stuff)
-        out = torch.zeros(len(proposals), height, width, device=prev_pred_scores[0].device, dtype=torch.int64)
-        for i, t in enumerate(targets):
-            masks = eroded_rect_masks(t.gt_boxes.tensor, height, width) > 0.5
-            vals = t.gt_classes - self.num_classes + 1
-            order = torch.argsort(t.gt_scores, descending=False).tolist()
-            for j in order:                       # ascending score: the best box is painted last
-                out[i][masks[j]] = vals[j]
-            for j in range(vals.numel()):          # a class painted over completely is painted again
-                if not bool((out[i] == vals[j]).any()):
-                    out[i][masks[j]] = vals[j]
+        return self._paint_sem_seg([t.gt_boxes.tensor for t in targets], [t.gt_classes for t in targets],
+                                   [t.gt_scores for t in targets], height, width)
+
+    @torch.no_grad()
+    def _paint_sem_seg(self, boxes, classes, scores, height, width):
+        """Pseudo semantic target: every pseudo stuff box paints its (shrunk) rectangle with its class id,
+        in ascending score order so the best box ends on top; a class that got painted over completely is
+        painted once more (in class order).  Written without host synchronisation: "ascending order,
+        last write wins" is the per-pixel maximum of the boxes' score RANKS."""
+        out = torch.zeros(len(boxes), height, width, device=boxes[0].device, dtype=torch.int64)
+        for i, (bx, cl, sc) in enumerate(zip(boxes, classes, scores)):
+            n = bx.shape[0]
+            if n == 0:
+                continue
+            masks = eroded_rect_masks(bx, height, width) > 0.5                  # (n,H,W)
+            vals = cl.to(torch.int64) - self.num_classes + 1
+            order = torch.argsort(sc, descending=False)
+            rank = torch.empty_like(order)
+            rank[order] = torch.arange(n, device=order.device)
+            top = torch.where(masks, rank.view(n, 1, 1), rank.new_full((), -1)).max(dim=0).values
+            painted = vals[order[top.clamp(min=0)]]
+            img = torch.where(top >= 0, painted, painted.new_zeros(()))
+            for j in range(n):                                                  # sequential, but sync-free
+                missing = ~(img == vals[j]).any()
+                img = torch.where(missing & masks[j], vals[j], img)
+            out[i] = img
         return out
 
     # ------------------------------------------------------------------ forward
@@ -199,65 +217,71 @@ class JTSMROIHeads(ROIHeads):
         losses, scores, img_probs = self.box_predictor.score_and_loss(cls_logits, det_logits, offsets, labels_oh,
                                                                       max(counts))
         self.pred_class_img_logits = img_probs
-        prev_pred_scores = list(scores.split(counts, dim=0))
-        prev_pred_boxes = [p.proposal_boxes for p in proposals]
         self.aux = {"mil_scores": scores, "img_probs": img_probs, "pooled_argmax": argmax}
+        all_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals]).contiguous()
+        things_cls, things_cnt, _ = pad_class_lists(self.gt_classes_img_int, dev)
+        self._mining = (all_boxes, offsets, things_cls, things_cnt, counts)
+
+        # pseudo semantic target from the top-1 box of every present stuff class (MIL scores)
         if self.gt_classes_img_stuff:
+            stuff_cls, stuff_cnt, _ = pad_class_lists(self.gt_classes_img_int_stuff, dev)
+            pg = mine_top1(scores, all_boxes, offsets, stuff_cls, stuff_cnt, img_probs)
+            ns = [int(c.numel()) for c in self.gt_classes_img_int_stuff]
             h, w = self.images.tensor.shape[-2:]
-            self.pgt_sem_seg = self.get_pgt_sem_seg(prev_pred_boxes, prev_pred_scores, proposals, h, w)
+            self.pgt_sem_seg = self._paint_sem_seg([pg["boxes"][i, :n] for i, n in enumerate(ns)],
+                                                   [stuff_cls[i, :n] for i, n in enumerate(ns)],
+                                                   [pg["scores"][i, :n] for i, n in enumerate(ns)], h, w)
         else:
             self.pgt_sem_seg = None
 
-        all_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals])
+        # K refinement branches: labels of branch k come from branch k-1's predictions (k = 0: MIL scores,
+        # raw proposals).  Three launches per round (row lse, top-1 per class, IoU match).
         col = 2
+        prev_logits = prev_deltas = None
         for k, refinery in enumerate(self.box_refinery):
-            targets = self.get_pgt_top_k(prev_pred_boxes, prev_pred_scores, proposals, self.num_classes,
-                                         self.gt_classes_img_int)
-            proposals_k = self.label_and_sample_proposals(proposals, targets)
+            if k == 0:
+                pg = mine_top1(scores, all_boxes, offsets, things_cls, things_cnt, img_probs)
+            else:
+                pg = mine_top1(prev_logits, all_boxes, offsets, things_cls, things_cnt, img_probs,
+                               lse=row_lse(prev_logits), deltas=prev_deltas)
+            lab = match_label(all_boxes, offsets, pg, things_cls, things_cnt, self.num_classes)
             z = outs[col]
             d = outs[col + 1] if refinery.has_reg else None
             col += 2 if refinery.has_reg else 1
-            gt_classes = torch.cat([p.gt_classes for p in proposals_k])
-            gt_boxes = torch.cat([p.gt_boxes.tensor for p in proposals_k])
-            gt_weights = torch.cat([p.gt_weights for p in proposals_k])
-            losses.update(refinery.losses((z, d), all_boxes, gt_classes, gt_boxes, gt_weights))
-            with torch.no_grad():
-                prev_pred_scores = list(F.softmax(z.detach(), dim=-1).split(counts, dim=0))
-                if d is not None:
-                    prev_pred_boxes = list(refinery.box2box_transform.apply_deltas(d.detach(), all_boxes).split(counts))
-                else:
-                    prev_pred_boxes = [p.proposal_boxes.tensor.unsqueeze(1).expand(len(p), self.num_classes, 4)
-                                       for p in proposals]
-            self.aux["pgt_idx_r%d" % k] = [t.pgt_idx for t in targets]
-            self.aux["labels_r%d" % k] = gt_classes
-        self.prev_pred_boxes, self.prev_pred_scores = prev_pred_boxes, prev_pred_scores
+            losses.update(refinery.losses((z, d), all_boxes, lab["labels"], lab["boxes"], lab["weights"]))
+            prev_logits, prev_deltas = z.detach(), (d.detach() if d is not None else None)
+            self.aux["pgt_idx_r%d" % k] = [pg["idx"][i, :int(c.numel())].to(torch.int64)
+                                           for i, c in enumerate(self.gt_classes_img_int)]
+            self.aux["labels_r%d" % k] = lab["labels"].to(torch.int64)
+        self._last_branch = (prev_logits, prev_deltas)
         return losses
 
     def _forward_mask(self, features, instances):
-        targets = self.get_pgt_top_k(self.prev_pred_boxes, self.prev_pred_scores, instances, self.num_classes,
-                                     self.gt_classes_img_int)
-        instances = self.label_and_sample_proposals(instances, targets)
-        fg, _ = select_foreground_proposals(instances, self.num_classes)       # dynamic count: one host sync
+        all_boxes, offsets, things_cls, things_cnt, counts = self._mining
+        prev_logits, prev_deltas = self._last_branch
+        pg = mine_top1(prev_logits, all_boxes, offsets, things_cls, things_cnt, self.pred_class_img_logits,
+                       lse=row_lse(prev_logits), deltas=prev_deltas)
+        lab = match_label(all_boxes, offsets, pg, things_cls, things_cnt, self.num_classes)
         height, width = self.images.tensor.shape[-2:]
         feats = [features[f] for f in self.mask_in_features]
-        mask_features = self.mask_pooler(feats, [x.proposal_boxes for x in fg])
         with torch.no_grad():
-            gt_classes = torch.cat([x.gt_classes for x in fg]).to(torch.int64)
+            # the head trains on foreground proposals only: a data-dependent count -> the step's one sync
+            fg = torch.nonzero(lab["labels"] != self.num_classes)[:, 0]
+            gt_classes = lab["labels"][fg].to(torch.int64)
+            fg_boxes = all_boxes[fg]
+            img_of = torch.bucketize(fg, offsets[1:].to(torch.int64), right=True)          # image of each fg row
+            G = things_cls.shape[1]
             # targets: the matched pseudo-GT rectangle (eroded) cropped to the proposal at 28x28 with
             # ROIAlign(1.0, sampling 0, aligned) and thresholded at 0.5 (structures/masks.py:169-200)
-            rect, rois, base = [], [], 0
-            for t, x in zip(targets, fg):
-                rect.append(eroded_rect_masks(t.gt_boxes.tensor, height, width))
-                idx = (x.matched_gt_idx + base).to(torch.float32)
-                rois.append(torch.cat([idx[:, None], x.proposal_boxes.tensor], dim=1))
-                base += len(t)
-            rect = torch.cat(rect)[:, None].contiguous(memory_format=torch.channels_last)
-            rois = torch.cat(rois)
+            rect = eroded_rect_masks(pg["boxes"].reshape(-1, 4), height, width)
+            rect = rect[:, None].contiguous(memory_format=torch.channels_last)
+            gidx = (img_of * G + lab["matched"][fg].to(torch.int64)).to(torch.float32)
             side = 2 * self.mask_pooler.output_size[0]
-            gt_masks = roi_align(rect, rois, (side, side), 1.0, 0, True)[:, 0] >= 0.5
-        self.aux.update(fg_rois=torch.cat([torch.cat([torch.full((len(x), 1), float(i), device=rois.device),
-                                                      x.proposal_boxes.tensor], 1) for i, x in enumerate(fg)]),
-                        fg_classes=gt_classes)
+            gt_masks = roi_align(rect, torch.cat([gidx[:, None], fg_boxes], dim=1), (side, side), 1.0, 0, True)[:, 0] >= 0.5
+            per_image = torch.bincount(img_of, minlength=len(counts)).tolist()
+        fg_box_lists = [Boxes(b) for b in fg_boxes.split(per_image)]
+        mask_features = self.mask_pooler(feats, fg_box_lists)
+        self.aux.update(fg_rois=torch.cat([img_of.to(torch.float32)[:, None], fg_boxes], dim=1), fg_classes=gt_classes)
         pred_mask_logits, _ = self.mask_head.layers(mask_features)
         losses = {"loss_mask": mask_rcnn_loss(pred_mask_logits, gt_classes, gt_masks)}
         for k, head in enumerate(self.mask_refinery):

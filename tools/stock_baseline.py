@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""The "reference single-GPU images/sec" of BASELINE.md §2: the SAME composite model, inputs, optimizer and
+step as bench.py, but with every contraction, normalisation, resampling and loss routed through stock
+PyTorch-ROCm operators (F.conv2d / F.linear via MIOpen+hipBLASLt, F.group_norm, F.interpolate,
+F.cross_entropy, softmax/BCE), i.e. what the reference's Python does on a GPU.  The three region-pooling
+operators keep the HIP kernels: this image has no torchvision and the reference's own CUDA kernels
+cannot run here, so no stock implementation exists for them (they are ~2 % of the step).
+
+    python tools/stock_baseline.py [--steps 10 --warmup 3]
+
+Prints one JSON line.  Not part of the product or of bench.py's contract; used for the README table.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+CL = torch.channels_last
+
+
+def conv2d_stock(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False,
+                 bias_needs_grad=False):
+    y = F.conv2d(x, w, None, stride, pad, dil)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def linear_stock(x, w, bias=None, relu=False, bias_needs_grad=True):
+    y = F.linear(x, w, bias)
+    return F.relu(y) if relu else y
+
+
+def mil_stock(cls_logits, det_logits, bag_offsets, labels, mean_loss=True, max_bag_rows=None):
+    off = bag_offsets.tolist()
+    counts = [b - a for a, b in zip(off[:-1], off[1:])]
+    scores = torch.cat([F.softmax(c, 1) * F.softmax(d, 0)
+                        for c, d in zip(cls_logits.split(counts), det_logits.split(counts))])
+    probs = torch.cat([s.sum(0, keepdim=True) for s in scores.split(counts)]).clamp(1e-6, 1 - 1e-6)
+    loss = F.binary_cross_entropy(probs, labels, reduction="mean" if mean_loss else "sum")
+    return (loss if mean_loss else loss / len(counts)), scores.detach(), probs.detach()
+
+
+def oicr_stock(cls_logits, box_deltas, labels, weights, proposals=None, gt_boxes=None):
+    from jtsm_amd.modeling.box_regression import Box2BoxTransform
+    w = weights.clone()
+    w[labels == -1] = 0
+    ce = F.cross_entropy(cls_logits, labels.long(), reduction="none", ignore_index=-1)
+    loss_cls = (ce * w).sum() / (w > 1e-12).to(w.dtype).sum()
+    if box_deltas is None:
+        return loss_cls, loss_cls * 0
+    k = cls_logits.shape[1] - 1
+    fg = torch.nonzero((labels >= 0) & (labels < k))[:, 0]
+    cols = 4 * labels[fg].long()[:, None] + torch.arange(4, device=labels.device)
+    tgt = Box2BoxTransform((10.0, 10.0, 5.0, 5.0)).get_deltas(proposals, gt_boxes)
+    l1 = (box_deltas[fg[:, None], cols] - tgt[fg]).abs()
+    return loss_cls, (l1 * w[fg, None]).sum() / labels.numel()
+
+
+def patch_to_stock():
+    import jtsm_amd.layers.conv as conv
+    import jtsm_amd.layers.elementwise as ew
+    import jtsm_amd.layers.wrappers as wr
+    import jtsm_amd.layers.wsl_losses as wl
+    import jtsm_amd.modeling.backbone.fpn as fpn
+    import jtsm_amd.modeling.backbone.resnet as resnet
+    import jtsm_amd.modeling.roi_heads.fast_rcnn_oicr as oicr
+    import jtsm_amd.modeling.roi_heads.fast_rcnn_tsm as tsm
+    import jtsm_amd.modeling.roi_heads.roi_heads_jtsm as rh
+
+    conv.conv2d_fused = wr.conv2d_fused = conv2d_stock
+    conv.linear_fused = wr.linear_fused = rh.linear_fused = linear_stock
+    resnet.max_pool_3x3_s2 = lambda x: F.max_pool2d(x, 3, 2, 1)
+    fpn.upsample2_add = lambda top, lat: lat + F.interpolate(top, scale_factor=2.0, mode="nearest")
+    fpn.subsample2 = lambda x: F.max_pool2d(x, 1, 2, 0)
+    ew.group_norm_relu = lambda x, g, b, groups, eps=1e-5, relu=True: (
+        F.relu(F.group_norm(x, groups, g, b, eps)) if relu else F.group_norm(x, groups, g, b, eps))
+    ew.upsample_bilinear2x = lambda x: F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
+    ew.semseg_cross_entropy = lambda z, t, scale=4, ignore_index=255: F.cross_entropy(
+        F.interpolate(z, scale_factor=float(scale), mode="bilinear", align_corners=False), t, reduction="mean",
+        ignore_index=ignore_index)
+    wl.mil_loss = tsm.mil_loss = mil_stock
+    wl.oicr_loss = oicr.oicr_loss = oicr_stock
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    args = ap.parse_args()
+    patch_to_stock()
+    import bench
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+
+    dev = torch.device("cuda", 0)
+    model = bench.build(dev)
+    inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev)
+    opt = bench.make_optimizer(model)
+
+    def step():
+        losses = model(inputs)
+        total = sum(losses.values())
+        total.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return total
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"what": "stock PyTorch-ROCm operators, same model/step as bench.py (pooling ops: HIP kernels)",
+                      "value": round(2 * args.steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / args.steps, 3),
+                      "steps": args.steps, "final_loss": round(float(last.detach()), 5),
+                      "torch": torch.__version__}))
+
+
+if __name__ == "__main__":
+    main()
