@@ -76,3 +76,59 @@ def test_oicr_forward_backward(cuda, R, with_box):
     rel_close(zd.grad, z.grad, what="dz")
     if with_box:
         rel_close(dd.grad, d.grad, what="dd")
+
+
+def test_fused_mining_and_labelling_vs_oracle(cuda):
+    """mine_top1 + match_label (jtsm_amd/csrc/mining.hip) against oracle/model.py's per-image torch
+    restatement of get_pgt_top_k / label_and_sample_proposals: winning rows, labels and matched indices
+    bit-exact; decoded boxes to fp32 rounding.  Ragged bags, an image without any present class, both the
+    raw-proposal path (round 0) and the softmax + apply_deltas path (rounds k > 0)."""
+    from jtsm_amd.layers.mining import match_label, mine_top1, pad_class_lists, row_lse
+
+    g = torch.Generator().manual_seed(12)
+    counts = [300, 41, 7]
+    R, K = sum(counts), OM.NUM_THINGS
+    boxes = torch.rand(R, 4, generator=g) * 300
+    boxes[:, 2:] = boxes[:, :2] + 8 + torch.rand(R, 2, generator=g) * 150
+    things = [torch.tensor([3, 17, 60]), torch.tensor([5]), torch.zeros(0, dtype=torch.int64)]
+    probs = torch.rand(3, OM.NUM_MIL, generator=g)
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=cuda)
+    cls, cnt, _ = pad_class_lists([t.to(cuda) for t in things], cuda)
+
+    # round 0: scores given directly, boxes = proposals
+    sc = torch.rand(R, OM.NUM_MIL, generator=g)
+    pg = mine_top1(sc.to(cuda), boxes.to(cuda), off, cls, cnt, probs.to(cuda))
+    lab = match_label(boxes.to(cuda), off, pg, cls, cnt, K)
+    r0 = 0
+    for i, n in enumerate(counts):
+        b_i, s_i = boxes[r0:r0 + n], sc[r0:r0 + n]
+        if things[i].numel():
+            t = OM.mine_top1(b_i[:, None, :].expand(n, OM.NUM_MIL, 4), s_i, things[i], probs[i])
+            assert torch.equal(pg["idx"][i, :things[i].numel()].cpu().long(), t["idx"])
+            assert torch.equal(pg["boxes"][i, :things[i].numel()].cpu(), t["boxes"])
+            assert torch.equal(pg["weights"][i, :things[i].numel()].cpu(), t["weights"])
+            m = OM.match_and_label(b_i, t)
+            assert torch.equal(lab["labels"][r0:r0 + n].cpu().long(), m["classes"])
+            assert torch.equal(lab["matched"][r0:r0 + n].cpu().long(), m["idx"])
+            assert torch.equal(lab["boxes"][r0:r0 + n].cpu(), m["boxes"])
+            assert torch.equal(lab["weights"][r0:r0 + n].cpu(), m["weights"])
+        else:
+            assert (lab["labels"][r0:r0 + n] == K).all() and (lab["weights"][r0:r0 + n] == 0).all()
+        r0 += n
+
+    # rounds k > 0: softmax of logits + per-class decoded boxes, taken from a wider (fused) matrix
+    wide = torch.randn(R, (K + 1) + 4 * K + 5, generator=g)
+    z, d = wide[:, :K + 1], wide[:, K + 1:K + 1 + 4 * K] * 0.3
+    wd = wide.to(cuda)
+    zd, dd = wd[:, :K + 1], (wd[:, K + 1:K + 1 + 4 * K] * 0.3).contiguous()
+    pg = mine_top1(zd, boxes.to(cuda), off, cls, cnt, probs.to(cuda), lse=row_lse(zd), deltas=dd)
+    r0 = 0
+    for i, n in enumerate(counts):
+        if things[i].numel():
+            ps = torch.softmax(z[r0:r0 + n], dim=-1)
+            pb = OM.apply_deltas(d[r0:r0 + n], boxes[r0:r0 + n]).view(n, K, 4)
+            t = OM.mine_top1(pb, ps, things[i], probs[i])
+            assert torch.equal(pg["idx"][i, :things[i].numel()].cpu().long(), t["idx"])
+            assert torch.allclose(pg["boxes"][i, :things[i].numel()].cpu(), t["boxes"], rtol=1e-5, atol=1e-3)
+            assert torch.allclose(pg["scores"][i, :things[i].numel()].cpu(), t["scores"], rtol=1e-4, atol=1e-7)
+        r0 += n
