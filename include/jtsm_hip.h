@@ -315,8 +315,8 @@ int jtsm_upsample_bilinear2x_backward_f32(const float* gy, float* gx, int N, int
 
 /* Fused "bilinear xS up-sampling (align_corners=False) + cross_entropy(mean, ignore_index)" of
  * SemSegFPNHead.losses (detectron2/modeling/meta_arch/semantic_seg.py:179-188): the full-resolution
- * logits are never materialised.  logits: (N,Hs,Ws,ld) NHWC with C <= ld <= 64 classes (ld = channel
- * pitch, so a padded 56-wide map holding 54 classes is fine); target: (N,Hs*S,Ws*S) int64.
+ * logits are never materialised.  logits: (N,Hs,Ws,ld) NHWC, 16-byte aligned, with C <= ld <= 64 classes and
+ * ld % 4 == 0 (ld = channel pitch: a 56-wide map holding 54 classes); target: (N,Hs*S,Ws*S) int64.
  * out[0] = loss, out[1] = number of non-ignored pixels.  The workspace keeps one log-sum-exp per output
  * pixel for the backward, which gathers (no atomics) and writes dlogits (N,Hs,Ws,ld), pad lanes zero. */
 size_t jtsm_semseg_ce_workspace_bytes(int N, int Hs, int Ws, int S);

@@ -699,15 +699,30 @@ inline bool dma_eligible(int role, const Params& p) {
   return taps == 1 || c % BK == 0;
 }
 
-// Fold the split-K slabs in slice order (deterministic) and apply the fused epilogue.
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+// Fold the split-K slabs in slice order (deterministic) and apply the fused epilogue.  VEC = 4 when the
+// row length and leading dimension are multiples of 4 (every layer of the model), else 1.
+template <int VEC>
 __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits) {
-  const long total = (long)p.M * p.N;
+  const int nv = p.N / VEC;
+  const long total = (long)p.M * nv;
   const Epilogue& e = p.e;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % p.N);
-    const long m = i / p.N;
-    float v = 0.f;
-    for (int s = 0; s < splits; ++s) v += p.slab[((size_t)s * p.M + m) * p.ldc + n];
+    const int n = (int)(i % nv) * VEC;
+    const long m = i / nv;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+    for (int s = 0; s < splits; ++s) {
+      const float* src = p.slab + ((size_t)s * p.M + m) * p.ldc + n;
+      if (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(src);
+        v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+      } else {
+        v[0] += src[0];
+      }
+    }
     size_t o = (size_t)m * p.ldc + n;
     if (p.scatter) {
       const int ow = (int)(m % p.sc_Wo);
@@ -715,18 +730,23 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits)
       const int oh = (int)(t % p.sc_Ho), b = (int)(t / p.sc_Ho);
       o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
     }
-    v = v * (e.scale ? e.scale[n] : 1.f) + (e.bias ? e.bias[n] : 0.f);
-    if (e.residual) v += e.residual[o];
-    if (e.relu) v = fmaxf(v, 0.f);
-    if (e.mask) v = e.mask[o] > 0.f ? v : 0.f;
-    p.C[o] = v;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float x = v[j] * (e.scale ? e.scale[n + j] : 1.f) + (e.bias ? e.bias[n + j] : 0.f);
+      if (e.residual) x += e.residual[o + j];
+      if (e.relu) x = fmaxf(x, 0.f);
+      if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
+      v[j] = x;
+    }
+    if (VEC == 4) *reinterpret_cast<float4*>(p.C + o) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+    else p.C[o] = v[0];
   }
 }
 
 // How many K slices for an (ntiles, ktiles) problem: aim at >= 3 workgroups per CU, keep >= 4 K tiles
 // (128 k) per slice, at most 16 slices.
 inline int plan_splits(int ntiles, int ktiles) {
-  if (ntiles >= 512) return 1;
+  if (ntiles >= 512 || ntiles <= 0) return 1;  // ntiles == 0: an empty batch
   int s = ceil_div(768, ntiles);
   if (s > ktiles / 4) s = ktiles / 4;
   if (s > 16) s = 16;
@@ -755,9 +775,12 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
   else if (dma1) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm split-K");
-  const long total = (long)p.M * p.N;
+  const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
+                   (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
+  const long total = (long)p.M * (vec ? p.N / 4 : p.N);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  hipLaunchKernelGGL(splitk_finish, dim3(blocks), dim3(256), 0, st, p, splits);
+  if (vec) hipLaunchKernelGGL(splitk_finish<4>, dim3(blocks), dim3(256), 0, st, p, splits);
+  else hipLaunchKernelGGL(splitk_finish<1>, dim3(blocks), dim3(256), 0, st, p, splits);
   JTSM_CHECK_LAUNCH("splitk_finish");
   return JTSM_OK;
 }
@@ -793,8 +816,6 @@ ConvShape to_shape(const jtsm_conv_shape* s) {
   c.Wo = (s->in_w + 2 * s->pad - s->dilation * (s->kernel_w - 1) - 1) / s->stride + 1;
   return c;
 }
-
-bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 }  // namespace jtsm
@@ -851,12 +872,12 @@ int jtsm_conv_plan(const jtsm_conv_shape* s, int role, int has_kscale, int* kern
     if (sp > ceil_div(ktiles, 8)) sp = ceil_div(ktiles, 8);
     if (sp < 1) sp = 1;
     kps = ceil_div(ktiles, sp);
-    sp = ceil_div(ktiles, kps);
+    sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
   } else {
     if (p.N <= 64) { bm = 256; bn = 64; }
     sp = plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ktiles);
     kps = ceil_div(ktiles, sp);
-    sp = ceil_div(ktiles, kps);
+    sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
   }
   if (kernel) *kernel = !dma_eligible(role, p) ? 0 : (kps >= kDmaMinKTiles ? 1 : ((kShortSweepDma && role != WGRAD) ? 2 : 0));
   if (tile_m) *tile_m = bm;

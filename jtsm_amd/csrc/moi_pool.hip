@@ -241,8 +241,6 @@ __global__ __launch_bounds__(256) void moi_pool_bwd(const float* __restrict__ gr
                                                     const int* __restrict__ roi_level, int level) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
-    const int a = argmax[idx];
-    if (a == -1) continue;
     int c, n;
     if (NHWC) {
       c = (int)(idx % C);
@@ -251,7 +249,9 @@ __global__ __launch_bounds__(256) void moi_pool_bwd(const float* __restrict__ gr
       c = (int)((idx / PW / PH) % C);
       n = (int)(idx / PW / PH / C);
     }
-    if (roi_level && roi_level[n] != level) continue;
+    if (roi_level && roi_level[n] != level) continue;  // before touching argmax/grad: each level reads only its rois
+    const int a = argmax[idx];
+    if (a == -1) continue;
     const int b = (int)rois[(size_t)n * 5];
     float* dst = NHWC ? gin + ((size_t)b * H * W + a) * C + c : gin + ((size_t)b * C + c) * H * W + a;
     atomicAdd(dst, grad[idx]);

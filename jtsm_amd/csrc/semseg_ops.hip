@@ -292,6 +292,8 @@ __device__ __forceinline__ float interp_logit(const float* __restrict__ zn, int 
   return a.l0 * (b.l0 * v00 + b.l1 * v01) + a.l1 * (b.l0 * v10 + b.l1 * v11);   // ATen's association
 }
 
+// Forward: one THREAD per output pixel (neighbouring pixels share their four taps, so the tap loads of a
+// wave collapse onto a few cache lines); the <= 64 interpolated logits stay in registers.
 __global__ __launch_bounds__(256) void ce_up_fwd_kernel(const float* __restrict__ z, int ldc, int C,
                                                         const long* __restrict__ target, float* __restrict__ lse,
                                                         float* __restrict__ part, int N, int Hs, int Ws, int S,
@@ -301,78 +303,143 @@ __global__ __launch_bounds__(256) void ce_up_fwd_kernel(const float* __restrict_
   const int H = Hs * S, W = Ws * S;
   const long npix = (long)N * H * W;
   const float inv = 1.f / (float)S;
+  const int nch = ldc >> 2;   // float4 chunks per pixel row (ldc % 4 == 0, <= 16)
   float loss = 0.f, cnt = 0.f;
-  for (long p = (long)blockIdx.x * 4 + wv; p < npix; p += (long)gridDim.x * 4) {
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < npix; p += (long)gridDim.x * blockDim.x) {
     const long t = target[p];
     const int ow = (int)(p % W);
     const long q = p / W;
     const int oh = (int)(q % H), n = (int)(q / H);
     const LerpS a = lerp_scale(oh, Hs, inv), b = lerp_scale(ow, Ws, inv);
     const float* zn = z + (size_t)n * Hs * Ws * ldc;
-    const float v = lane < C ? interp_logit(zn, Ws, ldc, a, b, lane) : -3.0e38f;
-    const float mx = wmax(v);
-    const float sm = wsum(lane < C ? __expf(v - mx) : 0.f);
+    const float4* p00 = reinterpret_cast<const float4*>(zn + ((size_t)a.i0 * Ws + b.i0) * ldc);
+    const float4* p01 = reinterpret_cast<const float4*>(zn + ((size_t)a.i0 * Ws + b.i1) * ldc);
+    const float4* p10 = reinterpret_cast<const float4*>(zn + ((size_t)a.i1 * Ws + b.i0) * ldc);
+    const float4* p11 = reinterpret_cast<const float4*>(zn + ((size_t)a.i1 * Ws + b.i1) * ldc);
+    float v[64];
+    float mx = -3.0e38f, vt = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j < nch) {
+        const float4 v00 = p00[j], v01 = p01[j], v10 = p10[j], v11 = p11[j];
+        const float x00[4] = {v00.x, v00.y, v00.z, v00.w}, x01[4] = {v01.x, v01.y, v01.z, v01.w};
+        const float x10[4] = {v10.x, v10.y, v10.z, v10.w}, x11[4] = {v11.x, v11.y, v11.z, v11.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int c = 4 * j + e;
+          float x = a.l0 * (b.l0 * x00[e] + b.l1 * x01[e]) + a.l1 * (b.l0 * x10[e] + b.l1 * x11[e]);   // ATen's association
+          if (c >= C) x = -3.0e38f;
+          v[c] = x;
+          mx = fmaxf(mx, x);
+          vt = (long)c == t ? x : vt;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * j + e] = -3.0e38f;
+      }
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (j < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sm += __expf(v[4 * j + e] - mx);
+      }
     const float l = mx + __logf(sm);
-    if (lane == 0) lse[p] = l;
+    lse[p] = l;
     if (t != ignore) {
-      const float vt = __shfl(v, (int)t);
       loss += l - vt;
       cnt += 1.f;
     }
   }
+  loss = wsum(loss);
+  cnt = wsum(cnt);
   if (lane == 0) { red[wv][0] = loss; red[wv][1] = cnt; }
   __syncthreads();
   if (threadIdx.x < 2)
     part[blockIdx.x * 2 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// out[0] = mean loss over non-ignored pixels, out[1] = their count
-__global__ void ce_finish_kernel(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double l = 0.0, c = 0.0;
-    for (int b = 0; b < nblocks; ++b) { l += part[2 * b]; c += part[2 * b + 1]; }
-    out[0] = (float)(l / c);
-    out[1] = (float)c;
+// out[0] = mean loss over non-ignored pixels, out[1] = their count (fixed-order tree, deterministic)
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ part, int nblocks,
+                                                        float* __restrict__ out) {
+  __shared__ double sl[256], sc[256];
+  double l = 0.0, c = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) { l += part[2 * b]; c += part[2 * b + 1]; }
+  sl[threadIdx.x] = l; sc[threadIdx.x] = c;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = (float)(sl[0] / sc[0]);
+    out[1] = (float)sc[0];
   }
 }
 
 // dz[n,h,w,c] = up/count * sum over output pixels o touching (h,w) of weight(o -> (h,w)) * (softmax_o[c] - [c == t_o])
+// A gather (no atomics, deterministic): 16 lanes per source pixel, one float4 of channels per lane.  For one
+// output column the three source rows h-1, h, h+1 are interpolated along x once and reused by all of that
+// column's output rows.
 __global__ __launch_bounds__(256) void ce_up_bwd_kernel(const float* __restrict__ z, int ldc, int C,
                                                         const long* __restrict__ target,
                                                         const float* __restrict__ lse, const float* __restrict__ fin,
                                                         const float* __restrict__ upstream, float* __restrict__ dz,
                                                         int N, int Hs, int Ws, int S, long ignore) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = threadIdx.x & 15;
   const int H = Hs * S, W = Ws * S;
   const long nsrc = (long)N * Hs * Ws;
   const float inv = 1.f / (float)S;
   const float k = (upstream ? *upstream : 1.f) / fin[1];
-  for (long p = (long)blockIdx.x * 4 + wv; p < nsrc; p += (long)gridDim.x * 4) {
+  const bool live = 4 * j < ldc;
+  const int c0 = 4 * j;
+  for (long p = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; p < nsrc; p += ((long)gridDim.x * blockDim.x) >> 4) {
+    if (!live) continue;
     const int w = (int)(p % Ws);
     const long q = p / Ws;
     const int h = (int)(q % Hs), n = (int)(q / Hs);
-    const float* zn = z + (size_t)n * Hs * Ws * ldc;
-    float acc = 0.f;
-    const int oh0 = max(S * h - S, 0), oh1 = min(S * h + 2 * S, H);   // superset of the rows touching h
-    const int ow0 = max(S * w - S, 0), ow1 = min(S * w + 2 * S, W);
-    for (int oh = oh0; oh < oh1; ++oh) {
-      const LerpS a = lerp_scale(oh, Hs, inv);
-      const float wy = (a.i0 == h ? a.l0 : 0.f) + (a.i1 == h ? a.l1 : 0.f);
-      if (wy == 0.f) continue;
-      for (int ow = ow0; ow < ow1; ++ow) {
-        const LerpS b = lerp_scale(ow, Ws, inv);
-        const float wx = (b.i0 == w ? b.l0 : 0.f) + (b.i1 == w ? b.l1 : 0.f);
-        if (wx == 0.f) continue;
+    const float* zn = z + (size_t)n * Hs * Ws * ldc + c0;
+    const int hm = max(h - 1, 0), hp = min(h + 1, Hs - 1);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    // rows / columns of the output that can put weight on (h, w): exact for even S, one spare each side for odd S
+    const int oh0 = max(S * h - (S + 1) / 2, 0), oh1 = min(S * h + S + (S + 1) / 2, H);
+    const int ow0 = max(S * w - (S + 1) / 2, 0), ow1 = min(S * w + S + (S + 1) / 2, W);
+    for (int ow = ow0; ow < ow1; ++ow) {
+      const LerpS b = lerp_scale(ow, Ws, inv);
+      const float wx = (b.i0 == w ? b.l0 : 0.f) + (b.i1 == w ? b.l1 : 0.f);
+      if (wx == 0.f) continue;
+      float r[3][4];   // x-interpolated logits of source rows h-1, h, h+1 at this output column
+      const int rows[3] = {hm, h, hp};
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float4 u0 = *reinterpret_cast<const float4*>(zn + ((size_t)rows[i] * Ws + b.i0) * ldc);
+        const float4 u1 = *reinterpret_cast<const float4*>(zn + ((size_t)rows[i] * Ws + b.i1) * ldc);
+        r[i][0] = b.l0 * u0.x + b.l1 * u1.x; r[i][1] = b.l0 * u0.y + b.l1 * u1.y;
+        r[i][2] = b.l0 * u0.z + b.l1 * u1.z; r[i][3] = b.l0 * u0.w + b.l1 * u1.w;
+      }
+      for (int oh = oh0; oh < oh1; ++oh) {
+        const LerpS a = lerp_scale(oh, Hs, inv);
+        const float wy = (a.i0 == h ? a.l0 : 0.f) + (a.i1 == h ? a.l1 : 0.f);
+        if (wy == 0.f) continue;
         const long o = ((long)n * H + oh) * W + ow;
         const long t = target[o];
         if (t == ignore) continue;
-        if (lane < C) {
-          const float v = interp_logit(zn, Ws, ldc, a, b, lane);
-          acc += wy * wx * (__expf(v - lse[o]) - (lane == (int)t ? 1.f : 0.f));
+        const float l = lse[o], wgt = wy * wx;
+        const bool lo0 = a.i0 < h, hi0 = a.i0 > h, lo1 = a.i1 < h, hi1 = a.i1 > h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float t0 = lo0 ? r[0][e] : (hi0 ? r[2][e] : r[1][e]);
+          const float t1 = lo1 ? r[0][e] : (hi1 ? r[2][e] : r[1][e]);
+          const float v = a.l0 * t0 + a.l1 * t1;
+          const float pr = c0 + e < C ? __expf(v - l) : 0.f;
+          acc[e] += wgt * (pr - ((long)(c0 + e) == t ? 1.f : 0.f));
         }
       }
     }
-    if (lane < ldc) dz[(size_t)p * ldc + lane] = lane < C ? acc * k : 0.f;
+    *reinterpret_cast<float4*>(dz + (size_t)p * ldc + c0) =
+        make_float4(c0 + 0 < C ? acc[0] * k : 0.f, c0 + 1 < C ? acc[1] * k : 0.f, c0 + 2 < C ? acc[2] * k : 0.f,
+                    c0 + 3 < C ? acc[3] * k : 0.f);
   }
 }
 
@@ -478,20 +545,21 @@ size_t jtsm_semseg_ce_workspace_bytes(int N, int Hs, int Ws, int S) {
 
 int jtsm_semseg_ce_forward_f32(const float* logits, int ld, int C, const int64_t* target, float* out,
                                void* workspace, int N, int Hs, int Ws, int S, long ignore_index, void* stream) {
-  JTSM_REQUIRE(N >= 0 && Hs > 0 && Ws > 0 && S > 0 && C > 0 && C <= 64 && ld >= C && ld <= 64,
-               "semseg_ce: need C <= ld <= 64 (C=%d ld=%d)", C, ld);
+  JTSM_REQUIRE(N >= 0 && Hs > 0 && Ws > 0 && S > 0 && C > 0 && C <= 64 && ld >= C && ld <= 64 && ld % 4 == 0,
+               "semseg_ce: need C <= ld <= 64 and ld %% 4 == 0 (C=%d ld=%d)", C, ld);
   JTSM_REQUIRE(out, "semseg_ce: null out");
   if (N == 0) return JTSM_OK;
   JTSM_REQUIRE(logits && target && workspace, "semseg_ce: null pointer");
+  JTSM_REQUIRE(((uintptr_t)logits & 15) == 0, "semseg_ce: logits must be 16-byte aligned");
   hipStream_t st = as_stream(stream);
   float* lse = reinterpret_cast<float*>(workspace);
   float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) +
                                          a16((size_t)N * Hs * S * Ws * S * sizeof(float)));
   const long npix = (long)N * Hs * S * Ws * S;
-  int blocks = (int)((npix + 3) / 4 < CE_BLOCKS ? (npix + 3) / 4 : CE_BLOCKS);
+  int blocks = (int)((npix + 255) / 256 < CE_BLOCKS ? (npix + 255) / 256 : CE_BLOCKS);
   hipLaunchKernelGGL(ce_up_fwd_kernel, dim3(blocks), dim3(256), 0, st, logits, ld, C, (const long*)target, lse, part,
                      N, Hs, Ws, S, ignore_index);
-  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(64), 0, st, part, blocks, out);
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, st, part, blocks, out);
   JTSM_CHECK_LAUNCH("semseg_ce forward");
   return JTSM_OK;
 }
@@ -499,13 +567,15 @@ int jtsm_semseg_ce_forward_f32(const float* logits, int ld, int C, const int64_t
 int jtsm_semseg_ce_backward_f32(const float* logits, int ld, int C, const int64_t* target, const float* fwd_out,
                                 const float* upstream, float* dlogits, const void* workspace, int N, int Hs, int Ws,
                                 int S, long ignore_index, void* stream) {
-  JTSM_REQUIRE(N >= 0 && Hs > 0 && Ws > 0 && S > 0 && C > 0 && C <= 64 && ld >= C && ld <= 64,
-               "semseg_ce backward: need C <= ld <= 64");
+  JTSM_REQUIRE(N >= 0 && Hs > 0 && Ws > 0 && S > 0 && C > 0 && C <= 64 && ld >= C && ld <= 64 && ld % 4 == 0,
+               "semseg_ce backward: need C <= ld <= 64 and ld %% 4 == 0");
   if (N == 0) return JTSM_OK;
   JTSM_REQUIRE(logits && target && fwd_out && dlogits && workspace, "semseg_ce backward: null pointer");
+  JTSM_REQUIRE(((uintptr_t)logits & 15) == 0 && ((uintptr_t)dlogits & 15) == 0,
+               "semseg_ce backward: logits and dlogits must be 16-byte aligned");
   const float* lse = reinterpret_cast<const float*>(workspace);
   const long nsrc = (long)N * Hs * Ws;
-  int blocks = (int)((nsrc + 3) / 4 < 8192 ? (nsrc + 3) / 4 : 8192);
+  int blocks = (int)((nsrc + 15) / 16 < 16384 ? (nsrc + 15) / 16 : 16384);
   hipLaunchKernelGGL(ce_up_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), logits, ld, C,
                      (const long*)target, lse, fwd_out, upstream, dlogits, N, Hs, Ws, S, ignore_index);
   JTSM_CHECK_LAUNCH("semseg_ce backward");

@@ -197,6 +197,12 @@ class _SemSegCE(torch.autograd.Function):
         if not (logits.stride(1) == 1 and logits.stride(3) >= c and logits.stride(2) == ws * logits.stride(3)
                 and logits.stride(0) == hs * logits.stride(2)):
             logits = logits.contiguous(memory_format=CL)
+        if logits.stride(3) % 4 or logits.data_ptr() % 16:
+            # the kernels read float4 rows: re-pitch to a multiple of 4 channels (padding is never read as a class)
+            ld4 = (c + 3) // 4 * 4
+            padded = torch.zeros((n, hs, ws, ld4), dtype=logits.dtype, device=logits.device)
+            padded[..., :c] = logits.permute(0, 2, 3, 1)
+            logits = padded.permute(0, 3, 1, 2)[:, :c]
         ld = logits.stride(3)
         target = target.to(torch.int64).contiguous()
         if tuple(target.shape) != (n, hs * scale, ws * scale):

@@ -63,3 +63,31 @@ def test_product_never_imports_the_oracle():
                         or re.search(r'#include\s+".*oracle', txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_conv_planning_host_logic_handles_empty_and_odd_shapes():
+    """jtsm_conv_workspace_bytes / jtsm_conv_plan are pure host code: an empty batch (a rank with no
+    foreground roi) must plan to 'nothing', not divide by zero; a real layer plans a sane tile / split."""
+    import ctypes as C
+    from jtsm_amd import _lib
+    from jtsm_amd.layers.conv import ConvShape
+
+    lib = _lib.lib()
+    lib.jtsm_conv_workspace_bytes.restype = C.c_size_t
+    for kh, stride, pad in ((1, 1, 0), (3, 1, 1), (1, 2, 0), (2, 2, 0)):
+        s = ConvShape(0, 14, 14, 256, 256, kh, kh, stride, pad, 1)
+        for bwd in (0, 1):
+            assert lib.jtsm_conv_workspace_bytes(C.byref(s), bwd) == 0
+        for role in (0, 1, 2):
+            k, tm, tn, sp = C.c_int(-1), C.c_int(), C.c_int(), C.c_int()
+            assert lib.jtsm_conv_plan(C.byref(s), role, 0, C.byref(k), C.byref(tm), C.byref(tn), C.byref(sp)) == 0
+            assert sp.value == 1
+    # res5 3x3 at 2x(32x32): few output tiles -> split-K with a workspace of splits * M * N floats
+    s = ConvShape(2, 32, 32, 512, 512, 3, 3, 1, 1, 1)
+    k, tm, tn, sp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    assert lib.jtsm_conv_plan(C.byref(s), 0, 0, C.byref(k), C.byref(tm), C.byref(tn), C.byref(sp)) == 0
+    assert (tm.value, tn.value) == (128, 128) and 1 < sp.value <= 16
+    assert lib.jtsm_conv_workspace_bytes(C.byref(s), 0) == sp.value * 2048 * 512 * 4
+    bad = ConvShape(1, 8, 8, 3, 8, 1, 1, 1, 0, 1)  # in_c not a multiple of 4
+    assert lib.jtsm_conv_plan(C.byref(bad), 0, 0, None, None, None, None) != 0
+    assert b"in_c" in lib.jtsm_last_error()

@@ -272,3 +272,25 @@ def test_fused_upsample_cross_entropy_vs_torch_cpu(cuda):
         (loss * 0.7).backward()
         close(wd.grad[:, :c], zr.grad, "ce dlogits")
         assert wd.grad[:, c:].abs().max().item() == 0
+
+
+def test_empty_batch_through_conv_linear_and_mask_head(cuda):
+    """Zero rows (an image batch with no foreground roi) must flow through forward AND backward and leave
+    zero (not missing) gradients — DDP without find_unused_parameters relies on that."""
+    from jtsm_amd.layers.shape_spec import ShapeSpec
+    from jtsm_amd.modeling.roi_heads.mask_head import MaskRCNNConvUpsampleWSLHead, mask_rcnn_loss
+
+    head = MaskRCNNConvUpsampleWSLHead(ShapeSpec(channels=16, height=14, width=14), num_classes=5,
+                                       conv_dims=[16, 16, 16]).to(cuda)
+    x = torch.zeros(0, 16, 14, 14, device=cuda).contiguous(memory_format=CL)
+    logits, _ = head.layers(x)
+    assert logits.shape == (0, 5, 28, 28)
+    loss = mask_rcnn_loss(logits, torch.zeros(0, dtype=torch.int64, device=cuda),
+                          torch.zeros(0, 28, 28, dtype=torch.bool, device=cuda))
+    loss.backward()
+    for n, p in head.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().sum()) == 0.0, n
+    w = torch.randn(8, 12, device=cuda, requires_grad=True)
+    y = K.linear_fused(torch.zeros(0, 12, device=cuda), w, None, True, False)
+    y.sum().backward()
+    assert y.shape == (0, 8) and float(w.grad.abs().sum()) == 0.0
