@@ -192,12 +192,46 @@ int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
                                     const jtsm_conv_shape* s, const float* row_scale, int zero_dw,
                                     void* stream);
 
+/* Split-bf16 ("bf16x3") contractions: the same fp32-in / fp32-out convolution as above (same shapes,
+ * epilogue, workspace and split-K rules), computed on the bf16 matrix cores from operands that were split
+ * once into two bf16 planes, hi = bf16(x), lo = bf16(x - hi), as a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with
+ * fp32 accumulation (relative error per product ~2^-16; the reference is plain fp32 cuDNN/ATen conv,
+ * detectron2/layers/wrappers.py:62-83).  Planes are raw bf16 bit patterns (uint16_t), 16-byte aligned.
+ *   jtsm_split_bf16_f32             hi/lo[i] <- src[i], same layout (activations NHWC, weights OHWI)
+ *   jtsm_split_bf16_transposed_f32  w [out_c][taps][in_c] -> planes of [in_c][taps][out_c] (what the
+ *                                   data gradient contracts against)
+ *   jtsm_conv_bf16x3_eligible       1 when a shape can take this path in `role` (0 forward, 1 backward-
+ *                                   data; 2 see below): the contracted channel count is a multiple of 32, or the kernel
+ *                                   is 1x1 and it is a multiple of 8 */
+int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, void* stream);
+int jtsm_split_bf16_transposed_f32(const float* w, uint16_t* hi, uint16_t* lo, int out_c, int taps,
+                                   int in_c, void* stream);
+int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role);
+/* y_hi / y_lo (both or neither; needs out_c % 4 == 0): the planes of the finished output y, written by the
+ * epilogue for a following bf16x3 contraction — saves that layer's jtsm_split_bf16_f32 pass. */
+int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
+                               const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,
+                               const jtsm_conv_shape* s, const float* scale, const float* bias,
+                               const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                               void* stream);
+int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                     const uint16_t* wt_lo, float* dx, const jtsm_conv_shape* s,
+                                     const float* accumulate, const float* relu_mask, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+/* role 2 (backward-weight) is eligible when in_c and out_c are multiples of 8; dy / x planes as above. */
+int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
+                                       const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
+                                       const float* row_scale, int zero_dw, void* stream);
+
 
 /* ---------------------------------------------------------------------------
  * Bandwidth-bound helpers (no reference source: torch elementwise ops behind
  * F.relu_ / autograd, e.g. detectron2/modeling/backbone/resnet.py:196-210).
  * ------------------------------------------------------------------------- */
 /* g[i] = y[i] > 0 ? dy[i] : 0   (y = the ReLU's output). */
+/* g = dy where y > 0 else 0, and the bf16 hi / lo planes of g (n % 8 == 0) in the same pass. */
+int jtsm_relu_backward_split_f32(const float* dy, const float* y, float* g, uint16_t* g_hi, uint16_t* g_lo,
+                                 long n, void* stream);
 int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, void* stream);
 /* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);

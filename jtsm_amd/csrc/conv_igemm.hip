@@ -66,6 +66,9 @@ struct Params {
   // DGRAD of a strided 1x1 convolution runs as a dense GEMM over the OUTPUT pixels; row m of the result
   // is scattered to input pixel (b, oh*stride, ow*stride) of a zero-filled dX.
   int scatter, sc_Ho, sc_Wo, sc_H, sc_W, sc_stride;
+  int wide;   // epilogue through LDS with 16-byte accesses (set by the launcher when alignment allows)
+  unsigned short* out_hi;   // optional: bf16 hi / lo planes of the finished output, for a bf16x3 consumer
+  unsigned short* out_lo;
   ConvShape s;
   Epilogue e;
 };
@@ -244,6 +247,84 @@ __device__ __forceinline__ void store_tile(const Params& p, f32x16 (&acc)[2][2],
         }
       }
     }
+  }
+}
+
+// hi/lo bf16 planes of four finished outputs (what jtsm_split_bf16_f32 would produce from them).
+__device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short* lo, size_t o, const float4& v) {
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  bf16x4_t h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    h[e] = hh;
+    l[e] = (__bf16)(x[e] - (float)hh);
+  }
+  *reinterpret_cast<bf16x4_t*>(hi + o) = h;
+  *reinterpret_cast<bf16x4_t*>(lo + o) = l;
+}
+
+// The same epilogue with 16-byte global accesses: the workgroup's BM x BN accumulator tile is parked in LDS
+// (free once the K loop is over; BM*BN*4 = 64 KiB), then every thread streams float4 pieces of whole output
+// rows — 512 contiguous bytes per 32 lanes — through the scale / bias / residual / ReLU / gate chain.
+// Short-K layers (1x1 convolutions into wide outputs) are bound by exactly this traffic.
+// Needs N % 4 == 0, ldc % 4 == 0 and 16-byte aligned C / residual / mask / slab (checked by the launcher).
+template <int ROLE, int BM, int BN>
+__device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                                int lane, int tid, float* tile /* [BM][BN] in LDS */) {
+  static_assert(ROLE != WGRAD, "wide epilogue: forward / data-gradient tiles");
+  __syncthreads();   // every wave is done reading the last K stage
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        tile[row * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+      }
+  __syncthreads();
+  const Epilogue& e = p.e;
+  constexpr int CPR = BN / 4;                 // float4 pieces per tile row
+  constexpr int PIECES = BM * CPR / 256;      // per thread
+  const bool raw = gridDim.y > 1;             // split-K: raw partial into this slice's slab
+#pragma unroll 4
+  for (int it = 0; it < PIECES; ++it) {
+    const int c = tid + 256 * it;
+    const int row = c / CPR, col = (c % CPR) * 4;
+    const int m = m0 + row, n = n0 + col;
+    if (m >= p.M || n >= p.N) continue;
+    float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
+    if (raw) {
+      *reinterpret_cast<float4*>(p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n) = v;
+      continue;
+    }
+    size_t o = (size_t)m * p.ldc + n;
+    if (ROLE == DGRAD && p.scatter) {
+      const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
+      const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
+      o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
+    }
+    if (e.scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
+      v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+    }
+    if (e.bias) {
+      const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
+      v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+    }
+    if (e.residual) {
+      const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (e.mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
+      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(p.C + o) = v;
+    if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v);
   }
 }
 
@@ -738,8 +819,13 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits)
       if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
       v[j] = x;
     }
-    if (VEC == 4) *reinterpret_cast<float4*>(p.C + o) = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
-    else p.C[o] = v[0];
+    if (VEC == 4) {
+      const float4 out = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+      *reinterpret_cast<float4*>(p.C + o) = out;
+      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out);
+    } else {
+      p.C[o] = v[0];
+    }
   }
 }
 
@@ -751,6 +837,17 @@ inline int plan_splits(int ntiles, int ktiles) {
   if (s > ktiles / 4) s = ktiles / 4;
   if (s > 16) s = 16;
   return s < 1 ? 1 : s;
+}
+
+inline int finish_split(const Params& p, int splits, hipStream_t st) {
+  const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
+                   (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
+  const long total = (long)p.M * (vec ? p.N / 4 : p.N);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  if (vec) hipLaunchKernelGGL(splitk_finish<4>, dim3(blocks), dim3(256), 0, st, p, splits);
+  else hipLaunchKernelGGL(splitk_finish<1>, dim3(blocks), dim3(256), 0, st, p, splits);
+  JTSM_CHECK_LAUNCH("splitk_finish");
+  return JTSM_OK;
 }
 
 template <int ROLE, int BM, int BN>
@@ -775,15 +872,10 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
   else if (dma1) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm split-K");
-  const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
-                   (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
-  const long total = (long)p.M * (vec ? p.N / 4 : p.N);
-  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  if (vec) hipLaunchKernelGGL(splitk_finish<4>, dim3(blocks), dim3(256), 0, st, p, splits);
-  else hipLaunchKernelGGL(splitk_finish<1>, dim3(blocks), dim3(256), 0, st, p, splits);
-  JTSM_CHECK_LAUNCH("splitk_finish");
-  return JTSM_OK;
+  return finish_split(p, splits, st);
 }
+
+#include "conv_x3.h"
 
 template <int ROLE, int BM, int BN>
 int launch(const Params& p, int splits, hipStream_t st) {
@@ -970,6 +1062,145 @@ int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
   p.ktiles_per_split = ceil_div(ktiles, splits);
   splits = ceil_div(ktiles, p.ktiles_per_split);
   return launch<WGRAD, 128, 128>(p, splits, st);
+}
+
+/* ---- split-bf16 ("bf16x3") path ---- */
+int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, void* stream) {
+  JTSM_REQUIRE(n >= 0, "split_bf16: negative size");
+  if (n == 0) return JTSM_OK;
+  JTSM_REQUIRE(src && hi && lo, "split_bf16: null pointer");
+  JTSM_REQUIRE(aligned16(src) && aligned16(hi) && aligned16(lo), "split_bf16: pointers must be 16-byte aligned");
+  const long n8 = n >> 3;
+  const int blocks = (int)(n8 / 256 + 1 < 8192 ? n8 / 256 + 1 : 8192);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src,
+                     reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), n);
+  JTSM_CHECK_LAUNCH("split_bf16");
+  return JTSM_OK;
+}
+
+int jtsm_split_bf16_transposed_f32(const float* w, uint16_t* hi, uint16_t* lo, int out_c, int taps, int in_c,
+                                   void* stream) {
+  JTSM_REQUIRE(out_c >= 0 && taps > 0 && in_c >= 0 && taps <= 65535, "split_bf16_transposed: bad sizes");
+  if (out_c == 0 || in_c == 0) return JTSM_OK;
+  JTSM_REQUIRE(w && hi && lo, "split_bf16_transposed: null pointer");
+  hipLaunchKernelGGL(split_bf16_transposed_kernel, dim3(ceil_div(in_c, 32), ceil_div(out_c, 32), taps), dim3(256), 0,
+                     as_stream(stream), w, reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), out_c, taps,
+                     in_c);
+  JTSM_CHECK_LAUNCH("split_bf16_transposed");
+  return JTSM_OK;
+}
+
+int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role) {
+  if (!s || check_shape(s)) return 0;
+  const ConvShape c = to_shape(s);
+  if (c.Ho <= 0 || c.Wo <= 0) return 0;
+  return x3_eligible(role, c) ? 1 : 0;
+}
+
+int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
+                               const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,
+                               const jtsm_conv_shape* s, const float* scale, const float* bias,
+                               const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  Params p = {};
+  p.s = to_shape(s);
+  JTSM_REQUIRE(p.s.Ho > 0 && p.s.Wo > 0, "conv: kernel larger than padded input");
+  JTSM_REQUIRE(x3_eligible(FWD, p.s), "conv forward bf16x3: in_c=%d with a %dx%d kernel is not eligible "
+               "(see jtsm_conv_bf16x3_eligible)", p.s.Cin, p.s.KH, p.s.KW);
+  p.M = p.s.Bn * p.s.Ho * p.s.Wo;
+  p.N = p.s.Cout;
+  p.K = p.s.KH * p.s.KW * p.s.Cin;
+  if (p.M == 0) return JTSM_OK;
+  JTSM_REQUIRE(x_hi && x_lo && w_hi && w_lo && y, "conv forward bf16x3: null pointer");
+  JTSM_REQUIRE(aligned16(x_hi) && aligned16(x_lo) && aligned16(w_hi) && aligned16(w_lo),
+               "conv forward bf16x3: planes must be 16-byte aligned");
+  X3Planes q = {reinterpret_cast<const __bf16*>(x_hi), reinterpret_cast<const __bf16*>(x_lo),
+                reinterpret_cast<const __bf16*>(w_hi), reinterpret_cast<const __bf16*>(w_lo)};
+  p.C = y; p.ldc = p.N;
+  p.e.scale = scale; p.e.bias = bias; p.e.residual = residual; p.e.relu = relu;
+  JTSM_REQUIRE((y_hi == nullptr) == (y_lo == nullptr), "conv forward bf16x3: give both output planes or neither");
+  if (y_hi) {
+    JTSM_REQUIRE(p.N % 4 == 0 && aligned16(y) && aligned16(y_hi) && aligned16(y_lo) &&
+                 (!scale || aligned16(scale)) && (!bias || aligned16(bias)) && (!residual || aligned16(residual)),
+                 "conv forward bf16x3: output planes need out_c %% 4 == 0 and 16-byte aligned tensors");
+    p.out_hi = y_hi; p.out_lo = y_lo;
+  }
+  hipStream_t st = as_stream(stream);
+  if (!workspace) workspace_bytes = 0;
+  if (p.N <= 64) return launch_split_x3<FWD, 256, 64>(p, q, workspace, workspace_bytes, st);
+  return launch_split_x3<FWD, 128, 128>(p, q, workspace, workspace_bytes, st);
+}
+
+int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                     const uint16_t* wt_lo, float* dx, const jtsm_conv_shape* s,
+                                     const float* accumulate, const float* relu_mask, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  Params p = {};
+  p.s = to_shape(s);
+  JTSM_REQUIRE(p.s.Ho > 0 && p.s.Wo > 0, "conv: kernel larger than padded input");
+  JTSM_REQUIRE(x3_eligible(DGRAD, p.s), "conv backward-data bf16x3: out_c=%d with a %dx%d kernel is not eligible",
+               p.s.Cout, p.s.KH, p.s.KW);
+  p.M = p.s.Bn * p.s.H * p.s.W;
+  p.N = p.s.Cin;
+  p.K = p.s.KH * p.s.KW * p.s.Cout;
+  if (p.M == 0) return JTSM_OK;
+  JTSM_REQUIRE(dy_hi && dy_lo && wt_hi && wt_lo && dx, "conv backward-data bf16x3: null pointer");
+  JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(wt_hi) && aligned16(wt_lo),
+               "conv backward-data bf16x3: planes must be 16-byte aligned");
+  X3Planes q = {reinterpret_cast<const __bf16*>(dy_hi), reinterpret_cast<const __bf16*>(dy_lo),
+                reinterpret_cast<const __bf16*>(wt_hi), reinterpret_cast<const __bf16*>(wt_lo)};
+  p.C = dx; p.ldc = p.N;
+  p.e.residual = accumulate; p.e.mask = relu_mask;
+  hipStream_t st = as_stream(stream);
+  if (!workspace) workspace_bytes = 0;
+  if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask) {
+    JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
+    p.scatter = 1; p.sc_Ho = p.s.Ho; p.sc_Wo = p.s.Wo; p.sc_H = p.s.H; p.sc_W = p.s.W; p.sc_stride = p.s.stride;
+    p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;
+    p.M = p.s.Bn * p.s.Ho * p.s.Wo;
+  }
+  if (p.N <= 64) return launch_split_x3<DGRAD, 256, 64>(p, q, workspace, workspace_bytes, st);
+  return launch_split_x3<DGRAD, 128, 128>(p, q, workspace, workspace_bytes, st);
+}
+
+int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
+                                       const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
+                                       const float* row_scale, int zero_dw, void* stream) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  Params p = {};
+  p.s = to_shape(s);
+  JTSM_REQUIRE(p.s.Ho > 0 && p.s.Wo > 0, "conv: kernel larger than padded input");
+  JTSM_REQUIRE(x3_eligible(WGRAD, p.s), "conv backward-weight bf16x3: in_c=%d and out_c=%d must be multiples of 8",
+               p.s.Cin, p.s.Cout);
+  p.M = p.s.Cout;
+  p.N = p.s.KH * p.s.KW * p.s.Cin;
+  p.K = p.s.Bn * p.s.Ho * p.s.Wo;
+  JTSM_REQUIRE(dw, "conv backward-weight bf16x3: null dw");
+  hipStream_t st = as_stream(stream);
+  if (zero_dw) JTSM_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)p.M * p.N * sizeof(float), st));
+  if (p.K == 0) return JTSM_OK;
+  JTSM_REQUIRE(dy_hi && dy_lo && x_hi && x_lo, "conv backward-weight bf16x3: null pointer");
+  JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(x_hi) && aligned16(x_lo),
+               "conv backward-weight bf16x3: planes must be 16-byte aligned");
+  X3Planes q = {reinterpret_cast<const __bf16*>(dy_hi), reinterpret_cast<const __bf16*>(dy_lo),
+                reinterpret_cast<const __bf16*>(x_hi), reinterpret_cast<const __bf16*>(x_lo)};
+  p.C = dw; p.ldc = p.N;
+  p.e.scale = row_scale;
+  const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
+  const int ktiles = ceil_div(p.K, XBK);
+  int splits = ceil_div(kWgradTargetBlocks, ntiles);
+  if (splits > ceil_div(ktiles, 8)) splits = ceil_div(ktiles, 8);
+  if (splits < 1) splits = 1;
+  p.ktiles_per_split = ceil_div(ktiles, splits);
+  splits = ceil_div(ktiles, p.ktiles_per_split);
+  hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
+  JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
+  return JTSM_OK;
 }
 
 }  // extern "C"

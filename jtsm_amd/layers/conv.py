@@ -7,6 +7,7 @@ Conv2d -> FrozenBatchNorm2d -> (+shortcut) -> ReLU (detectron2/layers/wrappers.p
 batch_norm.py:45-66, modeling/backbone/resnet.py:195-211).
 """
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -19,6 +20,84 @@ CL = torch.channels_last
 # Optional per-launch timing (bench.py's roofline leg): when a list, every contraction launch appends
 # (kernel variant, algorithmic FLOPs, start event, stop event), recorded on the launch stream.
 LAUNCH_LOG = None
+
+
+# Contraction arithmetic: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 (three bf16 MFMA products per fp32
+# product, fp32 accumulate, ~2^-16 relative error per product) for every eligible forward / data-gradient
+# contraction.  See csrc/conv_x3.h.
+MATH = os.environ.get("JTSM_CONV_MATH", "bf16x3")
+
+
+def set_math(mode):
+    global MATH
+    if mode not in ("f32", "bf16x3"):
+        raise ValueError("conv math must be 'f32' or 'bf16x3', got %r" % (mode,))
+    MATH = mode
+
+
+def split_bf16(t):
+    """(hi, lo) bf16 planes (int16 bit patterns) of a float32 tensor, in its storage order."""
+    flat = t.permute(0, 2, 3, 1) if t.dim() == 4 else t
+    if not flat.is_contiguous():
+        raise RuntimeError("split_bf16: tensor must be channels_last (4-d) or contiguous")
+    hi = torch.empty(t.numel(), dtype=torch.int16, device=t.device)
+    lo = torch.empty(t.numel(), dtype=torch.int16, device=t.device)
+    L.check(L.lib().jtsm_split_bf16_f32(L.ptr(t), L.ptr(hi), L.ptr(lo), C.c_long(t.numel()), L.stream()),
+            "split_bf16")
+    return hi, lo
+
+
+def split_bf16_transposed(w):
+    """Planes of W^T [in][taps][out] of a channels_last (out, in, kh, kw) weight."""
+    o, i, kh, kw = w.shape
+    hi = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
+    lo = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
+    L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(hi), L.ptr(lo), o, kh * kw, i, L.stream()),
+            "split_bf16_transposed")
+    return hi, lo
+
+
+# bf16 planes already made this step, keyed by the tensor's memory: a conv epilogue or relu_backward that
+# emitted the planes of its output registers them here, and the next contraction that consumes the tensor
+# (forward input, weight-gradient input, shared block input of conv1 + shortcut + FPN lateral) finds them.
+# Entries hold the tensor (detached), so its memory cannot be recycled under a live key; the model clears
+# the cache at the start of every forward (planes_clear).
+_PLANES = {}
+_PLANES_MAX = 4096
+
+
+def planes_clear():
+    _PLANES.clear()
+
+
+def _pkey(t):
+    # planes mirror the flat memory of a DENSE tensor, so any dense view of the same bytes shares them
+    return (t.data_ptr(), t.numel())
+
+
+def planes_put(t, hi, lo):
+    if len(_PLANES) >= _PLANES_MAX:
+        _PLANES.clear()
+    _PLANES[_pkey(t)] = (t.detach(), t._version, hi, lo)
+
+
+def planes_of(t):
+    """Cached (hi, lo) planes of a tensor, splitting it now if nobody has."""
+    e = _PLANES.get(_pkey(t))
+    if e is not None and e[1] == t._version:
+        return e[2], e[3]
+    hi, lo = split_bf16(t)
+    planes_put(t, hi, lo)
+    return hi, lo
+
+
+def _x3(s, role):
+    return MATH == "bf16x3" and s.batch > 0 and bool(L.lib().jtsm_conv_bf16x3_eligible(C.byref(s), role))
+
+
+def _x3_variant(s, role):
+    n = s.out_c if role == 0 else s.in_c
+    return "igemm_x3_kernel<%s,%s,2>" % (_ROLE_NAME[role], "256,64" if n <= 64 else "128,128")
 
 
 def _timed(variant, flops, call, shape=None):
@@ -95,7 +174,8 @@ def _check(*ts):
             raise RuntimeError("jtsm_amd conv kernels are float32, got %s" % t.dtype)
 
 
-def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual=None, relu=False):
+def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual=None, relu=False,
+                   emit_planes=False):
     _check(x, w, scale, bias, residual)
     x, w = _cl(x), _cl(w)
     s = _shape(x.shape, w.shape, stride, pad, dil)
@@ -104,8 +184,22 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
     if residual is not None:
         residual = _cl(residual)
         assert residual.shape == y.shape
-    variant = _variant(s, 0)
     ws, nbytes = _workspace(s, 0, x.device)
+    if _x3(s, 0):
+        xh, xl = planes_of(x)
+        wh, wl = split_bf16(w)
+        yh = yl = None
+        if emit_planes and s.out_c % 8 == 0:
+            yh = torch.empty(y.numel(), dtype=torch.int16, device=y.device)
+            yl = torch.empty(y.numel(), dtype=torch.int16, device=y.device)
+        L.check(_timed(_x3_variant(s, 0), _flops(s), lambda: L.lib().jtsm_conv2d_forward_bf16x3(
+            L.ptr(xh), L.ptr(xl), L.ptr(wh), L.ptr(wl), L.ptr(y), L.ptr(yh), L.ptr(yl), C.byref(s), L.ptr(scale),
+            L.ptr(bias), L.ptr(residual), int(bool(relu)), L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)),
+                "conv2d_forward_bf16x3")
+        if yh is not None:
+            planes_put(y, yh, yl)
+        return y
+    variant = _variant(s, 0)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_forward_f32(
         L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
         L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_forward")
@@ -122,8 +216,15 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         accumulate = _cl(accumulate)
     if relu_mask is not None:
         relu_mask = _cl(relu_mask)
-    variant = _variant(s, 1, kscale is not None)
     ws, nbytes = _workspace(s, 1, dy.device)
+    if kscale is None and _x3(s, 1):
+        gh, gl = planes_of(dy)
+        wh, wl = split_bf16_transposed(w)
+        L.check(_timed(_x3_variant(s, 1), _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_bf16x3(
+            L.ptr(gh), L.ptr(gl), L.ptr(wh), L.ptr(wl), L.ptr(dx), C.byref(s), L.ptr(accumulate), L.ptr(relu_mask),
+            L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_data_bf16x3")
+        return dx
+    variant = _variant(s, 1, kscale is not None)
     L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s), L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
         L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_data")
@@ -137,6 +238,13 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
         out = torch.zeros(tuple(w_shape), dtype=x.dtype, device=x.device).contiguous(memory_format=CL)
+    if _x3(s, 2):
+        gh, gl = planes_of(dy)
+        xh, xl = planes_of(x)
+        L.check(_timed("igemm_x3_wgrad_kernel<2>", _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_bf16x3(
+            L.ptr(gh), L.ptr(gl), L.ptr(xh), L.ptr(xl), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero),
+            L.stream()), _desc(s)), "conv2d_backward_weight_bf16x3")
+        return out
     L.check(_timed(_variant(s, 2), _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
         L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream()), _desc(s)),
             "conv2d_backward_weight")
@@ -148,8 +256,8 @@ class _ConvFused(Function):
     (FrozenBN statistics or a conv bias treated by the caller), residual gets dy * relu'."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad):
-        y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu)
+    def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True):
+        y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
         ctx.cfg = (stride, pad, dil, relu, bias_needs_grad, tuple(x.shape), tuple(w.shape))
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, w, scale, y if relu else None)
@@ -162,7 +270,12 @@ class _ConvFused(Function):
 
         x, w, scale, y = ctx.saved_tensors
         stride, pad, dil, relu, bias_needs_grad, xs, ws = ctx.cfg
-        g = relu_backward(dy, y) if relu else _cl(dy)
+        x3 = MATH == "bf16x3" and dy.shape[0] > 0 and dy.shape[1] % 8 == 0 and \
+            (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        if relu:
+            g = relu_backward(dy, y, emit_planes=x3)   # one pass: gate, and the planes both gradients contract
+        else:
+            g = _cl(dy)
         dx = dw = db = dres = None
         # (Launching dw on a second HIP stream beside dx was measured on MI355X: 46.6 vs 45.6 ms per step —
         # slower; the contractions already hold the chip at its power-limited clock.  Kept in order.)
@@ -177,11 +290,11 @@ class _ConvFused(Function):
             db = channel_sum(g)
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = g
-        return dx, dw, None, db, dres, None, None, None, None, None
+        return dx, dw, None, db, dres, None, None, None, None, None, None
 
 
 def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False,
-                 bias_needs_grad=False):
+                 bias_needs_grad=False, emit_planes=True):
     """Autograd-aware fused convolution.  An output-channel count that is not a multiple of 4 (54 sem-seg
     classes, the 1870-wide fused predictor) is zero-padded up for the kernels' 16-byte rows and the
     padding is sliced off the result (its gradient is zero by construction)."""
@@ -195,9 +308,9 @@ def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, di
             bias = torch.cat([bias, bias.new_zeros(extra)])
         if residual is not None:
             residual = torch.nn.functional.pad(residual, (0, 0, 0, 0, 0, extra))
-        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad)
+        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, False)
         return y[:, :o]
-    return _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad)
+    return _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes)
 
 
 def linear_fused(x, w, bias=None, relu=False, bias_needs_grad=True):

@@ -15,12 +15,22 @@ def _dense_like(t, ref):
     return t.contiguous()
 
 
-def relu_backward(dy, y):
+def relu_backward(dy, y, emit_planes=False):
+    """g = dy * (y > 0).  emit_planes: also write g's bf16 hi/lo planes (registered for the bf16x3 gradients)."""
     L.require_gpu(dy, y)
     y = y if (y.is_contiguous() or (y.dim() == 4 and y.is_contiguous(memory_format=CL))) else y.contiguous()
     dy = _dense_like(dy, y)
     g = torch.empty_like(y)
-    L.check(L.lib().jtsm_relu_backward_f32(L.ptr(dy), L.ptr(y), L.ptr(g), C.c_long(y.numel()), L.stream()),
+    n = y.numel()
+    if emit_planes and n % 8 == 0 and n > 0:
+        from . import conv
+        hi = torch.empty(n, dtype=torch.int16, device=y.device)
+        lo = torch.empty(n, dtype=torch.int16, device=y.device)
+        L.check(L.lib().jtsm_relu_backward_split_f32(L.ptr(dy), L.ptr(y), L.ptr(g), L.ptr(hi), L.ptr(lo), C.c_long(n),
+                                                     L.stream()), "relu_backward_split")
+        conv.planes_put(g, hi, lo)
+        return g
+    L.check(L.lib().jtsm_relu_backward_f32(L.ptr(dy), L.ptr(y), L.ptr(g), C.c_long(n), L.stream()),
             "relu_backward")
     return g
 

@@ -14,6 +14,7 @@ from ..backbone import build_backbone
 from ..roi_heads import build_roi_heads
 from .build import META_ARCH_REGISTRY
 from .semantic_seg import build_sem_seg_head
+from ...layers.conv import planes_clear
 
 
 @META_ARCH_REGISTRY.register()
@@ -43,6 +44,7 @@ class GeneralizedMCNNWSL(nn.Module):
     def forward(self, batched_inputs):
         if not self.training:
             raise NotImplementedError("jtsm_amd implements the training step; inference is a 'next' row (§8f)")
+        planes_clear()   # bf16x3 operand planes are cached per step (layers/conv.py)
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         gt_sem_seg = ImageList.from_tensors([x["sem_seg"].to(self.device) for x in batched_inputs],

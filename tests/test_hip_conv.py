@@ -18,6 +18,18 @@ CL = torch.channels_last
 REL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def conv_math(request):
+    """Every case runs in both contraction arithmetics: exact fp32 MFMA, and split-bf16 (three bf16 MFMA
+    products per fp32 product, csrc/conv_x3.h) — the same 1e-4 bar for both."""
+    old = K.MATH
+    K.set_math(request.param)
+    K.planes_clear()
+    yield request.param
+    K.set_math(old)
+    K.planes_clear()
+
+
 def close(a, b, what=""):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
@@ -130,6 +142,10 @@ def test_linear_dan_shape_slice(cuda):
     b = torch.full((O,), 0.1, requires_grad=True)
     y0 = nnref.linear(x, w, b, True)
     dy = torch.randn(y0.shape, generator=g)
+    # an output within rounding of the ReLU kink may be gated differently by two correct implementations:
+    # send no gradient through such elements, so the comparison is about arithmetic, not about ties
+    dy[(y0.detach().abs() < 1e-3) & (y0.detach() != 0)] = 0
+    dy[(y0.detach() == 0) & ((x.detach() @ w.detach().t() + b.detach()).abs() < 1e-3)] = 0
     y0.backward(dy)
     xd = x.detach().to(cuda).requires_grad_(True)
     wd = w.detach().to(cuda).requires_grad_(True)

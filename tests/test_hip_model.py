@@ -11,6 +11,7 @@ from oracle import model as OM
 
 pytestmark = pytest.mark.gpu
 
+from jtsm_amd.layers import conv as K  # noqa: E402
 from jtsm_amd.modeling import build_model  # noqa: E402
 
 
@@ -21,8 +22,18 @@ def _rel(a, b, floor=1e-8):
     return (a - b).abs().max().item() / (b.abs().max().item() + floor)
 
 
-@pytest.fixture(scope="module")
-def step(cuda):
+@pytest.fixture(scope="module", params=["f32", "bf16x3"])
+def step(cuda, request):
+    """One training step in each contraction arithmetic: exact fp32 MFMA and split-bf16 (csrc/conv_x3.h)."""
+    old = K.MATH
+    K.set_math(request.param)
+    try:
+        yield _run_step() + (request.param,)
+    finally:
+        K.set_math(old)
+
+
+def _run_step():
     torch.manual_seed(0)
     params = OM.init_params(seed=3, random_bn=True, input_gain=1.0 / 64)
     # 8-px superpixels: every >=16-px box owns at least one (no all-zero rois -> no exact score ties)
@@ -44,13 +55,13 @@ def step(cuda):
 
 
 def test_trainable_set_matches(step):
-    params, names, _, _, model, _ = step
+    params, names, _, _, model, _, _ = step
     mine = sorted(n for n, p in model.named_parameters() if p.requires_grad)
     assert mine == sorted(names)
 
 
 def test_losses_match(step):
-    _, _, losses0, _, _, losses = step
+    _, _, losses0, _, _, losses, _ = step
     assert set(losses) == set(losses0)
     for k in sorted(losses0):
         a, b = float(losses[k]), float(losses0[k])
@@ -58,7 +69,7 @@ def test_losses_match(step):
 
 
 def test_integer_artefacts_bit_exact(step):
-    _, _, _, aux0, model, _ = step
+    _, _, _, aux0, model, _, _ = step
     aux = model.roi_heads.aux
     # argmax of a max-pool is decided by near-ties between feature cells; the two backbones differ in
     # fp32 summation order, so a few winners may flip (exactness on identical inputs: test_hip_pooling)
@@ -75,7 +86,7 @@ def test_integer_artefacts_bit_exact(step):
 
 
 def test_gradients_match(step):
-    params, names, _, _, model, _ = step
+    params, names, _, _, model, _, math = step
     got = dict(model.named_parameters())
     worst = {}
     for n in names:
@@ -84,6 +95,8 @@ def test_gradients_match(step):
         g0, g = params[n].grad, got[n].grad
         assert g is not None, n
         worst[n] = _rel(g, g0)
-    # a handful of flipped max-pool winners and atomic summation order bound this from below
-    bad = {k: v for k, v in worst.items() if v > 5e-3}
+    # a handful of flipped max-pool winners / ReLU gates and atomic summation order bound this from below; the
+    # split-bf16 contractions (~5e-6 per layer instead of ~3e-7) flip a few more of those discrete choices
+    lim = 5e-3 if math == "f32" else 1e-2
+    bad = {k: v for k, v in worst.items() if v > lim}
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
