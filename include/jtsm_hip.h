@@ -199,13 +199,14 @@ int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
  * detectron2/layers/wrappers.py:62-83).  Planes are raw bf16 bit patterns (uint16_t), 16-byte aligned.
  *   jtsm_split_bf16_f32             hi/lo[i] <- src[i], same layout (activations NHWC, weights OHWI)
  *   jtsm_split_bf16_transposed_f32  w [out_c][taps][in_c] -> planes of [in_c][taps][out_c] (what the
- *                                   data gradient contracts against)
+ *                                   data gradient contracts against); row_scale (nullable, [out_c])
+ *                                   multiplies row o first — the FrozenBN scale of the layer
  *   jtsm_conv_bf16x3_eligible       1 when a shape can take this path in `role` (0 forward, 1 backward-
  *                                   data; 2 see below): the contracted channel count is a multiple of 32, or the kernel
  *                                   is 1x1 and it is a multiple of 8 */
 int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, void* stream);
-int jtsm_split_bf16_transposed_f32(const float* w, uint16_t* hi, uint16_t* lo, int out_c, int taps,
-                                   int in_c, void* stream);
+int jtsm_split_bf16_transposed_f32(const float* w, const float* row_scale, uint16_t* hi, uint16_t* lo,
+                                   int out_c, int taps, int in_c, void* stream);
 int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role);
 /* y_hi / y_lo (both or neither; needs out_c % 4 == 0): the planes of the finished output y, written by the
  * epilogue for a following bf16x3 contraction — saves that layer's jtsm_split_bf16_f32 pass. */
@@ -218,10 +219,15 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
                                      const uint16_t* wt_lo, float* dx, const jtsm_conv_shape* s,
                                      const float* accumulate, const float* relu_mask, void* workspace,
                                      size_t workspace_bytes, void* stream);
-/* role 2 (backward-weight) is eligible when in_c and out_c are multiples of 8; dy / x planes as above. */
+/* role 2 (backward-weight) is eligible when in_c and out_c are multiples of 8; dy / x planes as above.
+ * Unlike the fp32 kernel this one is DETERMINISTIC: each pixel slice writes a partial tile into the
+ * workspace (jtsm_conv_bf16x3_wgrad_workspace_bytes, 16-byte aligned) and a fixed-order pass adds them;
+ * zero_dw == 0 adds the result to what dw holds. */
+size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s);
 int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
                                        const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
-                                       const float* row_scale, int zero_dw, void* stream);
+                                       const float* row_scale, int zero_dw, void* workspace,
+                                       size_t workspace_bytes, void* stream);
 
 
 /* ---------------------------------------------------------------------------

@@ -31,6 +31,8 @@
 // resnet.py:195-211, layers/batch_norm.py:45-66, layers/wrappers.py:62-83) in FWD, and
 // "sum the two gradient paths, then gate by the ReLU mask" in DGRAD.  WGRAD accumulates with
 // float atomics into a zero-filled dW (optionally scaled per output row).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace jtsm {
@@ -273,7 +275,6 @@ __device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short*
 template <int ROLE, int BM, int BN>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
                                                 int lane, int tid, float* tile /* [BM][BN] in LDS */) {
-  static_assert(ROLE != WGRAD, "wide epilogue: forward / data-gradient tiles");
   __syncthreads();   // every wave is done reading the last K stage
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -306,7 +307,9 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[2
       const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
       o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
     }
-    if (e.scale) {
+    if (ROLE == WGRAD) {
+      if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+    } else if (e.scale) {
       const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
       v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
     }
@@ -785,7 +788,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // Fold the split-K slabs in slice order (deterministic) and apply the fused epilogue.  VEC = 4 when the
 // row length and leading dimension are multiples of 4 (every layer of the model), else 1.
 template <int VEC>
-__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits) {
+__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
   const int nv = p.N / VEC;
   const long total = (long)p.M * nv;
   const Epilogue& e = p.e;
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits)
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float x = v[j] * (e.scale ? e.scale[n + j] : 1.f) + (e.bias ? e.bias[n + j] : 0.f);
+      float x = v[j] * (e.scale ? e.scale[scale_by_row ? m : n + j] : 1.f) + (e.bias ? e.bias[n + j] : 0.f);
       if (e.residual) x += e.residual[o + j];
       if (e.relu) x = fmaxf(x, 0.f);
       if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
@@ -839,13 +842,13 @@ inline int plan_splits(int ntiles, int ktiles) {
   return s < 1 ? 1 : s;
 }
 
-inline int finish_split(const Params& p, int splits, hipStream_t st) {
+inline int finish_split(const Params& p, int splits, hipStream_t st, int scale_by_row = 0) {
   const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
                    (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
   const long total = (long)p.M * (vec ? p.N / 4 : p.N);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-  if (vec) hipLaunchKernelGGL(splitk_finish<4>, dim3(blocks), dim3(256), 0, st, p, splits);
-  else hipLaunchKernelGGL(splitk_finish<1>, dim3(blocks), dim3(256), 0, st, p, splits);
+  if (vec) hipLaunchKernelGGL(splitk_finish<4>, dim3(blocks), dim3(256), 0, st, p, splits, scale_by_row);
+  else hipLaunchKernelGGL(splitk_finish<1>, dim3(blocks), dim3(256), 0, st, p, splits, scale_by_row);
   JTSM_CHECK_LAUNCH("splitk_finish");
   return JTSM_OK;
 }
@@ -1078,14 +1081,14 @@ int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, vo
   return JTSM_OK;
 }
 
-int jtsm_split_bf16_transposed_f32(const float* w, uint16_t* hi, uint16_t* lo, int out_c, int taps, int in_c,
-                                   void* stream) {
+int jtsm_split_bf16_transposed_f32(const float* w, const float* row_scale, uint16_t* hi, uint16_t* lo, int out_c,
+                                   int taps, int in_c, void* stream) {
   JTSM_REQUIRE(out_c >= 0 && taps > 0 && in_c >= 0 && taps <= 65535, "split_bf16_transposed: bad sizes");
   if (out_c == 0 || in_c == 0) return JTSM_OK;
   JTSM_REQUIRE(w && hi && lo, "split_bf16_transposed: null pointer");
   hipLaunchKernelGGL(split_bf16_transposed_kernel, dim3(ceil_div(in_c, 32), ceil_div(out_c, 32), taps), dim3(256), 0,
-                     as_stream(stream), w, reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), out_c, taps,
-                     in_c);
+                     as_stream(stream), w, row_scale, reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), out_c,
+                     taps, in_c);
   JTSM_CHECK_LAUNCH("split_bf16_transposed");
   return JTSM_OK;
 }
@@ -1167,9 +1170,34 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
   return launch_split_x3<DGRAD, 128, 128>(p, q, workspace, workspace_bytes, st);
 }
 
+static int x3_wgrad_splits(const Params& p) {
+  const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
+  const int ktiles = ceil_div(p.K, XBK);
+  // Pixel-axis split (measured on MI355X, scratch/wgrad_sweep.py): about one workgroup per CU with >= 16 stages
+  // each; only when that would leave > 64 stages per workgroup (large maps) go to three workgroups per CU.
+  int splits = ceil_div(256, ntiles);
+  if (ceil_div(ktiles, splits) > 64) splits = ceil_div(768, ntiles);
+  if (splits > ceil_div(ktiles, 16)) splits = ceil_div(ktiles, 16);
+  if (splits < 1) splits = 1;
+  const int kps = ceil_div(ktiles, splits);
+  return kps > 0 ? ceil_div(ktiles, kps) : 1;
+}
+
+size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s) {
+  if (!s || check_shape(s)) return 0;
+  Params p = {};
+  p.s = to_shape(s);
+  if (p.s.Ho <= 0 || p.s.Wo <= 0) return 0;
+  p.M = p.s.Cout; p.N = p.s.KH * p.s.KW * p.s.Cin; p.K = p.s.Bn * p.s.Ho * p.s.Wo;
+  if (p.K == 0) return 0;
+  const int splits = x3_wgrad_splits(p);
+  return splits > 1 ? (size_t)splits * p.M * p.N * sizeof(float) : 0;
+}
+
 int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
                                        const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
-                                       const float* row_scale, int zero_dw, void* stream) {
+                                       const float* row_scale, int zero_dw, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1180,10 +1208,12 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
   p.M = p.s.Cout;
   p.N = p.s.KH * p.s.KW * p.s.Cin;
   p.K = p.s.Bn * p.s.Ho * p.s.Wo;
-  JTSM_REQUIRE(dw, "conv backward-weight bf16x3: null dw");
+  JTSM_REQUIRE(dw && aligned16(dw), "conv backward-weight bf16x3: dw must be non-null and 16-byte aligned");
   hipStream_t st = as_stream(stream);
-  if (zero_dw) JTSM_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)p.M * p.N * sizeof(float), st));
-  if (p.K == 0) return JTSM_OK;
+  if (p.K == 0) {
+    if (zero_dw) JTSM_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)p.M * p.N * sizeof(float), st));
+    return JTSM_OK;
+  }
   JTSM_REQUIRE(dy_hi && dy_lo && x_hi && x_lo, "conv backward-weight bf16x3: null pointer");
   JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(x_hi) && aligned16(x_lo),
                "conv backward-weight bf16x3: planes must be 16-byte aligned");
@@ -1191,15 +1221,19 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
                 reinterpret_cast<const __bf16*>(x_hi), reinterpret_cast<const __bf16*>(x_lo)};
   p.C = dw; p.ldc = p.N;
   p.e.scale = row_scale;
+  if (!zero_dw) p.e.residual = dw;   // accumulate: dw = dw + result (the epilogue reads dw[o] before writing it)
+  // Deterministic: every pixel slice writes its partial tile to a slab, a fixed-order pass adds them.
+  int splits = x3_wgrad_splits(p);
+  const size_t need = (size_t)splits * p.M * p.N * sizeof(float);
+  JTSM_REQUIRE(splits <= 1 || (workspace && workspace_bytes >= need && aligned16(workspace)),
+               "conv backward-weight bf16x3: workspace of %zu bytes needed (jtsm_conv_bf16x3_wgrad_workspace_bytes)", need);
   const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
-  const int ktiles = ceil_div(p.K, XBK);
-  int splits = ceil_div(kWgradTargetBlocks, ntiles);
-  if (splits > ceil_div(ktiles, 8)) splits = ceil_div(ktiles, 8);
-  if (splits < 1) splits = 1;
-  p.ktiles_per_split = ceil_div(ktiles, splits);
-  splits = ceil_div(ktiles, p.ktiles_per_split);
+  p.ktiles_per_split = ceil_div(ceil_div(p.K, XBK), splits);
+  p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  p.wide = 1;   // N = taps * in_c is a multiple of 8, dw / slab 16-byte aligned
   hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
+  if (splits > 1) return finish_split(p, splits, st, 1);
   return JTSM_OK;
 }
 

@@ -225,9 +225,9 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_kernel(const Params p, 
   if (gridDim.y > 1) {
     kbeg = blockIdx.y * p.ktiles_per_split * XBK;
     kend = min(p.K, kbeg + p.ktiles_per_split * XBK);
-    if (kbeg >= kend) return;
+    if (kbeg >= kend && !p.wide) return;   // (slab path: an empty slice still writes its zero slab)
   }
-  const int ntile_k = (kend - kbeg + XBK - 1) / XBK;
+  const int ntile_k = kbeg < kend ? (kend - kbeg + XBK - 1) / XBK : 0;
 
   // ---- load addressing: load j of this wave fills rows 4T .. 4T+3 (T = 2*wave + j); this lane owns row
   // r = 4T + lane/16 and the chunk whose slot is lane%16
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_kernel(const Params p, 
       b_rd[t][r2] = 256 * row + 16 * (chb ^ swz) + 8 * (pl & 1);
     }
 
-  if (NBUF == 2) issue(kbeg, 0);
+  if (NBUF == 2 && ntile_k > 0) issue(kbeg, 0);
   for (int t = 0; t < ntile_k; ++t) {
     if (NBUF == 1) {
       __syncthreads();
@@ -326,7 +326,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_kernel(const Params p, 
         }
     }
   }
-  store_tile<WGRAD>(p, acc, m0, n0, wm, wn, lane);
+  if (p.wide)
+    store_tile_wide<WGRAD, BM, BN>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
+  else
+    store_tile<WGRAD>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- the splitting pre-passes ---------------------------------------------------------------------
@@ -359,15 +362,18 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
 }
 
 // W [Cout][taps][Cin] -> planes of W^T [Cin][taps][Cout] (the K-contiguous B operand of the data gradient).
-__global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float* __restrict__ w, __bf16* __restrict__ hi,
-                                                                    __bf16* __restrict__ lo, int Cout, int taps, int Cin) {
+// row_scale (optional, [Cout]) multiplies row co first: the FrozenBN scale folded into the data gradient.
+__global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float* __restrict__ w,
+                                                                    const float* __restrict__ row_scale,
+                                                                    __bf16* __restrict__ hi, __bf16* __restrict__ lo,
+                                                                    int Cout, int taps, int Cin) {
   __shared__ float tile[32][33];
   const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int co = co0 + r, ci = ci0 + tx;
-    tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * taps + tap) * Cin + ci] : 0.f;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((size_t)co * taps + tap) * Cin + ci] * (row_scale ? row_scale[co] : 1.f) : 0.f;
   }
   __syncthreads();
 #pragma unroll

@@ -47,12 +47,14 @@ def split_bf16(t):
     return hi, lo
 
 
-def split_bf16_transposed(w):
-    """Planes of W^T [in][taps][out] of a channels_last (out, in, kh, kw) weight."""
+def split_bf16_transposed(w, row_scale=None):
+    """Planes of W^T [in][taps][out] of a channels_last (out, in, kh, kw) weight, rows pre-multiplied by
+    row_scale[out] when given."""
     o, i, kh, kw = w.shape
     hi = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
     lo = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
-    L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(hi), L.ptr(lo), o, kh * kw, i, L.stream()),
+    L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(row_scale), L.ptr(hi), L.ptr(lo), o, kh * kw, i,
+                                                   L.stream()),
             "split_bf16_transposed")
     return hi, lo
 
@@ -217,9 +219,9 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     if relu_mask is not None:
         relu_mask = _cl(relu_mask)
     ws, nbytes = _workspace(s, 1, dy.device)
-    if kscale is None and _x3(s, 1):
+    if _x3(s, 1):
         gh, gl = planes_of(dy)
-        wh, wl = split_bf16_transposed(w)
+        wh, wl = split_bf16_transposed(w, kscale)   # the per-row scale rides along in the transposing split
         L.check(_timed(_x3_variant(s, 1), _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_bf16x3(
             L.ptr(gh), L.ptr(gl), L.ptr(wh), L.ptr(wl), L.ptr(dx), C.byref(s), L.ptr(accumulate), L.ptr(relu_mask),
             L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_data_bf16x3")
@@ -235,16 +237,21 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     _check(dy, x, row_scale)
     dy, x = _cl(dy), _cl(x)
     s = _shape(x.shape, w_shape, stride, pad, dil)
-    zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
-    if out is None:
-        out = torch.zeros(tuple(w_shape), dtype=x.dtype, device=x.device).contiguous(memory_format=CL)
     if _x3(s, 2):
         gh, gl = planes_of(dy)
         xh, xl = planes_of(x)
+        fresh = out is None
+        if fresh:   # deterministic slab kernel: writes every element, nothing to clear
+            out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL)
+        nbytes = L.lib().jtsm_conv_bf16x3_wgrad_workspace_bytes(C.byref(s))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
         L.check(_timed("igemm_x3_wgrad_kernel<2>", _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_bf16x3(
-            L.ptr(gh), L.ptr(gl), L.ptr(xh), L.ptr(xl), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero),
-            L.stream()), _desc(s)), "conv2d_backward_weight_bf16x3")
+            L.ptr(gh), L.ptr(gl), L.ptr(xh), L.ptr(xl), L.ptr(out), C.byref(s), L.ptr(row_scale), int(fresh),
+            L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_weight_bf16x3")
         return out
+    zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
+    if out is None:
+        out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL).zero_()
     L.check(_timed(_variant(s, 2), _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
         L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream()), _desc(s)),
             "conv2d_backward_weight")
@@ -282,8 +289,11 @@ class _ConvFused(Function):
         if ctx.needs_input_grad[0]:
             # fold the FrozenBN scale into the weight rows once (a few MB) so the data-gradient GEMM takes
             # the direct-to-LDS path, which cannot rescale operands on the fly
-            w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
-            dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
+            if MATH == "bf16x3":   # (ineligible shapes fall through to the fp32 kernel's own kscale path)
+                dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale)
+            else:
+                w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
+                dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
         if ctx.needs_input_grad[1]:
             dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale)
         if bias_needs_grad and ctx.needs_input_grad[3]:

@@ -58,7 +58,7 @@ class _AlignLevels(Function):
     def forward(ctx, rois, roi_level, res, sampling_ratio, aligned, scales, *feats):
         feats = [_feat(f) for f in feats]
         M, C = rois.shape[0], feats[0].shape[1]
-        out = torch.zeros((M, C, res, res), dtype=torch.float32, device=rois.device).contiguous(memory_format=CL)
+        out = torch.empty((M, C, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)  # every roi is on exactly one level, whose kernel writes all of its bins
         for lvl, (f, sc) in enumerate(zip(feats, scales)):
             B, _, H, W = f.shape
             L.check(L.lib().jtsm_roi_align_forward_level_f32(
@@ -94,8 +94,9 @@ class _MOILevels(Function):
         feats = [_feat(f) for f in feats]
         M, C = rois.shape[0], feats[0].shape[1]
         Lw = oh_labels.shape[1]
-        out = torch.zeros((M, C, res, res), dtype=torch.float32, device=rois.device).contiguous(memory_format=CL)
-        arg = torch.full((M, C, res, res), -1, dtype=torch.int32, device=rois.device).contiguous(memory_format=CL)
+        # every roi is on exactly one level, whose kernel writes all of its bins (values and argmax)
+        out = torch.empty((M, C, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)
+        arg = torch.empty((M, C, res, res), dtype=torch.int32, device=rois.device, memory_format=CL)
         lib = L.lib()
         for lvl, (f, sc) in enumerate(zip(feats, scales)):
             B, _, H, W = f.shape
