@@ -272,62 +272,71 @@ __device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short*
 // rows — 512 contiguous bytes per 32 lanes — through the scale / bias / residual / ReLU / gate chain.
 // Short-K layers (1x1 convolutions into wide outputs) are bound by exactly this traffic.
 // Needs N % 4 == 0, ldc % 4 == 0 and 16-byte aligned C / residual / mask / slab (checked by the launcher).
-template <int ROLE, int BM, int BN>
+template <int ROLE, int BM, int BN, int PASSES = 1>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
-                                                int lane, int tid, float* tile /* [BM][BN] in LDS */) {
-  __syncthreads();   // every wave is done reading the last K stage
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        tile[row * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
-      }
-  __syncthreads();
+                                                int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */) {
+  // PASSES > 1: the tile goes through a smaller LDS window in row bands of BM / PASSES (single-buffered kernels)
+  constexpr int ROWS = BM / PASSES;
+  static_assert(ROWS % 64 == 0, "a band holds whole 64-row wave tiles");
   const Epilogue& e = p.e;
   constexpr int CPR = BN / 4;                 // float4 pieces per tile row
-  constexpr int PIECES = BM * CPR / 256;      // per thread
+  constexpr int PIECES = ROWS * CPR / 256;    // per thread per band
   const bool raw = gridDim.y > 1;             // split-K: raw partial into this slice's slab
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    __syncthreads();   // every wave is done reading the last K stage / streaming the previous band
+    if ((wm * 64) / ROWS == pass) {
+      const int r0 = wm * 64 - pass * ROWS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = r0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            tile[row * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
 #pragma unroll 4
-  for (int it = 0; it < PIECES; ++it) {
-    const int c = tid + 256 * it;
-    const int row = c / CPR, col = (c % CPR) * 4;
-    const int m = m0 + row, n = n0 + col;
-    if (m >= p.M || n >= p.N) continue;
-    float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
-    if (raw) {
-      *reinterpret_cast<float4*>(p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n) = v;
-      continue;
+    for (int it = 0; it < PIECES; ++it) {
+      const int c = tid + 256 * it;
+      const int row = c / CPR, col = (c % CPR) * 4;
+      const int m = m0 + pass * ROWS + row, n = n0 + col;
+      if (m >= p.M || n >= p.N) continue;
+      float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
+      if (raw) {
+        *reinterpret_cast<float4*>(p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n) = v;
+        continue;
+      }
+      size_t o = (size_t)m * p.ldc + n;
+      if (ROLE == DGRAD && p.scatter) {
+        const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
+        const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
+        o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
+      }
+      if (ROLE == WGRAD) {
+        if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+      } else if (e.scale) {
+        const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
+        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+      }
+      if (e.bias) {
+        const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
+        v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+      }
+      if (e.residual) {
+        const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      if (e.mask) {
+        const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
+        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+      }
+      *reinterpret_cast<float4*>(p.C + o) = v;
+      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v);
     }
-    size_t o = (size_t)m * p.ldc + n;
-    if (ROLE == DGRAD && p.scatter) {
-      const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
-      const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
-      o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
-    }
-    if (ROLE == WGRAD) {
-      if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-    } else if (e.scale) {
-      const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
-      v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-    }
-    if (e.bias) {
-      const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
-      v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
-    }
-    if (e.residual) {
-      const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
-      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-    }
-    if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (e.mask) {
-      const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
-      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-    }
-    *reinterpret_cast<float4*>(p.C + o) = v;
-    if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v);
   }
 }
 
@@ -834,9 +843,9 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
 
 // How many K slices for an (ntiles, ktiles) problem: aim at >= 3 workgroups per CU, keep >= 4 K tiles
 // (128 k) per slice, at most 16 slices.
-inline int plan_splits(int ntiles, int ktiles) {
+inline int plan_splits(int ntiles, int ktiles, int target = 768) {
   if (ntiles >= 512 || ntiles <= 0) return 1;  // ntiles == 0: an empty batch
-  int s = ceil_div(768, ntiles);
+  int s = target >= 768 ? ceil_div(target, ntiles) : target / ntiles;   // (smaller targets: never exceed them)
   if (s > ktiles / 4) s = ktiles / 4;
   if (s > 16) s = 16;
   return s < 1 ? 1 : s;

@@ -18,7 +18,7 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int XBK = 32;   // k per stage
+constexpr int XBK = 32;   // k per stage (and the unit of split-K bookkeeping)
 
 struct X3Planes {
   const __bf16* A_hi; const __bf16* A_lo;
@@ -30,14 +30,19 @@ __device__ __forceinline__ void dma16b(const void* g, void* lds_uniform_base) {
                                    (__attribute__((address_space(3))) void*)lds_uniform_base, 16, 0, 0);
 }
 
-template <int ROLE, int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const Params p, const X3Planes q) {
+// SK = k per stage: 32 (64-byte rows per plane, 16 rows per load) or 64 (128-byte rows, 8 rows per load).
+template <int ROLE, int BM, int BN, int NBUF, int SK = 32>
+__global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64 ? 2 : 1)) void igemm_x3_kernel(const Params p, const X3Planes q) {
+  constexpr int RB = SK * 2;            // bytes per row per plane per stage
+  constexpr int RPI = 1024 / RB;        // rows per direct-to-LDS load
+  constexpr int CPW = RB / 16;          // 16-byte chunks per row
+  constexpr int SWS = SK == 32 ? 2 : 1, SWM = CPW - 1;   // slot = chunk ^ ((row >> SWS) & SWM)
   static_assert(ROLE == FWD || ROLE == DGRAD, "bf16x3: forward and data-gradient roles");
   constexpr int WN = BN / 64;
   static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
-  constexpr int A_PL = BM * 64, B_PL = BN * 64;          // bytes per plane per stage
+  constexpr int A_PL = BM * RB, B_PL = BN * RB;          // bytes per plane per stage
   constexpr int STAGE = 2 * A_PL + 2 * B_PL;
-  constexpr int A_INS = BM / 64, B_INS = BN / 64;        // 16-row loads per wavefront per plane per stage
+  constexpr int A_INS = BM / RPI / 4, B_INS = BN / RPI / 4;   // loads per wavefront per plane per stage
   __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
 
   const ConvShape& s = p.s;
@@ -56,10 +61,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const Params p, const 
 
   int kbeg = 0, kend = p.K;
   if (gridDim.y > 1) {
-    kbeg = blockIdx.y * p.ktiles_per_split * XBK;
+    kbeg = blockIdx.y * p.ktiles_per_split * XBK;   // (split bookkeeping stays in units of 32 k)
     kend = min(p.K, kbeg + p.ktiles_per_split * XBK);
   }
-  const int ntile_k = kbeg < kend ? (kend - kbeg + XBK - 1) / XBK : 0;
+  const int ntile_k = kbeg < kend ? (kend - kbeg + SK - 1) / SK : 0;
 
   // ---- addressing state: the tap and first channel of a stage are wave-uniform and advance incrementally
   const int Cdim = ROLE == FWD ? s.Cin : s.Cout;
@@ -70,62 +75,84 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const Params p, const 
     t_kh = tap / s.KW;
     t_kw = tap - t_kh * s.KW;
   }
+  // Per-row state: element offset of (row, tap (0,0), this lane's chunk) and one validity bit per kh and per
+  // kw (zero padding, rows past M) — so a stage costs one add, two shifts and a select per load instead of
+  // re-deriving ih / iw.  A strided data gradient (rare: stride inside a k > 1 kernel) keeps the general path.
+  const bool linear = ROLE == FWD || s.stride == 1;
   PixelRow arow[A_INS];
-  int a_chunk[A_INS];
+  int a_chunk[A_INS], a_base[A_INS];
+  unsigned a_mh[A_INS], a_mw[A_INS];
 #pragma unroll
   for (int j = 0; j < A_INS; ++j) {
-    const int r = (wave * A_INS + j) * 16 + (lane >> 2);
+    const int r = (wave * A_INS + j) * RPI + lane / CPW;
     arow[j] = ROLE == FWD ? fwd_pixel(s, m0 + r, p.M) : dgrad_pixel(s, m0 + r, p.M);
-    a_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
+    a_chunk[j] = 8 * ((lane % CPW) ^ ((r >> SWS) & SWM));
+    unsigned mh = 0, mw = 0;
+    if (ROLE == FWD) {
+      for (int kh = 0; kh < s.KH; ++kh) mh |= ((unsigned)(arow[j].h0 + kh * s.dil) < (unsigned)s.H ? 1u : 0u) << kh;
+      for (int kw = 0; kw < s.KW; ++kw) mw |= ((unsigned)(arow[j].w0 + kw * s.dil) < (unsigned)s.W ? 1u : 0u) << kw;
+      a_base[j] = ((arow[j].b * s.H + arow[j].h0) * s.W + arow[j].w0) * s.Cin + a_chunk[j];
+    } else {
+      for (int kh = 0; kh < s.KH; ++kh) mh |= ((unsigned)(arow[j].h0 - kh * s.dil) < (unsigned)s.Ho ? 1u : 0u) << kh;
+      for (int kw = 0; kw < s.KW; ++kw) mw |= ((unsigned)(arow[j].w0 - kw * s.dil) < (unsigned)s.Wo ? 1u : 0u) << kw;
+      a_base[j] = ((arow[j].b * s.Ho + arow[j].h0) * s.Wo + arow[j].w0) * s.Cout + a_chunk[j];
+    }
+    a_mh[j] = arow[j].ok ? mh : 0u;
+    a_mw[j] = mw;
   }
   int b_off[B_INS], b_chunk[B_INS];
 #pragma unroll
   for (int j = 0; j < B_INS; ++j) {
-    const int r = (wave * B_INS + j) * 16 + (lane >> 2);
+    const int r = (wave * B_INS + j) * RPI + lane / CPW;
     b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
-    b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
+    b_chunk[j] = 8 * ((lane % CPW) ^ ((r >> SWS) & SWM));
   }
+  const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;   // the lo plane sits at a fixed distance
 
-  auto issue = [&](int k0, int buf) {
+  // One direct-to-LDS load ("piece") of the next stage: pieces 0 .. 2*A_INS-1 are the A rows (hi, lo
+  // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups: a
+  // load costs the issuing wave 60-180 cycles (MI355X_MICROARCH.md, cycle constants), which eight loads
+  // in a row would take out of the matrix pipe's time, while one load per three MFMAs hides in their shadow.
+  constexpr int PIECES = 2 * A_INS + 2 * B_INS;
+  auto issue_piece = [&](int idx, int k0, int buf) {
     char* St = lds + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < A_INS; ++j) {
-      const PixelRow& r = arow[j];
-      bool ok = r.ok && (k0 + a_chunk[j]) < kend;
+    if (idx < 2 * A_INS) {
+      const int j = idx >> 1, lo = idx & 1;
+      bool ok;
       int off;
-      if (ROLE == FWD) {
-        const int ih = r.h0 + t_kh * s.dil, iw = r.w0 + t_kw * s.dil;
-        ok = ok && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-        off = ((r.b * s.H + ih) * s.W + iw) * s.Cin + t_c + a_chunk[j];
+      if (linear) {
+        const int tap_delta = ROLE == FWD ? ((t_kh * s.dil) * s.W + t_kw * s.dil) * s.Cin + t_c
+                                          : -((t_kh * s.dil) * s.Wo + t_kw * s.dil) * s.Cout + t_c;
+        ok = ((a_mh[j] >> t_kh) & (a_mw[j] >> t_kw) & 1u) != 0u && (k0 + a_chunk[j]) < kend;
+        off = a_base[j] + tap_delta;
       } else {
+        const PixelRow& r = arow[j];
         const int th = r.h0 - t_kh * s.dil, tw = r.w0 - t_kw * s.dil;
-        int oh = th, ow = tw;
-        ok = ok && th >= 0 && tw >= 0;
-        if (s.stride != 1) {
-          oh = th / s.stride;
-          ow = tw / s.stride;
-          ok = ok && oh * s.stride == th && ow * s.stride == tw;
-        }
-        ok = ok && oh < s.Ho && ow < s.Wo;
+        const int oh = th / s.stride, ow = tw / s.stride;
+        ok = r.ok && (k0 + a_chunk[j]) < kend && th >= 0 && tw >= 0 && oh * s.stride == th && ow * s.stride == tw &&
+             oh < s.Ho && ow < s.Wo;
         off = ((r.b * s.Ho + oh) * s.Wo + ow) * s.Cout + t_c + a_chunk[j];
       }
-      const int dst = (wave * A_INS + j) * 1024;
-      dma16b(ok ? (const void*)(q.A_hi + off) : (const void*)g_zero_page, St + dst);
-      dma16b(ok ? (const void*)(q.A_lo + off) : (const void*)g_zero_page, St + A_PL + dst);
-    }
-#pragma unroll
-    for (int j = 0; j < B_INS; ++j) {
+      const __bf16* src = q.A_hi + off + (lo ? lo_delta_a : 0);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + lo * A_PL + (wave * A_INS + j) * 1024);
+    } else {
+      const int j = (idx - 2 * A_INS) >> 1, lo = (idx - 2 * A_INS) & 1;
       const bool ok = b_off[j] >= 0 && (k0 + b_chunk[j]) < kend;
-      const int off = b_off[j] + k0 + b_chunk[j];
-      const int dst = 2 * A_PL + (wave * B_INS + j) * 1024;
-      dma16b(ok ? (const void*)(q.B_hi + off) : (const void*)g_zero_page, St + dst);
-      dma16b(ok ? (const void*)(q.B_lo + off) : (const void*)g_zero_page, St + B_PL + dst);
+      const __bf16* src = q.B_hi + (b_off[j] + k0 + b_chunk[j]) + (lo ? lo_delta_b : 0);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + 2 * A_PL + lo * B_PL + (wave * B_INS + j) * 1024);
     }
-    t_c += XBK;   // next stage: same tap or the next one (stages never straddle taps)
+  };
+  auto advance_tap = [&]() {   // next stage: same tap or the next one (stages never straddle taps)
+    t_c += SK;
     if (t_c >= Cdim) {
       t_c -= Cdim;
       if (++t_kw == s.KW) { t_kw = 0; ++t_kh; }
     }
+  };
+  auto issue = [&](int k0, int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) issue_piece(i, k0, buf);
+    advance_tap();
   };
 
   f32x16 acc[2][2];
@@ -140,24 +167,28 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const Params p, const 
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int ar = wm * 64 + t * 32 + li, br = wn * 64 + t * 32 + li;
-    a_off[t] = ar * 64;
-    a_swz[t] = (ar >> 2) & 3;
-    bb_off[t] = 2 * A_PL + br * 64;
-    b_swz[t] = (br >> 2) & 3;
+    a_off[t] = ar * RB;
+    a_swz[t] = (ar >> SWS) & SWM;
+    bb_off[t] = 2 * A_PL + br * RB;
+    b_swz[t] = (br >> SWS) & SWM;
   }
 
+  constexpr int KSTEPS = SK / 16;
+  constexpr int SLOTS = 4 * KSTEPS;                         // MFMA groups per stage (k-steps x 2 x 2 tiles)
+  constexpr int PER_SLOT = (PIECES + SLOTS - 1) / SLOTS;    // loads placed behind each group
   if (NBUF == 2 && ntile_k > 0) issue(kbeg, 0);
   for (int t = 0; t < ntile_k; ++t) {
     if (NBUF == 1) {
       __syncthreads();
-      issue(kbeg + t * XBK, 0);
+      issue(kbeg + t * SK, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NBUF == 2 && t + 1 < ntile_k) issue(kbeg + (t + 1) * XBK, (t + 1) & 1);
+    const bool more = NBUF == 2 && t + 1 < ntile_k;   // wave-uniform
+    const int knext = kbeg + (t + 1) * SK, bnext = (t + 1) & 1;
     const char* St = lds + (NBUF == 2 ? (t & 1) : 0) * STAGE;
 #pragma unroll
-    for (int st = 0; st < 2; ++st) {
+    for (int st = 0; st < KSTEPS; ++st) {
       const int c = 2 * st + half;
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
@@ -176,11 +207,23 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_kernel(const Params p, const 
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          if (NBUF == 2) {
+            const int slot = st * 4 + i * 2 + j;
+            if (more) {
+#pragma unroll
+              for (int e = 0; e < PER_SLOT; ++e)
+                if (slot * PER_SLOT + e < PIECES) issue_piece(slot * PER_SLOT + e, knext, bnext);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the load behind this MFMA group
+          }
         }
     }
+    if (more) advance_tap();
   }
-  if (NBUF * STAGE >= BM * BN * 4 && p.wide)
-    store_tile_wide<ROLE, BM, BN>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
+  constexpr int PASSES = NBUF * STAGE >= BM * BN * 4 ? 1 : 2;
+  static_assert(NBUF * STAGE >= BM * BN * 4 / PASSES, "epilogue window does not fit the stage buffers");
+  if (p.wide)
+    store_tile_wide<ROLE, BM, BN, PASSES>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
   else
     store_tile<ROLE>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -398,7 +441,8 @@ template <int ROLE, int BM, int BN>
 int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const int ntiles = ceil_div(p.N, BN) * ceil_div(p.M, BM);
   const int ktiles = ceil_div(p.K, XBK);
-  int splits = plan_splits(ntiles, ktiles);
+  // Two 64-KiB workgroups fit a CU: aim at one full round of 512 (measured: scratch/x3_sweep.py).
+  int splits = plan_splits(ntiles, ktiles, 512);
   if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
   if (splits > 1) {
     p.ktiles_per_split = ceil_div(ktiles, splits);
@@ -409,7 +453,13 @@ int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t worksp
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
-  hipLaunchKernelGGL((igemm_x3_kernel<ROLE, BM, BN, 2>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
+  // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
+  // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
+  // (SK = 64 — 128-byte rows, one workgroup per CU — measured 15-25 % slower on every large layer; not dispatched)
+  if (ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
+  else
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, BM, BN, 2>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3");
   if (splits > 1) return finish_split(p, splits, st);
   return JTSM_OK;

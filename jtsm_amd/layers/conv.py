@@ -35,28 +35,51 @@ def set_math(mode):
     MATH = mode
 
 
-def split_bf16(t):
-    """(hi, lo) bf16 planes (int16 bit patterns) of a float32 tensor, in its storage order."""
+def _planes_buf(n, device):
+    n8 = (n + 7) // 8 * 8
+    return torch.empty(2 * n8, dtype=torch.int16, device=device)   # hi plane, then lo plane (16-byte aligned)
+
+
+def _hl(buf):
+    """(hi, lo) device pointers of a planes buffer."""
+    if buf is None:
+        return None, None
+    p = buf.data_ptr()
+    return C.c_void_p(p), C.c_void_p(p + buf.numel())   # lo starts numel/2 int16 = numel bytes in
+
+
+def _split(t):
     flat = t.permute(0, 2, 3, 1) if t.dim() == 4 else t
     if not flat.is_contiguous():
         raise RuntimeError("split_bf16: tensor must be channels_last (4-d) or contiguous")
-    hi = torch.empty(t.numel(), dtype=torch.int16, device=t.device)
-    lo = torch.empty(t.numel(), dtype=torch.int16, device=t.device)
-    L.check(L.lib().jtsm_split_bf16_f32(L.ptr(t), L.ptr(hi), L.ptr(lo), C.c_long(t.numel()), L.stream()),
-            "split_bf16")
-    return hi, lo
+    buf = _planes_buf(t.numel(), t.device)
+    hi, lo = _hl(buf)
+    L.check(L.lib().jtsm_split_bf16_f32(L.ptr(t), hi, lo, C.c_long(t.numel()), L.stream()), "split_bf16")
+    return buf
+
+
+def split_bf16(t):
+    """(hi, lo) bf16 planes (int16 bit patterns) of a float32 tensor, in its storage order."""
+    buf = _split(t)
+    n8 = buf.numel() // 2
+    return buf[:t.numel()], buf[n8:n8 + t.numel()]
+
+
+def _split_transposed(w, row_scale=None):
+    o, i, kh, kw = w.shape
+    buf = _planes_buf(w.numel(), w.device)
+    hi, lo = _hl(buf)
+    L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(row_scale), hi, lo, o, kh * kw, i, L.stream()),
+            "split_bf16_transposed")
+    return buf
 
 
 def split_bf16_transposed(w, row_scale=None):
     """Planes of W^T [in][taps][out] of a channels_last (out, in, kh, kw) weight, rows pre-multiplied by
     row_scale[out] when given."""
-    o, i, kh, kw = w.shape
-    hi = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
-    lo = torch.empty(w.numel(), dtype=torch.int16, device=w.device)
-    L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(row_scale), L.ptr(hi), L.ptr(lo), o, kh * kw, i,
-                                                   L.stream()),
-            "split_bf16_transposed")
-    return hi, lo
+    buf = _split_transposed(w, row_scale)
+    n8 = buf.numel() // 2
+    return buf[:w.numel()], buf[n8:n8 + w.numel()]
 
 
 # bf16 planes already made this step, keyed by the tensor's memory: a conv epilogue or relu_backward that
@@ -72,29 +95,61 @@ def planes_clear():
     _PLANES.clear()
 
 
-def _pkey(t):
-    # planes mirror the flat memory of a DENSE tensor, so any dense view of the same bytes shares them
-    return (t.data_ptr(), t.numel())
-
-
-def planes_put(t, hi, lo):
+def planes_put(t, buf):
     if len(_PLANES) >= _PLANES_MAX:
         _PLANES.clear()
-    _PLANES[_pkey(t)] = (t.detach(), t._version, hi, lo)
+    # planes mirror the flat memory of a DENSE tensor, so any dense view of the same bytes shares them
+    _PLANES[(t.data_ptr(), t.numel())] = (t.detach(), t._version, buf)
 
 
 def planes_of(t):
-    """Cached (hi, lo) planes of a tensor, splitting it now if nobody has."""
-    e = _PLANES.get(_pkey(t))
+    """Cached planes buffer of a tensor, splitting it now if nobody has."""
+    e = _PLANES.get((t.data_ptr(), t.numel()))
     if e is not None and e[1] == t._version:
-        return e[2], e[3]
-    hi, lo = split_bf16(t)
-    planes_put(t, hi, lo)
-    return hi, lo
+        return e[2]
+    buf = _split(t)
+    planes_put(t, buf)
+    return buf
 
 
-def _x3(s, role):
-    return MATH == "bf16x3" and s.batch > 0 and bool(L.lib().jtsm_conv_bf16x3_eligible(C.byref(s), role))
+# Per-shape launch facts (the ctypes shape struct, output size, FLOPs, workspace sizes, bf16x3 eligibility)
+# are computed once: a training step calls the same ~90 shapes over and over.
+class _Plan(object):
+    __slots__ = ("s", "ref", "oh", "ow", "flops", "desc", "ws", "x3")
+
+
+_PLANS = {}
+
+
+def _plan(x_shape, w_shape, stride, pad, dil):
+    key = (tuple(x_shape), tuple(w_shape), stride, pad, dil)
+    p = _PLANS.get(key)
+    if p is None:
+        lib = L.lib()
+        p = _Plan()
+        p.s = _shape(x_shape, w_shape, stride, pad, dil)
+        p.ref = C.byref(p.s)
+        p.oh, p.ow = out_hw(p.s)
+        p.flops = _flops(p.s)
+        p.desc = _desc(p.s)
+        p.x3 = tuple(bool(lib.jtsm_conv_bf16x3_eligible(p.ref, r)) and p.s.batch > 0 for r in range(3))
+        p.ws = (lib.jtsm_conv_workspace_bytes(p.ref, 0), lib.jtsm_conv_workspace_bytes(p.ref, 1),
+                lib.jtsm_conv_bf16x3_wgrad_workspace_bytes(p.ref))
+        _PLANS[key] = p
+    return p
+
+
+# One scratch buffer per device for split-K slabs: every user runs on the caller's stream, in order.
+_SCRATCH = {}
+
+
+def _scratch(nbytes, device):
+    if nbytes == 0:
+        return None
+    buf = _SCRATCH.get(device)
+    if buf is None or buf.numel() < nbytes:
+        buf = _SCRATCH[device] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+    return buf
 
 
 def _x3_variant(s, role):
@@ -130,14 +185,6 @@ def _variant(s, role, has_kscale=False):
 
 def _desc(s):
     return (s.batch, s.in_h, s.in_w, s.in_c, s.out_c, s.kernel_h, s.stride)
-
-
-def _workspace(s, backward_data, device):
-    """Split-K scratch for this shape (None when the layer is not split)."""
-    nbytes = L.lib().jtsm_conv_workspace_bytes(C.byref(s), backward_data)
-    if nbytes == 0:
-        return None, 0
-    return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes
 
 
 def _flops(s):
@@ -180,31 +227,30 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
                    emit_planes=False):
     _check(x, w, scale, bias, residual)
     x, w = _cl(x), _cl(w)
-    s = _shape(x.shape, w.shape, stride, pad, dil)
-    oh, ow = out_hw(s)
-    y = torch.empty((s.batch, s.out_c, oh, ow), dtype=x.dtype, device=x.device, memory_format=CL)
+    pl = _plan(x.shape, w.shape, stride, pad, dil)
+    s = pl.s
+    y = torch.empty((s.batch, s.out_c, pl.oh, pl.ow), dtype=x.dtype, device=x.device, memory_format=CL)
     if residual is not None:
         residual = _cl(residual)
         assert residual.shape == y.shape
-    ws, nbytes = _workspace(s, 0, x.device)
-    if _x3(s, 0):
-        xh, xl = planes_of(x)
-        wh, wl = split_bf16(w)
-        yh = yl = None
-        if emit_planes and s.out_c % 8 == 0:
-            yh = torch.empty(y.numel(), dtype=torch.int16, device=y.device)
-            yl = torch.empty(y.numel(), dtype=torch.int16, device=y.device)
-        L.check(_timed(_x3_variant(s, 0), _flops(s), lambda: L.lib().jtsm_conv2d_forward_bf16x3(
-            L.ptr(xh), L.ptr(xl), L.ptr(wh), L.ptr(wl), L.ptr(y), L.ptr(yh), L.ptr(yl), C.byref(s), L.ptr(scale),
-            L.ptr(bias), L.ptr(residual), int(bool(relu)), L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)),
-                "conv2d_forward_bf16x3")
-        if yh is not None:
-            planes_put(y, yh, yl)
+    nbytes = pl.ws[0]
+    ws = _scratch(nbytes, x.device)
+    lib = L.lib()
+    if MATH == "bf16x3" and pl.x3[0]:
+        xh, xl = _hl(planes_of(x))
+        wbuf = _split(w)
+        wh, wl = _hl(wbuf)
+        ybuf = _planes_buf(y.numel(), y.device) if (emit_planes and s.out_c % 8 == 0) else None
+        yh, yl = _hl(ybuf)
+        L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
+            xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
+            L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_forward_bf16x3")
+        if ybuf is not None:
+            planes_put(y, ybuf)
         return y
-    variant = _variant(s, 0)
-    L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_forward_f32(
-        L.ptr(x), L.ptr(w), L.ptr(y), C.byref(s), L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_forward")
+    L.check(_timed(_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f32(
+        L.ptr(x), L.ptr(w), L.ptr(y), pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_forward")
     return y
 
 
@@ -212,48 +258,53 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
                          relu_mask=None):
     _check(dy, w, kscale, accumulate, relu_mask)
     dy, w = _cl(dy), _cl(w)
-    s = _shape(x_shape, w.shape, stride, pad, dil)
+    pl = _plan(x_shape, w.shape, stride, pad, dil)
+    s = pl.s
     dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device, memory_format=CL)
     if accumulate is not None:
         accumulate = _cl(accumulate)
     if relu_mask is not None:
         relu_mask = _cl(relu_mask)
-    ws, nbytes = _workspace(s, 1, dy.device)
-    if _x3(s, 1):
-        gh, gl = planes_of(dy)
-        wh, wl = split_bf16_transposed(w, kscale)   # the per-row scale rides along in the transposing split
-        L.check(_timed(_x3_variant(s, 1), _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_bf16x3(
-            L.ptr(gh), L.ptr(gl), L.ptr(wh), L.ptr(wl), L.ptr(dx), C.byref(s), L.ptr(accumulate), L.ptr(relu_mask),
-            L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_data_bf16x3")
+    nbytes = pl.ws[1]
+    ws = _scratch(nbytes, dy.device)
+    lib = L.lib()
+    if MATH == "bf16x3" and pl.x3[1]:
+        gh, gl = _hl(planes_of(dy))
+        wbuf = _split_transposed(w, kscale)   # the per-row scale rides along in the transposing split
+        wh, wl = _hl(wbuf)
+        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
+            gh, gl, wh, wl, L.ptr(dx), pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc), "conv2d_backward_data_bf16x3")
         return dx
-    variant = _variant(s, 1, kscale is not None)
-    L.check(_timed(variant, _flops(s), lambda: L.lib().jtsm_conv2d_backward_data_f32(
-        L.ptr(dy), L.ptr(w), L.ptr(dx), C.byref(s), L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_data")
+    L.check(_timed(_variant(s, 1, kscale is not None), pl.flops, lambda: lib.jtsm_conv2d_backward_data_f32(
+        L.ptr(dy), L.ptr(w), L.ptr(dx), pl.ref, L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_backward_data")
     return dx
 
 
 def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=None, out=None):
     _check(dy, x, row_scale)
     dy, x = _cl(dy), _cl(x)
-    s = _shape(x.shape, w_shape, stride, pad, dil)
-    if _x3(s, 2):
-        gh, gl = planes_of(dy)
-        xh, xl = planes_of(x)
+    pl = _plan(x.shape, w_shape, stride, pad, dil)
+    s = pl.s
+    lib = L.lib()
+    if MATH == "bf16x3" and pl.x3[2]:
+        gh, gl = _hl(planes_of(dy))
+        xh, xl = _hl(planes_of(x))
         fresh = out is None
         if fresh:   # deterministic slab kernel: writes every element, nothing to clear
             out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL)
-        nbytes = L.lib().jtsm_conv_bf16x3_wgrad_workspace_bytes(C.byref(s))
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-        L.check(_timed("igemm_x3_wgrad_kernel<2>", _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_bf16x3(
-            L.ptr(gh), L.ptr(gl), L.ptr(xh), L.ptr(xl), L.ptr(out), C.byref(s), L.ptr(row_scale), int(fresh),
-            L.ptr(ws), C.c_size_t(nbytes), L.stream()), _desc(s)), "conv2d_backward_weight_bf16x3")
+        nbytes = pl.ws[2]
+        ws = _scratch(nbytes, x.device)
+        L.check(_timed("igemm_x3_wgrad_kernel<2>", pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
+            gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc), "conv2d_backward_weight_bf16x3")
         return out
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
         out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL).zero_()
-    L.check(_timed(_variant(s, 2), _flops(s), lambda: L.lib().jtsm_conv2d_backward_weight_f32(
-        L.ptr(dy), L.ptr(x), L.ptr(out), C.byref(s), L.ptr(row_scale), int(zero), L.stream()), _desc(s)),
+    L.check(_timed(_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_f32(
+        L.ptr(dy), L.ptr(x), L.ptr(out), pl.ref, L.ptr(row_scale), int(zero), L.stream()), pl.desc),
             "conv2d_backward_weight")
     return out
 

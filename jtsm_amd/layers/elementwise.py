@@ -24,11 +24,11 @@ def relu_backward(dy, y, emit_planes=False):
     n = y.numel()
     if emit_planes and n % 8 == 0 and n > 0:
         from . import conv
-        hi = torch.empty(n, dtype=torch.int16, device=y.device)
-        lo = torch.empty(n, dtype=torch.int16, device=y.device)
-        L.check(L.lib().jtsm_relu_backward_split_f32(L.ptr(dy), L.ptr(y), L.ptr(g), L.ptr(hi), L.ptr(lo), C.c_long(n),
+        buf = conv._planes_buf(n, y.device)
+        hi, lo = conv._hl(buf)
+        L.check(L.lib().jtsm_relu_backward_split_f32(L.ptr(dy), L.ptr(y), L.ptr(g), hi, lo, C.c_long(n),
                                                      L.stream()), "relu_backward_split")
-        conv.planes_put(g, hi, lo)
+        conv.planes_put(g, buf)
         return g
     L.check(L.lib().jtsm_relu_backward_f32(L.ptr(dy), L.ptr(y), L.ptr(g), C.c_long(n), L.stream()),
             "relu_backward")
