@@ -130,6 +130,22 @@ int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32
 int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32_t* argmax,
                                float* grad_input, int B, int C, int H, int W, int M,
                                int pooled_h, int pooled_w, int layout, void* stream);
+/* All FPN levels in ONE launch — what detectron2/modeling/poolers.py:193-250 does level by level around
+ * wsl/layers/moi_pool.py:10-33.  inputs[l] / grad_inputs[l]: (B,H[l],W[l],C) NHWC maps (host arrays of device
+ * pointers, nlevels <= 8); roi_level[n] in [0,nlevels) picks roi n's map; output / argmax as above (NHWC).
+ * The backward zero-fills every grad_inputs[l] and accumulates with float atomics. */
+size_t jtsm_moi_pool_levels_workspace_bytes(int B, const int* H, const int* W, int nlevels, int M, int L);
+int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, const int* W,
+                                     const float* scales, int nlevels, const float* rois,
+                                     const int32_t* roi_level, const int32_t* oh_labels,
+                                     const int32_t* superpixels, float* output, int32_t* argmax,
+                                     void* workspace, int B, int C, int M, int L, int Hs, int Ws,
+                                     int pooled_h, int pooled_w, void* stream);
+int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                      const int32_t* argmax, float* const* grad_inputs, const int* H,
+                                      const int* W, int nlevels, int B, int C, int M, int pooled_h,
+                                      int pooled_w, void* stream);
+
 /* mois (M,H,W) int32 exactly as MoIForward (MOIPool_cuda.cu:138-215) would write it;
  * test/diagnostic entry, same workspace contract as the forward. */
 int jtsm_moi_mask_f32(const float* rois, const int32_t* oh_labels, const int32_t* superpixels,
@@ -207,6 +223,12 @@ int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
 int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, void* stream);
 int jtsm_split_bf16_transposed_f32(const float* w, const float* row_scale, uint16_t* hi, uint16_t* lo,
                                    int out_c, int taps, int in_c, void* stream);
+/* The same two splits for MANY weights in one launch.  table: device array of `entries` records of eight
+ * 64-bit words {src, hi, lo, row_scale (transposed only, may be 0), first_block, n, taps, in_c}:
+ *   transposed == 0: n = element count; the record owns ceil(n / 2048) consecutive workgroups;
+ *   transposed != 0: n = out_c;          it owns ceil(in_c/32) * ceil(out_c/32) * taps workgroups.
+ * first_block is the running sum of those counts (first record 0), `blocks` their total. */
+int jtsm_split_bf16_multi_f32(const void* table, int entries, long blocks, int transposed, void* stream);
 int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role);
 /* y_hi / y_lo (both or neither; needs out_c % 4 == 0): the planes of the finished output y, written by the
  * epilogue for a following bf16x3 contraction — saves that layer's jtsm_split_bf16_f32 pass. */

@@ -209,22 +209,22 @@ __device__ __forceinline__ float4 load_or_zero(const float* __restrict__ base, i
 
 // Write one wavefront's 64x64 accumulator tile with the fused epilogue (or as a raw split-K slab / an
 // atomic WGRAD contribution).
-template <int ROLE>
-__device__ __forceinline__ void store_tile(const Params& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+template <int ROLE, int TM = 2, int TN = 2>
+__device__ __forceinline__ void store_tile(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                            int lane) {
   // Epilogue.  C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
   const Epilogue& e = p.e;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
     if (n >= p.N) continue;
     const float sc = (ROLE != WGRAD && e.scale) ? e.scale[n] : 1.f;
     const float bi = e.bias ? e.bias[n] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
         float v = acc[i][j][r];
         if (ROLE != WGRAD && gridDim.y > 1) {  // split-K: raw partial into this slice's slab
@@ -272,35 +272,35 @@ __device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short*
 // rows — 512 contiguous bytes per 32 lanes — through the scale / bias / residual / ReLU / gate chain.
 // Short-K layers (1x1 convolutions into wide outputs) are bound by exactly this traffic.
 // Needs N % 4 == 0, ldc % 4 == 0 and 16-byte aligned C / residual / mask / slab (checked by the launcher).
-template <int ROLE, int BM, int BN, int PASSES = 1>
-__device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256>
+__device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                 int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */) {
   // PASSES > 1: the tile goes through a smaller LDS window in row bands of BM / PASSES (single-buffered kernels)
   constexpr int ROWS = BM / PASSES;
-  static_assert(ROWS % 64 == 0, "a band holds whole 64-row wave tiles");
+  static_assert(ROWS % (32 * TM) == 0, "a band holds whole wave tiles");
   const Epilogue& e = p.e;
   constexpr int CPR = BN / 4;                 // float4 pieces per tile row
-  constexpr int PIECES = ROWS * CPR / 256;    // per thread per band
+  constexpr int PIECES = ROWS * CPR / NT;     // per thread per band
   const bool raw = gridDim.y > 1;             // split-K: raw partial into this slice's slab
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     __syncthreads();   // every wave is done reading the last K stage / streaming the previous band
-    if ((wm * 64) / ROWS == pass) {
-      const int r0 = wm * 64 - pass * ROWS;
+    if ((wm * TM * 32) / ROWS == pass) {
+      const int r0 = wm * TM * 32 - pass * ROWS;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = r0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            tile[row * BN + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            tile[row * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
           }
     }
     __syncthreads();
 #pragma unroll 4
     for (int it = 0; it < PIECES; ++it) {
-      const int c = tid + 256 * it;
+      const int c = tid + NT * it;
       const int row = c / CPR, col = (c % CPR) * 4;
       const int m = m0 + pass * ROWS + row, n = n0 + col;
       if (m >= p.M || n >= p.N) continue;
@@ -947,7 +947,11 @@ size_t jtsm_conv_workspace_bytes(const jtsm_conv_shape* s, int backward_data) {
   else if (c.KH == 1 && c.KW == 1 && c.pad == 0 && c.stride > 1) { M = (long)c.Bn * c.Ho * c.Wo; N = c.Cin; K = c.Cout; }
   else { M = (long)c.Bn * c.H * c.W; N = c.Cin; K = (long)c.KH * c.KW * c.Cout; }
   const int bm = N <= 64 ? 256 : 128, bn = N <= 64 ? 64 : 128;
-  const int splits = plan_splits(ceil_div(N, bn) * ceil_div(M, bm), ceil_div(K, BK));
+  int splits = plan_splits(ceil_div(N, bn) * ceil_div(M, bm), ceil_div(K, BK));
+  Params p = {};   // the bf16x3 launcher may want more slices (other tiles, other round size): cover both
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  const int sx = x3_wanted_splits(p);
+  if (sx > splits) splits = sx;
   return splits > 1 ? (size_t)splits * M * N * sizeof(float) : 0;
 }
 
@@ -1141,8 +1145,7 @@ int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const
   }
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
-  if (p.N <= 64) return launch_split_x3<FWD, 256, 64>(p, q, workspace, workspace_bytes, st);
-  return launch_split_x3<FWD, 128, 128>(p, q, workspace, workspace_bytes, st);
+  return launch_split_x3<FWD>(p, q, workspace, workspace_bytes, st);
 }
 
 int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
@@ -1175,17 +1178,28 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
     p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;
     p.M = p.s.Bn * p.s.Ho * p.s.Wo;
   }
-  if (p.N <= 64) return launch_split_x3<DGRAD, 256, 64>(p, q, workspace, workspace_bytes, st);
-  return launch_split_x3<DGRAD, 128, 128>(p, q, workspace, workspace_bytes, st);
+  return launch_split_x3<DGRAD>(p, q, workspace, workspace_bytes, st);
+}
+
+// 256x256 tiles for the weight gradients whose output is large enough to fill the chip with them.
+static bool x3_wgrad_big(const Params& p) {
+  static const int force = getenv("JTSM_X3_WGRAD_TILE") ? atoi(getenv("JTSM_X3_WGRAD_TILE")) : -1;
+  if (p.M < 256 || p.N < 256) return false;
+  if (force >= 0) return force == 2;
+  static const long min_work = getenv("JTSM_X3_WGRAD_BIG_MIN") ? atol(getenv("JTSM_X3_WGRAD_BIG_MIN")) : 2000;
+  const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
+  return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, scratch/wgrad_sweep.py)
 }
 
 static int x3_wgrad_splits(const Params& p) {
-  const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
+  const bool big = x3_wgrad_big(p);
+  const int t = big ? 256 : 128;
+  const int ntiles = ceil_div(p.N, t) * ceil_div(p.M, t);
   const int ktiles = ceil_div(p.K, XBK);
   // Pixel-axis split (measured on MI355X, scratch/wgrad_sweep.py): about one workgroup per CU with >= 16 stages
   // each; only when that would leave > 64 stages per workgroup (large maps) go to three workgroups per CU.
   int splits = ceil_div(256, ntiles);
-  if (ceil_div(ktiles, splits) > 64) splits = ceil_div(768, ntiles);
+  if (!big && ceil_div(ktiles, splits) > 64) splits = ceil_div(768, ntiles);
   if (splits > ceil_div(ktiles, 16)) splits = ceil_div(ktiles, 16);
   if (splits < 1) splits = 1;
   const int kps = ceil_div(ktiles, splits);
@@ -1236,13 +1250,29 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
   const size_t need = (size_t)splits * p.M * p.N * sizeof(float);
   JTSM_REQUIRE(splits <= 1 || (workspace && workspace_bytes >= need && aligned16(workspace)),
                "conv backward-weight bf16x3: workspace of %zu bytes needed (jtsm_conv_bf16x3_wgrad_workspace_bytes)", need);
-  const int ntiles = ceil_div(p.N, 128) * ceil_div(p.M, 128);
+  const bool big = x3_wgrad_big(p);
+  const int tl = big ? 256 : 128;
+  const int ntiles = ceil_div(p.N, tl) * ceil_div(p.M, tl);
   p.ktiles_per_split = ceil_div(ceil_div(p.K, XBK), splits);
   p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   p.wide = 1;   // N = taps * in_c is a multiple of 8, dw / slab 16-byte aligned
-  hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
+  if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
+  else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
   if (splits > 1) return finish_split(p, splits, st, 1);
+  return JTSM_OK;
+}
+
+int jtsm_split_bf16_multi_f32(const void* table, int entries, long blocks, int transposed, void* stream) {
+  JTSM_REQUIRE(entries >= 0 && blocks >= 0 && blocks < 2147483647L, "split_bf16_multi: bad sizes");
+  if (entries == 0 || blocks == 0) return JTSM_OK;
+  JTSM_REQUIRE(table && aligned16(table), "split_bf16_multi: table must be a 16-byte aligned device pointer");
+  const SplitEntry* tab = reinterpret_cast<const SplitEntry*>(table);
+  if (transposed)
+    hipLaunchKernelGGL(split_bf16_transposed_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab, entries);
+  else
+    hipLaunchKernelGGL(split_bf16_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), tab, entries);
+  JTSM_CHECK_LAUNCH("split_bf16_multi");
   return JTSM_OK;
 }
 

@@ -30,19 +30,21 @@ __device__ __forceinline__ void dma16b(const void* g, void* lds_uniform_base) {
                                    (__attribute__((address_space(3))) void*)lds_uniform_base, 16, 0, 0);
 }
 
-// SK = k per stage: 32 (64-byte rows per plane, 16 rows per load) or 64 (128-byte rows, 8 rows per load).
-template <int ROLE, int BM, int BN, int NBUF, int SK = 32>
-__global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64 ? 2 : 1)) void igemm_x3_kernel(const Params p, const X3Planes q) {
-  constexpr int RB = SK * 2;            // bytes per row per plane per stage
-  constexpr int RPI = 1024 / RB;        // rows per direct-to-LDS load
-  constexpr int CPW = RB / 16;          // 16-byte chunks per row
-  constexpr int SWS = SK == 32 ? 2 : 1, SWM = CPW - 1;   // slot = chunk ^ ((row >> SWS) & SWM)
+// Tile shape: WM x WN wavefronts, each TM x TN MFMA tiles of 32x32 -> a workgroup of 64*WM*WN threads owns
+// BM x BN = 32*WM*TM x 32*WN*TN outputs.  The loop is bound by how many operand bytes a CU can keep in
+// flight from L2 (measured: the same kernel without its MFMAs takes 67-90 % of the full time, and LDS limits
+// the bytes in flight), so the large layers use 256x256 (half the operand bytes per FLOP of 128x128).
+// DBG: ablation builds for profiling only (1 no MFMA, 2 no loads).
+template <int ROLE, int WM, int WN, int TM, int TN, int NBUF, int DBG = 0>
+__global__ __launch_bounds__(64 * WM * WN, (NBUF == 1 && WM * WN == 4) ? 4 : (WM * WN == 4 ? 2 : 2))
+void igemm_x3_kernel(const Params p, const X3Planes q) {
   static_assert(ROLE == FWD || ROLE == DGRAD, "bf16x3: forward and data-gradient roles");
-  constexpr int WN = BN / 64;
-  static_assert((BM / 64) * WN == 4, "four wavefronts of 64x64");
-  constexpr int A_PL = BM * RB, B_PL = BN * RB;          // bytes per plane per stage
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  constexpr int A_PL = BM * 64, B_PL = BN * 64;          // bytes per plane per stage (64-byte rows)
   constexpr int STAGE = 2 * A_PL + 2 * B_PL;
-  constexpr int A_INS = BM / RPI / 4, B_INS = BN / RPI / 4;   // loads per wavefront per plane per stage
+  static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "16-row loads must divide evenly among the wavefronts");
+  constexpr int A_INS = BM / 16 / NW, B_INS = BN / 16 / NW;   // loads per wavefront per plane per stage
   __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
 
   const ConvShape& s = p.s;
@@ -61,10 +63,10 @@ __global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64
 
   int kbeg = 0, kend = p.K;
   if (gridDim.y > 1) {
-    kbeg = blockIdx.y * p.ktiles_per_split * XBK;   // (split bookkeeping stays in units of 32 k)
+    kbeg = blockIdx.y * p.ktiles_per_split * XBK;
     kend = min(p.K, kbeg + p.ktiles_per_split * XBK);
   }
-  const int ntile_k = kbeg < kend ? (kend - kbeg + SK - 1) / SK : 0;
+  const int ntile_k = kbeg < kend ? (kend - kbeg + XBK - 1) / XBK : 0;
 
   // ---- addressing state: the tap and first channel of a stage are wave-uniform and advance incrementally
   const int Cdim = ROLE == FWD ? s.Cin : s.Cout;
@@ -84,9 +86,9 @@ __global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64
   unsigned a_mh[A_INS], a_mw[A_INS];
 #pragma unroll
   for (int j = 0; j < A_INS; ++j) {
-    const int r = (wave * A_INS + j) * RPI + lane / CPW;
+    const int r = (wave * A_INS + j) * 16 + (lane >> 2);
     arow[j] = ROLE == FWD ? fwd_pixel(s, m0 + r, p.M) : dgrad_pixel(s, m0 + r, p.M);
-    a_chunk[j] = 8 * ((lane % CPW) ^ ((r >> SWS) & SWM));
+    a_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
     unsigned mh = 0, mw = 0;
     if (ROLE == FWD) {
       for (int kh = 0; kh < s.KH; ++kh) mh |= ((unsigned)(arow[j].h0 + kh * s.dil) < (unsigned)s.H ? 1u : 0u) << kh;
@@ -103,18 +105,17 @@ __global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64
   int b_off[B_INS], b_chunk[B_INS];
 #pragma unroll
   for (int j = 0; j < B_INS; ++j) {
-    const int r = (wave * B_INS + j) * RPI + lane / CPW;
+    const int r = (wave * B_INS + j) * 16 + (lane >> 2);
     b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
-    b_chunk[j] = 8 * ((lane % CPW) ^ ((r >> SWS) & SWM));
+    b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
   }
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;   // the lo plane sits at a fixed distance
 
   // One direct-to-LDS load ("piece") of the next stage: pieces 0 .. 2*A_INS-1 are the A rows (hi, lo
-  // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups: a
-  // load costs the issuing wave 60-180 cycles (MI355X_MICROARCH.md, cycle constants), which eight loads
-  // in a row would take out of the matrix pipe's time, while one load per three MFMAs hides in their shadow.
+  // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups.
   constexpr int PIECES = 2 * A_INS + 2 * B_INS;
   auto issue_piece = [&](int idx, int k0, int buf) {
+    if (DBG == 2) return;
     char* St = lds + buf * STAGE;
     if (idx < 2 * A_INS) {
       const int j = idx >> 1, lo = idx & 1;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64
     }
   };
   auto advance_tap = [&]() {   // next stage: same tap or the next one (stages never straddle taps)
-    t_c += SK;
+    t_c += XBK;
     if (t_c >= Cdim) {
       t_c -= Cdim;
       if (++t_kw == s.KW) { t_kw = 0; ++t_kh; }
@@ -155,60 +156,70 @@ __global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64
     advance_tap();
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  int a_off[2], a_swz[2], bb_off[2], b_swz[2];
+  int a_off[TM], a_swz[TM], bb_off[TN], b_swz[TN];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int ar = wm * 64 + t * 32 + li, br = wn * 64 + t * 32 + li;
-    a_off[t] = ar * RB;
-    a_swz[t] = (ar >> SWS) & SWM;
-    bb_off[t] = 2 * A_PL + br * RB;
-    b_swz[t] = (br >> SWS) & SWM;
+  for (int t = 0; t < TM; ++t) {
+    const int ar = (wm * TM + t) * 32 + li;
+    a_off[t] = ar * 64;
+    a_swz[t] = (ar >> 2) & 3;
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int br = (wn * TN + t) * 32 + li;
+    bb_off[t] = 2 * A_PL + br * 64;
+    b_swz[t] = (br >> 2) & 3;
   }
 
-  constexpr int KSTEPS = SK / 16;
-  constexpr int SLOTS = 4 * KSTEPS;                         // MFMA groups per stage (k-steps x 2 x 2 tiles)
+  constexpr int SLOTS = 2 * TM * TN;                        // MFMA groups per stage (2 k-steps x TM x TN tiles)
   constexpr int PER_SLOT = (PIECES + SLOTS - 1) / SLOTS;    // loads placed behind each group
   if (NBUF == 2 && ntile_k > 0) issue(kbeg, 0);
   for (int t = 0; t < ntile_k; ++t) {
     if (NBUF == 1) {
       __syncthreads();
-      issue(kbeg + t * SK, 0);
+      issue(kbeg + t * XBK, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool more = NBUF == 2 && t + 1 < ntile_k;   // wave-uniform
-    const int knext = kbeg + (t + 1) * SK, bnext = (t + 1) & 1;
+    const int knext = kbeg + (t + 1) * XBK, bnext = (t + 1) & 1;
     const char* St = lds + (NBUF == 2 ? (t & 1) : 0) * STAGE;
 #pragma unroll
-    for (int st = 0; st < KSTEPS; ++st) {
+    for (int st = 0; st < 2; ++st) {
       const int c = 2 * st + half;
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < TM; ++u) {
         const int ao = a_off[u] + ((c ^ a_swz[u]) << 4);
         ah[u] = *reinterpret_cast<const bf16x8*>(St + ao);
         al[u] = *reinterpret_cast<const bf16x8*>(St + A_PL + ao);
+      }
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
         const int bo = bb_off[u] + ((c ^ b_swz[u]) << 4);
         bh[u] = *reinterpret_cast<const bf16x8*>(St + bo);
         bl[u] = *reinterpret_cast<const bf16x8*>(St + B_PL + bo);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if (DBG == 1) {   // keep the operands alive without the matrix pipe
+            acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1];
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
           if (NBUF == 2) {
-            const int slot = st * 4 + i * 2 + j;
+            const int slot = (st * TM + i) * TN + j;
             if (more) {
 #pragma unroll
               for (int e = 0; e < PER_SLOT; ++e)
@@ -220,12 +231,13 @@ __global__ __launch_bounds__(256, (NBUF == 1 && SK == 32) ? 4 : (NBUF * SK <= 64
     }
     if (more) advance_tap();
   }
-  constexpr int PASSES = NBUF * STAGE >= BM * BN * 4 ? 1 : 2;
-  static_assert(NBUF * STAGE >= BM * BN * 4 / PASSES, "epilogue window does not fit the stage buffers");
+  constexpr int LDSB = NBUF * STAGE;
+  constexpr int PASSES = LDSB >= BM * BN * 4 ? 1 : (LDSB >= BM * BN * 2 ? 2 : 4);
+  static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
   if (p.wide)
-    store_tile_wide<ROLE, BM, BN, PASSES>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
+    store_tile_wide<ROLE, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
   else
-    store_tile<ROLE>(p, acc, m0, n0, wm, wn, lane);
+    store_tile<ROLE, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- weight gradient ------------------------------------------------------------------------------
@@ -243,17 +255,22 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* lo_rows, const char* hi_ro
   return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-template <int NBUF>
-__global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_kernel(const Params p, const X3Planes q) {
-  constexpr int BM = 128, BN = 128;
-  constexpr int PL = XBK * 256;            // bytes per plane per stage: 32 pixel rows x 128 channels
-  constexpr int STAGE = 4 * PL;            // dY hi, dY lo, X hi, X lo
-  constexpr int INS = 2;                   // 4-row loads per wavefront per plane per stage
+// WM x WN wavefronts of TM x TN MFMA tiles, as in igemm_x3_kernel; operands wider than 128 channels are kept
+// as several 128-channel images (each with the swizzle above).
+template <int WM, int WN, int TM, int TN, int NBUF>
+__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const Params p, const X3Planes q) {
+  constexpr int NW = WM * WN, NT = 64 * NW;
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+  static_assert(BM % 128 == 0 && BN % 128 == 0 && 8 % NW == 0, "128-channel images; 8 row groups shared by the wavefronts");
+  constexpr int ASUB = BM / 128, BSUB = BN / 128;
+  constexpr int PL = XBK * 256;                 // bytes per image per plane per stage: 32 pixel rows x 128 channels
+  constexpr int STAGE = 2 * (ASUB + BSUB) * PL; // [dY image 0 hi, lo, image 1 hi, lo ...][X images likewise]
+  constexpr int INS = 8 / NW;                   // 4-row load groups per wavefront per image
   __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
 
   const ConvShape& s = p.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int ntiles = ntn * ntm;
@@ -272,72 +289,99 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_kernel(const Params p, 
   }
   const int ntile_k = kbeg < kend ? (kend - kbeg + XBK - 1) / XBK : 0;
 
-  // ---- load addressing: load j of this wave fills rows 4T .. 4T+3 (T = 2*wave + j); this lane owns row
+  // ---- load addressing: row group T = INS*wave + j fills rows 4T .. 4T+3 of every image; this lane owns row
   // r = 4T + lane/16 and the chunk whose slot is lane%16
-  int a_col[INS], b_ci[INS], b_kh[INS], b_kw[INS], row_k[INS];
-  bool a_ok[INS], b_ok[INS];
+  int row_k[INS], a_col[INS][ASUB], b_ci[INS][BSUB], b_kh[INS][BSUB], b_kw[INS][BSUB];
+  bool a_ok[INS][ASUB], b_ok[INS][BSUB];
   PixState bpix[INS];
 #pragma unroll
   for (int j = 0; j < INS; ++j) {
     const int r = 4 * (wave * INS + j) + (lane >> 4);
     const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
     row_k[j] = r;
-    a_col[j] = m0 + 8 * ch;
-    a_ok[j] = a_col[j] < p.M;
-    const int col = n0 + 8 * ch;
-    b_ok[j] = col < p.N;
-    const int cc = b_ok[j] ? col : 0;
-    const int tap = cc / s.Cin;
-    b_ci[j] = cc - tap * s.Cin;
-    b_kh[j] = tap / s.KW;
-    b_kw[j] = tap - b_kh[j] * s.KW;
+#pragma unroll
+    for (int u = 0; u < ASUB; ++u) {
+      a_col[j][u] = m0 + u * 128 + 8 * ch;
+      a_ok[j][u] = a_col[j][u] < p.M;
+    }
+#pragma unroll
+    for (int u = 0; u < BSUB; ++u) {
+      const int col = n0 + u * 128 + 8 * ch;
+      b_ok[j][u] = col < p.N;
+      const int cc = b_ok[j][u] ? col : 0;
+      const int tap = cc / s.Cin;
+      b_ci[j][u] = cc - tap * s.Cin;
+      b_kh[j][u] = tap / s.KW;
+      b_kw[j][u] = tap - b_kh[j][u] * s.KW;
+    }
     bpix[j] = pix_init(kbeg + r, s.Ho, s.Wo);
   }
+  const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
 
-  auto issue = [&](int k0, int buf) {
+  // piece idx -> (row group j, operand, image u, plane): INS * 2 * (ASUB + BSUB) pieces per wavefront per stage
+  constexpr int PPJ = 2 * (ASUB + BSUB);
+  constexpr int PIECES = INS * PPJ;
+  auto issue_piece = [&](int idx, int k0, int buf) {
     char* St = lds + buf * STAGE;
-#pragma unroll
-    for (int j = 0; j < INS; ++j) {
-      const int dst = (wave * INS + j) * 1024;
+    const int j = idx / PPJ, w = idx % PPJ;
+    const int dst = (wave * INS + j) * 1024;
+    if (w < 2 * ASUB) {
+      const int u = w >> 1, lo = w & 1;
       const int k = k0 + row_k[j];
-      const bool oka = a_ok[j] && k < kend;
-      const long aoff = (long)k * s.Cout + a_col[j];
-      dma16b(oka ? (const void*)(q.A_hi + aoff) : (const void*)g_zero_page, St + dst);
-      dma16b(oka ? (const void*)(q.A_lo + aoff) : (const void*)g_zero_page, St + PL + dst);
+      const bool ok = a_ok[j][u] && k < kend;
+      const __bf16* src = q.A_hi + ((long)k * s.Cout + a_col[j][u]) + (lo ? lo_delta_a : 0);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (u * 2 + lo) * PL + dst);
+    } else {
+      const int u = (w - 2 * ASUB) >> 1, lo = (w - 2 * ASUB) & 1;
       const PixState& px = bpix[j];
-      const int ih = px.oh * s.stride - s.pad + b_kh[j] * s.dil, iw = px.ow * s.stride - s.pad + b_kw[j] * s.dil;
-      const bool okb = b_ok[j] && px.k < kend && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
-      const long boff = ((long)(px.b * s.H + ih) * s.W + iw) * s.Cin + b_ci[j];
-      dma16b(okb ? (const void*)(q.B_hi + boff) : (const void*)g_zero_page, St + 2 * PL + dst);
-      dma16b(okb ? (const void*)(q.B_lo + boff) : (const void*)g_zero_page, St + 3 * PL + dst);
-      pix_advance(bpix[j], XBK, s.Ho, s.Wo);
+      const int ih = px.oh * s.stride - s.pad + b_kh[j][u] * s.dil, iw = px.ow * s.stride - s.pad + b_kw[j][u] * s.dil;
+      const bool ok = b_ok[j][u] && px.k < kend && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
+      const __bf16* src = q.B_hi + (((long)(px.b * s.H + ih) * s.W + iw) * s.Cin + b_ci[j][u]) + (lo ? lo_delta_b : 0);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (2 * ASUB + u * 2 + lo) * PL + dst);
     }
   };
+  auto advance_pix = [&]() {
+#pragma unroll
+    for (int j = 0; j < INS; ++j) pix_advance(bpix[j], XBK, s.Ho, s.Wo);
+  };
+  auto issue = [&](int k0, int buf) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) issue_piece(i, k0, buf);
+    advance_pix();
+  };
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // ---- transposed fragment reads: lane = 32h + 16g + 4ql + pl supplies, for read r2 of step st, the address
   // of row 16st + 8h + 4r2 + ql, channels 32*tile + 16g + 4pl .. +3; it receives channel 16g + lane%16.
   const int h = lane >> 5, g = (lane >> 4) & 1, ql = (lane >> 2) & 3, pl = lane & 3;
-  int a_rd[2][2], b_rd[2][2];   // [tile][r2], byte offset inside a plane for step 0
+  int a_rd[TM][2], b_rd[TN][2];   // [tile][r2]: byte offset inside a stage (hi plane) for step 0
 #pragma unroll
-  for (int t = 0; t < 2; ++t)
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int row = 8 * h + 4 * r2 + ql;
+    const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
 #pragma unroll
-    for (int r2 = 0; r2 < 2; ++r2) {
-      const int row = 8 * h + 4 * r2 + ql;
-      const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
-      const int cha = (wm * 64 + t * 32) / 8 + 2 * g + (pl >> 1);
-      const int chb = (wn * 64 + t * 32) / 8 + 2 * g + (pl >> 1);
-      a_rd[t][r2] = 256 * row + 16 * (cha ^ swz) + 8 * (pl & 1);
-      b_rd[t][r2] = 256 * row + 16 * (chb ^ swz) + 8 * (pl & 1);
+    for (int t = 0; t < TM; ++t) {
+      const int cb = (wm * TM + t) * 32;          // first channel of this tile inside the BM tile
+      const int ch = (cb % 128) / 8 + 2 * g + (pl >> 1);
+      a_rd[t][r2] = (cb / 128) * 2 * PL + 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
     }
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int cb = (wn * TN + t) * 32;
+      const int ch = (cb % 128) / 8 + 2 * g + (pl >> 1);
+      b_rd[t][r2] = (2 * ASUB + (cb / 128) * 2) * PL + 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
+    }
+  }
 
+  constexpr int SLOTS = 2 * TM * TN;
+  constexpr int PER_SLOT = (PIECES + SLOTS - 1) / SLOTS;
   if (NBUF == 2 && ntile_k > 0) issue(kbeg, 0);
   for (int t = 0; t < ntile_k; ++t) {
     if (NBUF == 1) {
@@ -346,33 +390,50 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_kernel(const Params p, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (NBUF == 2 && t + 1 < ntile_k) issue(kbeg + (t + 1) * XBK, (t + 1) & 1);
+    const bool more = NBUF == 2 && t + 1 < ntile_k;
+    const int knext = kbeg + (t + 1) * XBK, bnext = (t + 1) & 1;
     const char* St = lds + (NBUF == 2 ? (t & 1) : 0) * STAGE;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const char* Ss = St + st * 16 * 256;   // rows 16st ..; the swizzle does not depend on st
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < TM; ++u) {
         ah[u] = lds_tr8(Ss + a_rd[u][0], Ss + a_rd[u][1]);
         al[u] = lds_tr8(Ss + PL + a_rd[u][0], Ss + PL + a_rd[u][1]);
-        bh[u] = lds_tr8(Ss + 2 * PL + b_rd[u][0], Ss + 2 * PL + b_rd[u][1]);
-        bl[u] = lds_tr8(Ss + 3 * PL + b_rd[u][0], Ss + 3 * PL + b_rd[u][1]);
       }
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int u = 0; u < TN; ++u) {
+        bh[u] = lds_tr8(Ss + b_rd[u][0], Ss + b_rd[u][1]);
+        bl[u] = lds_tr8(Ss + PL + b_rd[u][0], Ss + PL + b_rd[u][1]);
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          if (NBUF == 2) {
+            const int slot = (st * TM + i) * TN + j;
+            if (more) {
+#pragma unroll
+              for (int e = 0; e < PER_SLOT; ++e)
+                if (slot * PER_SLOT + e < PIECES) issue_piece(slot * PER_SLOT + e, knext, bnext);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
     }
+    if (more) advance_pix();
   }
+  constexpr int LDSB = NBUF * STAGE;
+  constexpr int PASSES = LDSB >= BM * BN * 4 ? 1 : (LDSB >= BM * BN * 2 ? 2 : 4);
+  static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
   if (p.wide)
-    store_tile_wide<WGRAD, BM, BN>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
+    store_tile_wide<WGRAD, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
   else
-    store_tile<WGRAD>(p, acc, m0, n0, wm, wn, lane);
+    store_tile<WGRAD, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- the splitting pre-passes ---------------------------------------------------------------------
@@ -429,6 +490,80 @@ __global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float*
   }
 }
 
+// ---- many weights in one launch ---------------------------------------------------------------------
+// A training step re-splits every trainable weight once (straight for the forward, transposed + BN-scaled
+// for the data gradient): ~150 tiny launches.  These two kernels walk a device table instead.
+struct SplitEntry {        // 8 x 8 bytes, built by the host as int64 words
+  const float* src;        // weight [Cout][taps][Cin]
+  __bf16* hi;
+  __bf16* lo;
+  const float* row_scale;  // transposed form only (nullable)
+  long first_block;        // first workgroup of this entry
+  long n;                  // straight: elements.  transposed: Cout
+  long taps;               // transposed only
+  long cin;                // transposed only
+};
+
+__device__ __forceinline__ int find_entry(const SplitEntry* __restrict__ tab, int n, long block) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= block) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// straight: each workgroup splits 2048 consecutive elements of its entry
+__global__ __launch_bounds__(256) void split_bf16_multi_kernel(const SplitEntry* __restrict__ tab, int nent) {
+  const int e = find_entry(tab, nent, blockIdx.x);
+  const SplitEntry t = tab[e];
+  const long base = ((long)blockIdx.x - t.first_block) * 2048 + threadIdx.x * 8;
+  if (base + 8 <= t.n) {
+    const float4 a = *reinterpret_cast<const float4*>(t.src + base), b = *reinterpret_cast<const float4*>(t.src + base + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    bf16x8 h, l;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      __bf16 hh, ll;
+      split1(v[k], hh, ll);
+      h[k] = hh; l[k] = ll;
+    }
+    *reinterpret_cast<bf16x8*>(t.hi + base) = h;
+    *reinterpret_cast<bf16x8*>(t.lo + base) = l;
+  } else {
+    for (long i = base; i < t.n; ++i) split1(t.src[i], t.hi[i], t.lo[i]);
+  }
+}
+
+// transposed: each workgroup handles one 32x32 (ci, co) tile of one tap of its entry
+__global__ __launch_bounds__(256) void split_bf16_transposed_multi_kernel(const SplitEntry* __restrict__ tab, int nent) {
+  __shared__ float tile[32][33];
+  const int e = find_entry(tab, nent, blockIdx.x);
+  const SplitEntry t = tab[e];
+  const int Cout = (int)t.n, taps = (int)t.taps, Cin = (int)t.cin;
+  const int tx_n = (Cin + 31) / 32, ty_n = (Cout + 31) / 32;
+  long r = (long)blockIdx.x - t.first_block;
+  const int bx = (int)(r % tx_n); r /= tx_n;
+  const int by = (int)(r % ty_n);
+  const int tap = (int)(r / ty_n);
+  const int ci0 = bx * 32, co0 = by * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int co = co0 + rr, ci = ci0 + tx;
+    tile[rr][tx] = (co < Cout && ci < Cin) ? t.src[((size_t)co * taps + tap) * Cin + ci] * (t.row_scale ? t.row_scale[co] : 1.f) : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int ci = ci0 + rr, co = co0 + tx;
+    if (ci < Cin && co < Cout) {
+      const size_t o = ((size_t)ci * taps + tap) * Cout + co;
+      split1(tile[tx][rr], t.hi[o], t.lo[o]);
+    }
+  }
+}
+
 // Every stage inside one filter tap, and 16-byte chunks never straddling the end of K.
 inline bool x3_eligible(int role, const ConvShape& s) {
   if (role == WGRAD) return s.Cin % 8 == 0 && s.Cout % 8 == 0;   // 16-byte chunks of 8 channels inside one tap
@@ -437,12 +572,15 @@ inline bool x3_eligible(int role, const ConvShape& s) {
   return c % XBK == 0 || (taps == 1 && c % 8 == 0);
 }
 
-template <int ROLE, int BM, int BN>
-int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
+// Launch one tile configuration, with its split-K plan.
+template <int ROLE, int WM, int WN, int TM, int TN>
+int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, int round_blocks,
+                  hipStream_t st) {
+  constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
   const int ntiles = ceil_div(p.N, BN) * ceil_div(p.M, BM);
   const int ktiles = ceil_div(p.K, XBK);
-  // Two 64-KiB workgroups fit a CU: aim at one full round of 512 (measured: scratch/x3_sweep.py).
-  int splits = plan_splits(ntiles, ktiles, 512);
+  // aim at one full round of resident workgroups (measured: scratch/x3_sweep.py)
+  int splits = plan_splits(ntiles, ktiles, round_blocks);
   if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
   if (splits > 1) {
     p.ktiles_per_split = ceil_div(ktiles, splits);
@@ -453,14 +591,48 @@ int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t worksp
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
-  // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
-  // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
-  // (SK = 64 — 128-byte rows, one workgroup per CU — measured 15-25 % slower on every large layer; not dispatched)
-  if (ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
-    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
+  const dim3 grid(ntiles, splits > 1 ? splits : 1);
+  static const int dbg = getenv("JTSM_X3_DBG") ? atoi(getenv("JTSM_X3_DBG")) : 0;
+  if (dbg == 1 && ROLE == FWD && NT == 512)
+    hipLaunchKernelGGL((igemm_x3_kernel<FWD, WM, WN, TM, TN, 2, 1>), grid, dim3(NT), 0, st, p, q);
+  else if (dbg == 2 && ROLE == FWD && NT == 512)
+    hipLaunchKernelGGL((igemm_x3_kernel<FWD, WM, WN, TM, TN, 2, 2>), grid, dim3(NT), 0, st, p, q);
+  else if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
+    // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
+    // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 1>), grid, dim3(NT), 0, st, p, q);
   else
-    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, BM, BN, 2>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2>), grid, dim3(NT), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3");
   if (splits > 1) return finish_split(p, splits, st);
   return JTSM_OK;
+}
+
+// Tile choice.  0: 128x128 (4 waves), 1: 256x64 (4 waves, narrow outputs), 2: 256x256 (8 waves, large layers).
+inline int x3_tile_choice(const Params& p) {
+  static const int force = getenv("JTSM_X3_TILE") ? atoi(getenv("JTSM_X3_TILE")) : -1;
+  if (p.N <= 64) return 1;
+  if (force >= 0) return force == 2 && p.N >= 192 ? 2 : 0;
+  // 256x256 pays once its (fewer, larger) workgroups still fill the chip and K is deep enough to amortise them
+  const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
+  const int ktiles = ceil_div(p.K, XBK);
+  static const long min_work = getenv("JTSM_X3_BIG_MIN") ? atol(getenv("JTSM_X3_BIG_MIN")) : 9216;
+  if (p.N >= 192 && t256 * ktiles >= min_work && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
+  return 0;
+}
+
+// K slices the launcher will want for this problem (before the workspace clamp).
+inline int x3_wanted_splits(const Params& p) {
+  const int c = x3_tile_choice(p);
+  const int bm = c == 0 ? 128 : 256, bn = c == 0 ? 128 : (c == 1 ? 64 : 256);
+  return plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ceil_div(p.K, XBK), c == 2 ? 256 : 512);
+}
+
+template <int ROLE>
+int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  switch (x3_tile_choice(p)) {
+    case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2>(p, q, workspace, workspace_bytes, 512, st);
+    case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4>(p, q, workspace, workspace_bytes, 256, st);
+    default: return launch_x3_cfg<ROLE, 2, 2, 2, 2>(p, q, workspace, workspace_bytes, 512, st);
+  }
 }

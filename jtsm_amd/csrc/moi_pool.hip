@@ -120,17 +120,12 @@ __device__ __forceinline__ bool cell_hit(const unsigned* __restrict__ cell_row,
 }
 
 template <int VEC>
-__global__ __launch_bounds__(256) void moi_pool_fwd_nhwc(
+__device__ __forceinline__ void moi_pool_wave(
     const float* __restrict__ in, const float* __restrict__ rois,
     const unsigned* __restrict__ cell_bits, const unsigned* __restrict__ roi_bits,
-    float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, int M, int words,
-    float scale, int PH, int PW, const int* __restrict__ roi_level, int level) {
-  const int lane = threadIdx.x & 63;
+    float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, int words,
+    float scale, int PH, int PW, int n, int bin, int lane) {
   const int nbins = PH * PW;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= (long)M * nbins) return;
-  if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level
-  const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
   const int ph = bin / PW, pw = bin - ph * PW;
   const IBox r = round_box(rois + (size_t)n * 5, scale);
   const BinRange q = bin_range(r, ph, pw, PH, PW, H, W);
@@ -175,6 +170,68 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_nhwc(
         arow[c + v] = at[v];
       }
     }
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void moi_pool_fwd_nhwc(
+    const float* __restrict__ in, const float* __restrict__ rois,
+    const unsigned* __restrict__ cell_bits, const unsigned* __restrict__ roi_bits,
+    float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, int M, int words,
+    float scale, int PH, int PW, const int* __restrict__ roi_level, int level) {
+  const int nbins = PH * PW;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= (long)M * nbins) return;
+  if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level
+  const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
+  moi_pool_wave<VEC>(in, rois, cell_bits, roi_bits, out, argmax, C, H, W, words, scale, PH, PW, n, bin,
+                     threadIdx.x & 63);
+}
+
+// All FPN levels in one launch: each roi reads the map of its own level.
+constexpr int kMaxLevels = 8;
+struct MoiLevels {
+  const float* in[kMaxLevels];
+  float* gin[kMaxLevels];
+  const unsigned* cell[kMaxLevels];
+  int H[kMaxLevels], W[kMaxLevels];
+  float scale[kMaxLevels];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void moi_pool_fwd_levels(
+    const MoiLevels lv, const float* __restrict__ rois, const unsigned* __restrict__ roi_bits,
+    float* __restrict__ out, int* __restrict__ argmax, int C, int M, int words, int PH, int PW,
+    const int* __restrict__ roi_level, int nlevels) {
+  const int nbins = PH * PW;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= (long)M * nbins) return;
+  const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
+  const int l = roi_level[n];
+  if ((unsigned)l >= (unsigned)nlevels) return;
+  moi_pool_wave<VEC>(lv.in[l], rois, lv.cell[l], roi_bits, out, argmax, C, lv.H[l], lv.W[l], words, lv.scale[l],
+                     PH, PW, n, bin, threadIdx.x & 63);
+}
+
+// grad_input[level(n)][b, argmax, c] += grad[n, bin, c]: a wavefront per (roi, bin).
+__global__ __launch_bounds__(256) void moi_pool_bwd_levels(
+    const MoiLevels lv, const float* __restrict__ grad, const float* __restrict__ rois,
+    const int* __restrict__ argmax, int C, int M, int nbins, const int* __restrict__ roi_level, int nlevels) {
+  const int lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= (long)M * nbins) return;
+  const int n = (int)(wave / nbins);
+  const int l = roi_level[n];
+  if ((unsigned)l >= (unsigned)nlevels) return;
+  const int b = (int)rois[(size_t)n * 5];
+  float* __restrict__ g = lv.gin[l] + (size_t)b * lv.H[l] * lv.W[l] * C;
+  const float* __restrict__ src = grad + (size_t)wave * C;
+  const int* __restrict__ arg = argmax + (size_t)wave * C;
+  // one channel per lane: neighbouring channels mostly share their winning cell, so a wave-instruction's 64
+  // atomics land in a few contiguous 256-byte runs (the shape the L2 atomic units take at full rate)
+  for (int c = lane; c < C; c += 64) {
+    const int a = arg[c];
+    if (a != -1) atomicAdd(g + (size_t)a * C + c, src[c]);
   }
 }
 
@@ -410,6 +467,78 @@ int jtsm_moi_mask_f32(const float* rois, const int32_t* oh_labels, const int32_t
   hipLaunchKernelGGL(moi_mask_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, rois, k.cell,
                      k.roi, mois, H, W, total, bit_words(L), spatial_scale);
   JTSM_CHECK_LAUNCH("moi_mask");
+  return JTSM_OK;
+}
+
+/* All FPN levels in one launch (what ROIPooler does for MOIPool, detectron2/modeling/poolers.py:193-250 with
+ * wsl/layers/moi_pool.py): inputs[l] / grad_inputs[l] are (B,H[l],W[l],C) NHWC maps, roi_level[n] in
+ * [0,nlevels) picks the map of roi n.  workspace: jtsm_moi_pool_levels_workspace_bytes. */
+size_t jtsm_moi_pool_levels_workspace_bytes(int B, const int* H, const int* W, int nlevels, int M, int L) {
+  if (B < 0 || M < 0 || L < 0 || nlevels < 0 || nlevels > kMaxLevels || !H || !W) return 0;
+  size_t total = 16 + (((size_t)M * bit_words(L) * sizeof(unsigned) + 15) & ~(size_t)15);
+  for (int l = 0; l < nlevels; ++l)
+    total += (((size_t)B * H[l] * W[l] * bit_words(L) * sizeof(unsigned)) + 15) & ~(size_t)15;
+  return total;
+}
+
+int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, const int* W, const float* scales,
+                                     int nlevels, const float* rois, const int32_t* roi_level,
+                                     const int32_t* oh_labels, const int32_t* superpixels, float* output,
+                                     int32_t* argmax, void* workspace, int B, int C, int M, int L, int Hs, int Ws,
+                                     int pooled_h, int pooled_w, void* stream) {
+  JTSM_REQUIRE(nlevels > 0 && nlevels <= kMaxLevels && inputs && H && W && scales, "moi_pool levels: bad level table");
+  JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && L >= 0 && pooled_h > 0 && pooled_w > 0, "moi_pool levels: negative size");
+  if ((long)M * C == 0) return JTSM_OK;
+  JTSM_REQUIRE(rois && roi_level && oh_labels && superpixels && output && argmax && workspace,
+               "moi_pool levels: null pointer");
+  JTSM_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && L > 0 && C % 4 == 0, "moi_pool levels: empty map / C %% 4 != 0");
+  JTSM_REQUIRE(((uintptr_t)workspace & 15) == 0, "moi_pool levels: workspace must be 16-byte aligned");
+  hipStream_t st = as_stream(stream);
+  const int words = bit_words(L);
+  char* w = reinterpret_cast<char*>(workspace);
+  unsigned* roi_bits = reinterpret_cast<unsigned*>(w);
+  w += (((size_t)M * words * sizeof(unsigned)) + 15) & ~(size_t)15;
+  MoiLevels lv = {};
+  for (int l = 0; l < nlevels; ++l) {
+    JTSM_REQUIRE(inputs[l] && H[l] > 0 && W[l] > 0 && ((uintptr_t)inputs[l] & 15) == 0, "moi_pool levels: bad level %d", l);
+    lv.in[l] = inputs[l]; lv.H[l] = H[l]; lv.W[l] = W[l]; lv.scale[l] = scales[l];
+    unsigned* cell = reinterpret_cast<unsigned*>(w);
+    lv.cell[l] = cell;
+    w += (((size_t)B * H[l] * W[l] * words * sizeof(unsigned)) + 15) & ~(size_t)15;
+    const long cells = (long)B * H[l] * W[l];
+    hipLaunchKernelGGL(moi_cell_bits_kernel, dim3(ceil_div(cells, 4)), dim3(256), 4 * words * sizeof(unsigned), st,
+                       superpixels, cell, B, H[l], W[l], Hs, Ws, L, words);
+  }
+  hipLaunchKernelGGL(moi_roi_bits_kernel, dim3(ceil_div((long)M * words, 256)), dim3(256), 0, st, oh_labels, roi_bits,
+                     (long)M * words, L, words);
+  const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
+  hipLaunchKernelGGL(moi_pool_fwd_levels<4>, dim3(blocks), dim3(256), 0, st, lv, rois, roi_bits, output, argmax, C, M,
+                     words, pooled_h, pooled_w, roi_level, nlevels);
+  JTSM_CHECK_LAUNCH("moi_pool forward levels");
+  return JTSM_OK;
+}
+
+int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                      const int32_t* argmax, float* const* grad_inputs, const int* H, const int* W,
+                                      int nlevels, int B, int C, int M, int pooled_h, int pooled_w, void* stream) {
+  JTSM_REQUIRE(nlevels > 0 && nlevels <= kMaxLevels && grad_inputs && H && W, "moi_pool levels backward: bad level table");
+  JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0 && C % 4 == 0,
+               "moi_pool levels backward: bad sizes (C %% 4 must be 0)");
+  hipStream_t st = as_stream(stream);
+  MoiLevels lv = {};
+  for (int l = 0; l < nlevels; ++l) {
+    lv.gin[l] = grad_inputs[l]; lv.H[l] = H[l]; lv.W[l] = W[l];
+    if (!grad_inputs[l]) continue;   // a level whose gradient is not wanted
+    JTSM_CHECK_HIP(hipMemsetAsync(grad_inputs[l], 0, (size_t)B * H[l] * W[l] * C * sizeof(float), st));
+  }
+  if ((long)M * C == 0) return JTSM_OK;
+  JTSM_REQUIRE(grad && rois && roi_level && argmax, "moi_pool levels backward: null pointer");
+  for (int l = 0; l < nlevels; ++l)
+    JTSM_REQUIRE(grad_inputs[l], "moi_pool levels backward: every level needs a gradient buffer");
+  const int nbins = pooled_h * pooled_w;
+  hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(ceil_div((long)M * nbins, 4)), dim3(256), 0, st, lv, grad, rois, argmax,
+                     C, M, nbins, roi_level, nlevels);
+  JTSM_CHECK_LAUNCH("moi_pool backward levels");
   return JTSM_OK;
 }
 

@@ -93,6 +93,7 @@ _PLANES_MAX = 4096
 
 def planes_clear():
     _PLANES.clear()
+    refresh_weight_planes()
 
 
 def planes_put(t, buf):
@@ -110,6 +111,85 @@ def planes_of(t):
     buf = _split(t)
     planes_put(t, buf)
     return buf
+
+
+# Weight planes live across steps: a weight is re-split only when its version counter has moved (the
+# optimizer's in-place update), frozen weights never again.  At the start of a step (planes_clear) every stale
+# entry is refreshed by ONE launch per form (straight / transposed+scaled) instead of ~150 small ones.
+class _WEntry(object):
+    __slots__ = ("w", "scale", "transposed", "buf", "version")
+
+
+_WPLANES = {}
+_WTABLES = {}   # (transposed, tuple of entry keys) -> (device table, blocks): rebuilt only when the stale set changes
+
+
+def _cacheable_weight(w):
+    base = w._base if w._base is not None else w
+    return base.is_leaf and (w.dim() != 4 or w.permute(0, 2, 3, 1).is_contiguous())
+
+
+def _weight_planes(w, transposed=False, scale=None):
+    """Planes of a weight ([out][taps][in], or transposed+row-scaled for the data gradient), cached by version."""
+    if not _cacheable_weight(w):
+        return _split_transposed(w, scale) if transposed else _split(w)
+    key = (w.data_ptr(), w.numel(), transposed, scale.data_ptr() if scale is not None else 0)
+    e = _WPLANES.get(key)
+    if e is not None and e.version == w._version:
+        return e.buf
+    if e is None:
+        if len(_WPLANES) >= 2048:   # (entries pin their weights; a process that keeps building models starts over)
+            _WPLANES.clear()
+            _WTABLES.clear()
+        e = _WEntry()
+        e.w, e.scale, e.transposed = w.detach(), scale, transposed
+        e.buf = _planes_buf(w.numel(), w.device)
+        _WPLANES[key] = e
+    hi, lo = _hl(e.buf)
+    lib = L.lib()
+    if transposed:
+        o, i, kh, kw = w.shape
+        L.check(lib.jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(scale), hi, lo, o, kh * kw, i, L.stream()),
+                "split_bf16_transposed")
+    else:
+        L.check(lib.jtsm_split_bf16_f32(L.ptr(w), hi, lo, C.c_long(w.numel()), L.stream()), "split_bf16")
+    e.version = w._version
+    return e.buf
+
+
+def refresh_weight_planes():
+    """Re-split every cached weight whose version moved, one launch per form."""
+    if MATH != "bf16x3" or not _WPLANES:
+        return
+    for transposed in (False, True):
+        stale = [(k, e) for k, e in _WPLANES.items() if e.transposed == transposed and e.version != e.w._version]
+        if not stale:
+            continue
+        tkey = (transposed, tuple(k for k, _ in stale))
+        tab = _WTABLES.get(tkey)
+        if tab is None:
+            rows, blocks = [], 0
+            for _, e in stale:
+                hi = e.buf.data_ptr()
+                lo = hi + e.buf.numel()
+                if transposed:
+                    o, i, kh, kw = e.w.shape
+                    nb = ((i + 31) // 32) * ((o + 31) // 32) * kh * kw
+                    rows.append([e.w.data_ptr(), hi, lo, e.scale.data_ptr() if e.scale is not None else 0, blocks, o,
+                                 kh * kw, i])
+                else:
+                    nb = (e.w.numel() + 2047) // 2048
+                    rows.append([e.w.data_ptr(), hi, lo, 0, blocks, e.w.numel(), 0, 0])
+                blocks += nb
+            dev = stale[0][1].w.device
+            tab = (torch.tensor(rows, dtype=torch.int64).to(dev), blocks)
+            if len(_WTABLES) > 8:
+                _WTABLES.clear()
+            _WTABLES[tkey] = tab
+        L.check(L.lib().jtsm_split_bf16_multi_f32(L.ptr(tab[0]), len(stale), C.c_long(tab[1]), int(transposed),
+                                                  L.stream()), "split_bf16_multi")
+        for _, e in stale:
+            e.version = e.w._version
 
 
 # Per-shape launch facts (the ctypes shape struct, output size, FLOPs, workspace sizes, bf16x3 eligibility)
@@ -238,7 +318,7 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
     lib = L.lib()
     if MATH == "bf16x3" and pl.x3[0]:
         xh, xl = _hl(planes_of(x))
-        wbuf = _split(w)
+        wbuf = _weight_planes(w)
         wh, wl = _hl(wbuf)
         ybuf = _planes_buf(y.numel(), y.device) if (emit_planes and s.out_c % 8 == 0) else None
         yh, yl = _hl(ybuf)
@@ -270,7 +350,7 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     lib = L.lib()
     if MATH == "bf16x3" and pl.x3[1]:
         gh, gl = _hl(planes_of(dy))
-        wbuf = _split_transposed(w, kscale)   # the per-row scale rides along in the transposing split
+        wbuf = _weight_planes(w, True, kscale)   # the per-row scale rides along in the transposing split
         wh, wl = _hl(wbuf)
         L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
             gh, gl, wh, wl, L.ptr(dx), pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws), C.c_size_t(nbytes),

@@ -13,6 +13,8 @@ returned for all boxes.
 import math
 from typing import List
 
+import ctypes as C
+
 import torch
 from torch import nn
 from torch.autograd import Function
@@ -89,22 +91,29 @@ class _AlignLevels(Function):
 
 
 class _MOILevels(Function):
+    """MOIPool over all FPN levels in one launch each way (csrc/moi_pool.hip: moi_pool_fwd_levels / _bwd_levels)."""
+
     @staticmethod
     def forward(ctx, rois, roi_level, res, scales, oh_labels, superpixels, *feats):
         feats = [_feat(f) for f in feats]
-        M, C = rois.shape[0], feats[0].shape[1]
+        M, Cc = rois.shape[0], feats[0].shape[1]
         Lw = oh_labels.shape[1]
+        nl = len(feats)
+        B = feats[0].shape[0]
         # every roi is on exactly one level, whose kernel writes all of its bins (values and argmax)
-        out = torch.empty((M, C, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)
-        arg = torch.empty((M, C, res, res), dtype=torch.int32, device=rois.device, memory_format=CL)
+        out = torch.empty((M, Cc, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)
+        arg = torch.empty((M, Cc, res, res), dtype=torch.int32, device=rois.device, memory_format=CL)
         lib = L.lib()
-        for lvl, (f, sc) in enumerate(zip(feats, scales)):
-            B, _, H, W = f.shape
-            ws = torch.empty(lib.jtsm_moi_pool_workspace_bytes(B, H, W, M, Lw), dtype=torch.uint8, device=f.device)
-            L.check(lib.jtsm_moi_pool_forward_level_f32(
-                L.ptr(f), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(oh_labels), L.ptr(superpixels), L.ptr(out),
-                L.ptr(arg), L.ptr(ws), B, C, H, W, M, Lw, superpixels.shape[1], superpixels.shape[2], L.f32(sc),
-                res, res, L.stream()), "moi_pool_forward_level")
+        Hs = (C.c_int * nl)(*[f.shape[2] for f in feats])
+        Ws = (C.c_int * nl)(*[f.shape[3] for f in feats])
+        sc = (C.c_float * nl)(*[float(x) for x in scales])
+        ptrs = (C.c_void_p * nl)(*[f.data_ptr() for f in feats])
+        ws = torch.empty(lib.jtsm_moi_pool_levels_workspace_bytes(B, Hs, Ws, nl, M, Lw), dtype=torch.uint8,
+                         device=rois.device)
+        L.check(lib.jtsm_moi_pool_forward_levels_f32(
+            ptrs, Hs, Ws, sc, nl, L.ptr(rois), L.ptr(roi_level), L.ptr(oh_labels), L.ptr(superpixels), L.ptr(out),
+            L.ptr(arg), L.ptr(ws), B, Cc, M, Lw, superpixels.shape[1], superpixels.shape[2], res, res, L.stream()),
+            "moi_pool_forward_levels")
         ctx.save_for_backward(rois, roi_level, arg)
         ctx.cfg = (res, [tuple(f.shape) for f in feats])
         ctx.mark_non_differentiable(arg)
@@ -116,17 +125,16 @@ class _MOILevels(Function):
         rois, roi_level, arg = ctx.saved_tensors
         res, shapes = ctx.cfg
         g = g.contiguous(memory_format=CL)
-        grads = []
-        for lvl, shape in enumerate(shapes):
-            if not ctx.needs_input_grad[6 + lvl]:
-                grads.append(None)
-                continue
-            B, C, H, W = shape
-            gi = torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
-            L.check(L.lib().jtsm_moi_pool_backward_level_f32(
-                L.ptr(g), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(arg), L.ptr(gi), B, C, H, W, rois.shape[0],
-                res, res, L.stream()), "moi_pool_backward_level")
-            grads.append(gi)
+        nl = len(shapes)
+        B, Cc = shapes[0][0], shapes[0][1]
+        grads = [torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL) for shape in shapes]
+        Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
+        Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
+        ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads])
+        L.check(L.lib().jtsm_moi_pool_backward_levels_f32(
+            L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, nl, B, Cc, rois.shape[0], res, res,
+            L.stream()), "moi_pool_backward_levels")
+        grads = [gi if ctx.needs_input_grad[6 + lvl] else None for lvl, gi in enumerate(grads)]
         return (None, None, None, None, None, None, *grads)
 
 
