@@ -45,6 +45,15 @@ const char* jtsm_version(void);
 /* Number of visible HIP devices (<0 on error).  Does not create a context. */
 int jtsm_device_count(void);
 
+/* Launch timing for measurement harnesses: thin hipEvent wrappers, and a hook that records `event` right after
+ * the next contraction kernel launched by the calling thread (before its split-K finishing pass, if any) — the
+ * kernel's own duration, as rocprofv3 reports it, without a second process. */
+void* jtsm_event_create(void);
+int jtsm_event_record(void* event, void* stream);
+int jtsm_event_elapsed_ms(void* start, void* stop, float* ms);
+void jtsm_event_destroy(void* event);
+void jtsm_conv_set_mid_event(void* event);
+
 /* ---------------------------------------------------------------------------
  * ROIAlign — replaces detectron2/layers/csrc/ROIAlign/ROIAlign.h:7-27
  *   ROIAlign_forward(input, rois, spatial_scale, pooled_h, pooled_w, sampling_ratio, aligned)
@@ -230,6 +239,11 @@ int jtsm_split_bf16_transposed_f32(const float* w, const float* row_scale, uint1
  * first_block is the running sum of those counts (first record 0), `blocks` their total. */
 int jtsm_split_bf16_multi_f32(const void* table, int entries, long blocks, int transposed, void* stream);
 int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role);
+/* What a bf16x3 call of this shape launches (given the advertised workspace): the template arguments of
+ * igemm_x3_kernel<role,WM,WN,TM,TN,NBUF> (role 0/1) or igemm_x3_wgrad_kernel<WM,WN,TM,TN,NBUF> (role 2) —
+ * WM x WN wavefronts of TM x TN 32x32 MFMA tiles — and the number of K slices. */
+int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, int* tm, int* tn, int* nbuf,
+                          int* splits);
 /* y_hi / y_lo (both or neither; needs out_c % 4 == 0): the planes of the finished output y, written by the
  * epilogue for a following bf16x3 contraction — saves that layer's jtsm_split_bf16_f32 pass. */
 int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,

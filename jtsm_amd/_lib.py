@@ -28,6 +28,9 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.jtsm_last_error.restype = C.c_char_p
         _lib.jtsm_version.restype = C.c_char_p
+        _lib.jtsm_event_create.restype = C.c_void_p
+        _lib.jtsm_event_destroy.restype = None
+        _lib.jtsm_conv_set_mid_event.restype = None
         _lib.jtsm_moi_pool_workspace_bytes.restype = C.c_size_t
         for name in ("jtsm_mil_workspace_bytes", "jtsm_oicr_workspace_bytes", "jtsm_conv_workspace_bytes",
                      "jtsm_group_norm_workspace_bytes", "jtsm_semseg_ce_workspace_bytes",

@@ -851,6 +851,17 @@ inline int plan_splits(int ntiles, int ktiles, int target = 768) {
   return s < 1 ? 1 : s;
 }
 
+// Timing hook (bench.py's roofline leg): an event handed in through jtsm_conv_set_mid_event is recorded right
+// after the NEXT contraction kernel of this thread is launched — before any split-K finishing pass — so the
+// caller can time that kernel alone, as rocprofv3 reports it.
+static thread_local hipEvent_t g_mid_event = nullptr;
+inline void record_mid(hipStream_t st) {
+  if (g_mid_event) {
+    (void)hipEventRecord(g_mid_event, st);
+    g_mid_event = nullptr;
+  }
+}
+
 inline int finish_split(const Params& p, int splits, hipStream_t st, int scale_by_row = 0) {
   const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
                    (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
@@ -875,6 +886,7 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
     else if (dma1) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, 1), dim3(256), 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, 1), dim3(256), 0, st, p);
     JTSM_CHECK_LAUNCH("igemm");
+    record_mid(st);
     return JTSM_OK;
   }
   p.ktiles_per_split = ceil_div(ktiles, splits);
@@ -884,6 +896,7 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
   else if (dma1) hipLaunchKernelGGL((igemm_dma_kernel<ROLE, BM, BN, 1>), dim3(ntiles, splits), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm split-K");
+  record_mid(st);
   return finish_split(p, splits, st);
 }
 
@@ -899,6 +912,7 @@ int launch(const Params& p, int splits, hipStream_t st) {
   else
     hipLaunchKernelGGL((igemm_kernel<ROLE, BM, BN>), dim3(ntiles, splits), dim3(256), 0, st, p);
   JTSM_CHECK_LAUNCH("igemm");
+  record_mid(st);
   return JTSM_OK;
 }
 
@@ -1259,6 +1273,7 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
   if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
   else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
+  record_mid(st);
   if (splits > 1) return finish_split(p, splits, st, 1);
   return JTSM_OK;
 }
@@ -1275,5 +1290,46 @@ int jtsm_split_bf16_multi_f32(const void* table, int entries, long blocks, int t
   JTSM_CHECK_LAUNCH("split_bf16_multi");
   return JTSM_OK;
 }
+
+/* What a bf16x3 call of this shape launches (assuming the advertised workspace): the template arguments of
+ * igemm_x3_kernel<role, WM, WN, TM, TN, NBUF> / igemm_x3_wgrad_kernel<WM, WN, TM, TN, NBUF> and the K slices. */
+int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, int* tm, int* tn, int* nbuf,
+                          int* splits) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  Params p = {};
+  p.s = to_shape(s);
+  JTSM_REQUIRE(p.s.Ho > 0 && p.s.Wo > 0, "conv: kernel larger than padded input");
+  JTSM_REQUIRE(role >= 0 && role <= 2 && x3_eligible(role, p.s), "conv_bf16x3_plan: shape not eligible in this role");
+  int cfg[4] = {2, 2, 2, 2}, nb = 2, sp = 1;
+  if (role == WGRAD) {
+    p.M = p.s.Cout; p.N = p.s.KH * p.s.KW * p.s.Cin; p.K = p.s.Bn * p.s.Ho * p.s.Wo;
+    if (x3_wgrad_big(p)) { cfg[0] = 4; cfg[1] = 2; cfg[2] = 2; cfg[3] = 4; }
+    sp = p.K > 0 ? x3_wgrad_splits(p) : 1;
+  } else {
+    if (role == FWD) { p.M = p.s.Bn * p.s.Ho * p.s.Wo; p.N = p.s.Cout; p.K = p.s.KH * p.s.KW * p.s.Cin; }
+    else {
+      p.M = p.s.Bn * p.s.H * p.s.W; p.N = p.s.Cin; p.K = p.s.KH * p.s.KW * p.s.Cout;
+      if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1) p.M = p.s.Bn * p.s.Ho * p.s.Wo;
+    }
+    const int c = x3_tile_choice(p);
+    if (c == 1) { cfg[0] = 4; cfg[1] = 1; }
+    if (c == 2) { cfg[0] = 4; cfg[1] = 2; cfg[2] = 2; cfg[3] = 4; }
+    sp = x3_wanted_splits(p);
+    const int ktiles = ceil_div(p.K, XBK);
+    const int kps = ceil_div(ktiles, sp);
+    sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
+    if (c != 2 && ceil_div(ktiles, sp) <= 4) nb = 1;
+  }
+  if (wm) *wm = cfg[0];
+  if (wn) *wn = cfg[1];
+  if (tm) *tm = cfg[2];
+  if (tn) *tn = cfg[3];
+  if (nbuf) *nbuf = nb;
+  if (splits) *splits = sp;
+  return JTSM_OK;
+}
+
+void jtsm_conv_set_mid_event(void* event) { g_mid_event = reinterpret_cast<hipEvent_t>(event); }
 
 }  // extern "C"

@@ -604,6 +604,7 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
   else
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2>), grid, dim3(NT), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3");
+  record_mid(st);
   if (splits > 1) return finish_split(p, splits, st);
   return JTSM_OK;
 }

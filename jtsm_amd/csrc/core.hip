@@ -34,4 +34,25 @@ int jtsm_device_count(void) {
   return n;
 }
 
+/* ---- launch timing (bench.py's roofline leg) ---- */
+void* jtsm_event_create(void) {
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) { jtsm::fail(JTSM_ELAUNCH, "hipEventCreate failed"); return nullptr; }
+  return e;
+}
+int jtsm_event_record(void* event, void* stream) {
+  JTSM_REQUIRE(event, "event_record: null event");
+  JTSM_CHECK_HIP(hipEventRecord(reinterpret_cast<hipEvent_t>(event), reinterpret_cast<hipStream_t>(stream)));
+  return JTSM_OK;
+}
+int jtsm_event_elapsed_ms(void* start, void* stop, float* ms) {
+  JTSM_REQUIRE(start && stop && ms, "event_elapsed_ms: null argument");
+  JTSM_CHECK_HIP(hipEventSynchronize(reinterpret_cast<hipEvent_t>(stop)));
+  JTSM_CHECK_HIP(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+  return JTSM_OK;
+}
+void jtsm_event_destroy(void* event) {
+  if (event) (void)hipEventDestroy(reinterpret_cast<hipEvent_t>(event));
+}
+
 }  // extern "C"

@@ -18,7 +18,7 @@ from .. import _lib as L
 CL = torch.channels_last
 
 # Optional per-launch timing (bench.py's roofline leg): when a list, every contraction launch appends
-# (kernel variant, algorithmic FLOPs, start event, stop event), recorded on the launch stream.
+# (kernel variant, algorithmic FLOPs, LaunchSpan, shape); events are recorded on the launch stream.
 LAUNCH_LOG = None
 
 
@@ -233,18 +233,58 @@ def _scratch(nbytes, device):
 
 
 def _x3_variant(s, role):
-    n = s.out_c if role == 0 else s.in_c
-    return "igemm_x3_kernel<%s,%s,2>" % (_ROLE_NAME[role], "256,64" if n <= 64 else "128,128")
+    """Exact bf16x3 kernel instantiation for this call (only looked up while LAUNCH_LOG is recording)."""
+    if LAUNCH_LOG is None:
+        return None
+    v = [C.c_int() for _ in range(6)]
+    L.check(L.lib().jtsm_conv_bf16x3_plan(C.byref(s), role, *[C.byref(x) for x in v]), "conv_bf16x3_plan")
+    wm, wn, tm, tn, nbuf, _ = [x.value for x in v]
+    if role == 2:
+        return "igemm_x3_wgrad_kernel<%d,%d,%d,%d,%d>" % (wm, wn, tm, tn, nbuf)
+    return "igemm_x3_kernel<%s,%d,%d,%d,%d,%d>" % (_ROLE_NAME[role], wm, wn, tm, tn, nbuf)
+
+
+class LaunchSpan(object):
+    """hipEvents around one contraction call: before, right after its main kernel (library hook), after the call."""
+    __slots__ = ("a", "mid", "b")
+
+    def __init__(self):
+        lib = L.lib()
+        self.a, self.mid, self.b = lib.jtsm_event_create(), lib.jtsm_event_create(), lib.jtsm_event_create()
+
+    def _ms(self, x, y):
+        out = C.c_float()
+        return out.value if L.lib().jtsm_event_elapsed_ms(C.c_void_p(x), C.c_void_p(y), C.byref(out)) == 0 else None
+
+    def kernel_ms(self):
+        """The contraction kernel alone (falls back to the whole call if the hook did not fire)."""
+        ms = self._ms(self.a, self.mid)
+        return ms if ms is not None else self._ms(self.a, self.b)
+
+    def call_ms(self):
+        return self._ms(self.a, self.b)
+
+    def __del__(self):
+        try:
+            lib = L.lib()
+            for e in (self.a, self.mid, self.b):
+                lib.jtsm_event_destroy(C.c_void_p(e))
+        except Exception:
+            pass
 
 
 def _timed(variant, flops, call, shape=None):
     if LAUNCH_LOG is None:
         return call()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    lib = L.lib()
+    span = LaunchSpan()
+    st = L.stream()
+    lib.jtsm_event_record(C.c_void_p(span.a), st)
+    lib.jtsm_conv_set_mid_event(C.c_void_p(span.mid))
     rc = call()
-    b.record()
-    LAUNCH_LOG.append((variant, flops, a, b, shape))
+    lib.jtsm_conv_set_mid_event(None)
+    lib.jtsm_event_record(C.c_void_p(span.b), st)
+    LAUNCH_LOG.append((variant, flops, span, shape))
     return rc
 
 
@@ -376,7 +416,7 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
             out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL)
         nbytes = pl.ws[2]
         ws = _scratch(nbytes, x.device)
-        L.check(_timed("igemm_x3_wgrad_kernel<2>", pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
+        L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
             gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws), C.c_size_t(nbytes),
             L.stream()), pl.desc), "conv2d_backward_weight_bf16x3")
         return out

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Produce the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
+#   gpurun_out/art/bench.json, kernel_stats.csv, pmc/{fetch,write}, pmc_traffic.json, stock.json
+# Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch).
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+A=gpurun_out/art
+mkdir -p $A
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact > $A/pmc_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact > $A/pmc_write.log 2>&1 &&
+python tools/pmc_traffic.py $A/pmc profiles/pmc_traffic.json && cp profiles/pmc_traffic.json $A/pmc_traffic.json &&
+rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact > $A/prof_bench.json 2> $A/prof.log &&
+cp $A/prof/r_kernel_stats.csv $A/kernel_stats.csv &&
+python bench.py --steps 20 --warmup 5 > $A/bench.json 2> $A/bench.err &&
+python tools/stock_baseline.py > $A/stock.json 2> $A/stock.err
+echo "exit $?"; tail -c 600 $A/bench.json
