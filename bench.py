@@ -56,7 +56,7 @@ def build(device):
     return model
 
 
-def make_optimizer(model):
+def make_optimizer(model, fused=True):
     """SGD as the reference configures it (detectron2/solver/build.py:110-195 with the JTSM config's
     BASE_LR 0.01, WEIGHT_DECAY 5e-4, BIAS_LR_FACTOR 2, WEIGHT_DECAY_BIAS 0, momentum 0.9)."""
     decay, bias = [], []
@@ -66,8 +66,11 @@ def make_optimizer(model):
     # Random-init weights diverge within a few steps at the reference's BASE_LR (0.01), which would empty
     # the foreground set and silently shrink the work; the update arithmetic is kept, only lr is tiny.
     lr = 1e-7
-    return torch.optim.SGD([{"params": decay, "lr": lr, "weight_decay": 5e-4},
-                            {"params": bias, "lr": 2 * lr, "weight_decay": 0.0}], lr=lr, momentum=0.9)
+    groups = [{"params": decay, "lr": lr, "weight_decay": 5e-4}, {"params": bias, "lr": 2 * lr, "weight_decay": 0.0}]
+    if fused:   # the same update for every parameter in one launch (jtsm_amd/solver/build.py)
+        from jtsm_amd.solver import SGD
+        return SGD(groups, lr=lr, momentum=0.9)
+    return torch.optim.SGD(groups, lr=lr, momentum=0.9)
 
 
 def roofline_leg(step_fn):
@@ -202,7 +205,7 @@ def main():
                          "on v_mfma_f32_32x32x16_bf16 with fp32 accumulate; measured error <= 6e-6 relative per layer "
                          "against fp64 (bar 1e-4); everything else fp32. JTSM_CONV_MATH=f32 selects exact fp32 MFMA "
                          "(see `exact_fp32`)") if conv_math != "f32" else "exact fp32 MFMA contractions",
-                "torch_device_ops": ["mask BCE", "dropout", "SGD", "DDP all-reduce", "sort / gather glue"],
+                "torch_device_ops": ["mask BCE", "dropout", "DDP all-reduce", "sort / gather glue"],
                 "final_loss": round(loss_value, 5), "lr": 1e-7,
                 "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
             },

@@ -277,6 +277,12 @@ int jtsm_relu_backward_split_f32(const float* dy, const float* y, float* g, uint
 int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, void* stream);
 /* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);
+/* SGD with momentum over many tensors in ONE launch — torch.optim.SGD as detectron2/solver/build.py:110-195
+ * configures it (dampening 0, no nesterov): d = g + wd*p; buf = first_step ? d : mu*buf + d; p -= lr*buf.
+ * table: device array of `entries` records of eight 64-bit words {param, grad, momentum_buffer, n, first_block,
+ * lr, weight_decay, momentum} (the three floats as their bit patterns in the low 32 bits); a record owns
+ * ceil(n / 1024) consecutive workgroups, first_block is the running sum, `blocks` the total. */
+int jtsm_sgd_momentum_multi_f32(const void* table, int entries, long blocks, int first_step, void* stream);
 
 
 /* NHWC spatial helpers, C % 4 == 0 (no reference source; torch ops at

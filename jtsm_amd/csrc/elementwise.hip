@@ -179,6 +179,45 @@ __global__ __launch_bounds__(256) void subsample2_kernel(const float4* __restric
   }
 }
 
+// ---- SGD with momentum over many tensors in one launch (torch.optim.SGD semantics: dampening 0, no nesterov;
+// detectron2/solver/build.py:110-195 builds exactly that).  Table rows are eight 64-bit words:
+// {param, grad, momentum buffer, n, first_block, lr (float bits), weight_decay (float bits), momentum (float bits)}.
+struct SgdEntry { float* p; const float* g; float* buf; long n; long first_block; long lr; long wd; long mu; };
+
+__device__ __forceinline__ float word_f32(long w) { return __int_as_float((int)w); }
+
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdEntry* __restrict__ tab, int nent, int first_step) {
+  int lo = 0, hi = nent - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].first_block <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const SgdEntry t = tab[lo];
+  const float lr = word_f32(t.lr), wd = word_f32(t.wd), mu = word_f32(t.mu);
+  const long base = ((long)blockIdx.x - t.first_block) * 1024 + threadIdx.x * 4;
+  if (base >= t.n) return;
+  if (base + 4 <= t.n && ((((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.buf) & 15) == 0)) {
+    float4 p = *reinterpret_cast<const float4*>(t.p + base);
+    const float4 g = *reinterpret_cast<const float4*>(t.g + base);
+    float4 b = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(t.buf + base);
+    const float d[4] = {g.x + wd * p.x, g.y + wd * p.y, g.z + wd * p.z, g.w + wd * p.w};
+    b.x = first_step ? d[0] : mu * b.x + d[0];
+    b.y = first_step ? d[1] : mu * b.y + d[1];
+    b.z = first_step ? d[2] : mu * b.z + d[2];
+    b.w = first_step ? d[3] : mu * b.w + d[3];
+    p.x -= lr * b.x; p.y -= lr * b.y; p.z -= lr * b.z; p.w -= lr * b.w;
+    *reinterpret_cast<float4*>(t.buf + base) = b;
+    *reinterpret_cast<float4*>(t.p + base) = p;
+  } else {
+    for (long i = base; i < t.n && i < base + 4; ++i) {
+      const float d = t.g[i] + wd * t.p[i];
+      const float b = first_step ? d : mu * t.buf[i] + d;
+      t.buf[i] = b;
+      t.p[i] -= lr * b;
+    }
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -302,6 +341,16 @@ int jtsm_subsample2_f32(const float* src, float* dst, int N, int H, int W, int C
   hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float4*)src,
                      (float4*)dst, N, H, W, C / 4, Ho, Wo, scatter);
   JTSM_CHECK_LAUNCH("subsample2");
+  return JTSM_OK;
+}
+
+int jtsm_sgd_momentum_multi_f32(const void* table, int entries, long blocks, int first_step, void* stream) {
+  JTSM_REQUIRE(entries >= 0 && blocks >= 0 && blocks < 2147483647L, "sgd_multi: bad sizes");
+  if (entries == 0 || blocks == 0) return JTSM_OK;
+  JTSM_REQUIRE(table && ((uintptr_t)table & 15) == 0, "sgd_multi: table must be a 16-byte aligned device pointer");
+  hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const SgdEntry*>(table), entries, first_step);
+  JTSM_CHECK_LAUNCH("sgd_multi");
   return JTSM_OK;
 }
 

@@ -132,3 +132,34 @@ def test_fused_mining_and_labelling_vs_oracle(cuda):
             assert torch.allclose(pg["boxes"][i, :things[i].numel()].cpu(), t["boxes"], rtol=1e-5, atol=1e-3)
             assert torch.allclose(pg["scores"][i, :things[i].numel()].cpu(), t["scores"], rtol=1e-4, atol=1e-7)
         r0 += n
+
+
+def test_fused_sgd_matches_torch_sgd(cuda):
+    """jtsm_amd.solver.SGD (one launch for all parameters) against torch.optim.SGD: three steps with momentum,
+    weight decay, two parameter groups, a channels_last 4-d weight and an odd-sized vector."""
+    from jtsm_amd.solver import SGD
+
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 32, 3, 3), (37,), (128, 64, 1, 1), (5, 7)]
+    ref = [torch.randn(s, generator=g) for s in shapes]
+    mine = [r.clone().to(cuda) for r in ref]
+    mine[0] = mine[0].contiguous(memory_format=torch.channels_last)
+    for t in ref + mine:
+        t.requires_grad_(True)
+    groups = lambda ps: [{"params": [ps[0], ps[2]], "lr": 0.05, "weight_decay": 5e-4},
+                         {"params": [ps[1], ps[3]], "lr": 0.1, "weight_decay": 0.0}]
+    o_ref = torch.optim.SGD(groups(ref), lr=0.05, momentum=0.9)
+    o_mine = SGD(groups(mine), lr=0.05, momentum=0.9)
+    for step in range(3):
+        for r, m in zip(ref, mine):
+            gr = torch.randn(r.shape, generator=g)
+            r.grad = gr.clone()
+            m.grad = gr.to(cuda)          # plain-contiguous gradient for the channels_last weight: copied to its layout
+        v = mine[0]._version
+        o_ref.step()
+        o_mine.step()
+        assert mine[0]._version > v      # the update is visible to version-keyed caches
+        for r, m in zip(ref, mine):
+            assert torch.allclose(m.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7), (step, tuple(r.shape))
+    sd = o_mine.state_dict()
+    assert len(sd["state"]) == 4 and "momentum_buffer" in next(iter(sd["state"].values()))

@@ -107,7 +107,7 @@ def main():
     dev = torch.device("cuda", 0)
     model = bench.build(dev)
     inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev)
-    opt = bench.make_optimizer(model)
+    opt = bench.make_optimizer(model, fused=False)
 
     def step():
         losses = model(inputs)
