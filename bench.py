@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 reference leg")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank code-path rehearsal on a single GPU: every rank uses device 0 and the gloo backend "
+                         "(not a measurement)")
     return ap.parse_args()
 
 
@@ -147,10 +150,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product path has no CPU fallback)")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     from jtsm_amd.engine import dp
-    dp.init_distributed("nccl", device)
+    dp.init_distributed("gloo" if args.rehearse_on_one_gpu else "nccl", device)
     assert world == args.gpus, "WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run" % (world, args.gpus)
 
     from jtsm_amd.utils.synthetic import synthetic_inputs
@@ -210,8 +215,11 @@ def main():
                 "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
             },
         }
-    if rank == 0 and not args.no_roofline:
-        out["roofline"] = roofline_leg(step)
+    if not args.no_roofline:
+        # every rank runs the extra (untimed) step — it contains the gradient all-reduce — rank 0 reports it
+        roof = roofline_leg(step)
+        if rank == 0:
+            out["roofline"] = roof
     if world == 1 and conv_math != "f32" and not args.no_exact:
         # the same step with exact fp32 MFMA contractions, for reference beside the headline
         conv_layers.set_math("f32")

@@ -469,6 +469,10 @@ class _ConvFused(Function):
             dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale)
         if bias_needs_grad and ctx.needs_input_grad[3]:
             db = channel_sum(g)
+        if dw is not None and dw.stride() != w.stride() and w.shape[2] == 1 and w.shape[3] == 1:
+            # 1x1 weights: OHWI and OIHW are the same bytes; hand the gradient back with the parameter's own
+            # strides (DDP bucket views and the fused SGD compare strides, not byte order)
+            dw = dw.as_strided(w.shape, w.stride())
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = g
         return dx, dw, None, db, dres, None, None, None, None, None, None
