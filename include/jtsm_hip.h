@@ -251,10 +251,13 @@ int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const
                                const jtsm_conv_shape* s, const float* scale, const float* bias,
                                const float* residual, int relu, void* workspace, size_t workspace_bytes,
                                void* stream);
+/* dx_hi / dx_lo (both or neither): planes of the finished dx (after accumulate / relu_mask) — with relu_mask =
+ * the previous layer's ReLU output this IS that layer's gated gradient, ready for its own two contractions. */
 int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
-                                     const uint16_t* wt_lo, float* dx, const jtsm_conv_shape* s,
-                                     const float* accumulate, const float* relu_mask, void* workspace,
-                                     size_t workspace_bytes, void* stream);
+                                     const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                     const jtsm_conv_shape* s, const float* accumulate,
+                                     const float* relu_mask, void* workspace, size_t workspace_bytes,
+                                     void* stream);
 /* role 2 (backward-weight) is eligible when in_c and out_c are multiples of 8; dy / x planes as above.
  * Unlike the fp32 kernel this one is DETERMINISTIC: each pixel slice writes a partial tile into the
  * workspace (jtsm_conv_bf16x3_wgrad_workspace_bytes, 16-byte aligned) and a fixed-order pass adds them;

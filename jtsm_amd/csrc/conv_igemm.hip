@@ -1163,9 +1163,9 @@ int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const
 }
 
 int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
-                                     const uint16_t* wt_lo, float* dx, const jtsm_conv_shape* s,
-                                     const float* accumulate, const float* relu_mask, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                     const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1184,9 +1184,17 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
                 reinterpret_cast<const __bf16*>(wt_hi), reinterpret_cast<const __bf16*>(wt_lo)};
   p.C = dx; p.ldc = p.N;
   p.e.residual = accumulate; p.e.mask = relu_mask;
+  JTSM_REQUIRE((dx_hi == nullptr) == (dx_lo == nullptr), "conv backward-data bf16x3: give both output planes or neither");
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
-  if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask) {
+  const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask;
+  if (dx_hi) {   // planes of the finished gradient (e.g. already gated by relu_mask) for the next layer's contractions
+    JTSM_REQUIRE(!scatter, "conv backward-data bf16x3: output planes are not produced by the strided 1x1 scatter path");
+    JTSM_REQUIRE(p.N % 4 == 0 && aligned16(dx) && aligned16(dx_hi) && aligned16(dx_lo),
+                 "conv backward-data bf16x3: output planes need in_c %% 4 == 0 and 16-byte aligned tensors");
+    p.out_hi = dx_hi; p.out_lo = dx_lo;
+  }
+  if (scatter) {
     JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
     p.scatter = 1; p.sc_Ho = p.s.Ho; p.sc_Wo = p.s.Wo; p.sc_H = p.s.H; p.sc_W = p.s.W; p.sc_stride = p.s.stride;
     p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;

@@ -375,7 +375,7 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
 
 
 def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, accumulate=None,
-                         relu_mask=None):
+                         relu_mask=None, emit_planes=False):
     _check(dy, w, kscale, accumulate, relu_mask)
     dy, w = _cl(dy), _cl(w)
     pl = _plan(x_shape, w.shape, stride, pad, dil)
@@ -392,9 +392,15 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         gh, gl = _hl(planes_of(dy))
         wbuf = _weight_planes(w, True, kscale)   # the per-row scale rides along in the transposing split
         wh, wl = _hl(wbuf)
+        scatter = s.kernel_h == 1 and s.kernel_w == 1 and s.pad == 0 and s.stride > 1 and accumulate is None and \
+            relu_mask is None
+        dbuf = _planes_buf(dx.numel(), dx.device) if (emit_planes and s.in_c % 8 == 0 and not scatter) else None
+        dh, dl = _hl(dbuf)
         L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
-            gh, gl, wh, wl, L.ptr(dx), pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc), "conv2d_backward_data_bf16x3")
+            gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_backward_data_bf16x3")
+        if dbuf is not None:
+            planes_put(dx, dbuf)
         return dx
     L.check(_timed(_variant(s, 1, kscale is not None), pl.flops, lambda: lib.jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), pl.ref, L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),

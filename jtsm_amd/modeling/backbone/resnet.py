@@ -10,9 +10,10 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ...layers.batch_norm import get_norm
+from ...layers.batch_norm import FrozenBatchNorm2d, get_norm
 from ...layers.blocks import CNNBlockBase
 from ...layers.elementwise import max_pool_3x3_s2
+from ...layers.fused_blocks import bottleneck_fused
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d
 from .backbone import Backbone
@@ -49,7 +50,20 @@ class BottleneckBlock(CNNBlockBase):
             if layer is not None:
                 _msra(layer)
 
+    def _fusable(self, x):
+        convs = [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
+        return (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and
+                all(isinstance(c.norm, FrozenBatchNorm2d) and c.bias is None for c in convs))
+
     def forward(self, x):
+        if self._fusable(x):
+            # one autograd node for the block: ReLU gates and the two-path sum ride in the data-gradient epilogues
+            sc = self.shortcut
+            return bottleneck_fused(
+                x, self.conv1.weight, self.conv1.norm.scale_bias(), self.conv2.weight, self.conv2.norm.scale_bias(),
+                self.conv3.weight, self.conv3.norm.scale_bias(), sc.weight if sc is not None else None,
+                sc.norm.scale_bias() if sc is not None else None, self.conv1.stride[0], self.conv2.stride[0],
+                self.conv2.padding[0], self.conv2.dilation[0], sc.stride[0] if sc is not None else 1)
         out = self.conv1(x)
         out = self.conv2(out)
         shortcut = self.shortcut(x) if self.shortcut is not None else x

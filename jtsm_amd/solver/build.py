@@ -58,7 +58,18 @@ class SGD(torch.optim.Optimizer):
                 blocks += (n + 1023) // 1024
                 device = p.device
         if rows:
-            table = torch.tensor(rows, dtype=torch.int64).to(device)
+            # table upload without stalling the host: pinned staging buffers (two, alternating: the copy of step t
+            # is long done before step t+2 rewrites its buffer) and an asynchronous copy on the launch stream
+            nwords = len(rows) * 8
+            st = self.__dict__.setdefault("_staging", {"host": [None, None], "dev": None, "turn": 0})
+            if st["dev"] is None or st["dev"].numel() < nwords or st["dev"].device != device:
+                st["host"] = [torch.empty(nwords, dtype=torch.int64).pin_memory() for _ in range(2)]
+                st["dev"] = torch.empty(nwords, dtype=torch.int64, device=device)
+            st["turn"] ^= 1
+            host = st["host"][st["turn"]]
+            host[:nwords].copy_(torch.tensor(rows, dtype=torch.int64).view(-1))
+            table = st["dev"][:nwords]
+            table.copy_(host[:nwords], non_blocking=True)
             L.check(L.lib().jtsm_sgd_momentum_multi_f32(L.ptr(table), len(rows), C.c_long(blocks), int(bool(first)),
                                                         L.stream()), "sgd_momentum_multi")
             torch.autograd.graph.increment_version(touched)   # updated behind autograd's back: say so
