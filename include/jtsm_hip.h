@@ -388,12 +388,15 @@ size_t jtsm_group_norm_workspace_bytes(int N, long HW, int C);
 int jtsm_group_norm_forward_f32(const float* x, const float* gamma, const float* beta, float* y,
                                 float* mean, float* rstd, void* workspace, int N, long HW, int C, int G,
                                 float eps, int relu, void* stream);
+/* dx_hi / dx_lo, y_hi / y_lo below (both or neither, nullable): bf16 planes of the result for a following
+ * bf16x3 contraction (see jtsm_split_bf16_f32). */
 int jtsm_group_norm_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta,
-                                 const float* mean, const float* rstd, float* dx, float* dgamma,
-                                 float* dbeta, void* workspace, int N, long HW, int C, int G, int relu,
-                                 void* stream);
+                                 const float* mean, const float* rstd, float* dx, uint16_t* dx_hi,
+                                 uint16_t* dx_lo, float* dgamma, float* dbeta, void* workspace, int N, long HW,
+                                 int C, int G, int relu, void* stream);
 /* y (N,2H,2W,C) <- x (N,H,W,C); backward is a gather (no atomics). */
-int jtsm_upsample_bilinear2x_forward_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int jtsm_upsample_bilinear2x_forward_f32(const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, int N, int H,
+                                         int W, int C, void* stream);
 int jtsm_upsample_bilinear2x_backward_f32(const float* gy, float* gx, int N, int H, int W, int C,
                                           void* stream);
 

@@ -9,7 +9,7 @@
 namespace jtsm {
 namespace {
 
-constexpr int GN_SLAB_ROWS = 1024;  // pixels per workgroup in the statistics passes
+constexpr int GN_SLAB_ROWS = 256;   // pixels per workgroup in the statistics passes (>= 2 workgroups per CU on the 256x256 map)
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -55,6 +55,21 @@ __global__ void gn_fold_kernel(const float2* __restrict__ part, float* __restric
   if (var < 0.0) var = 0.0;
   mean[n * G + g] = (float)mu;
   rstd[n * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// bf16 hi / lo planes of four values (what jtsm_split_bf16_f32 would make of them), for a bf16x3 consumer
+typedef __bf16 ss_bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void put_planes4(unsigned short* hi, unsigned short* lo, long i4, const float4& v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  ss_bf16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    h[e] = hh;
+    l[e] = (__bf16)(x[e] - (float)hh);
+  }
+  reinterpret_cast<ss_bf16x4*>(hi)[i4] = h;
+  reinterpret_cast<ss_bf16x4*>(lo)[i4] = l;
 }
 
 // y = relu?((x - mean) * rstd * gamma + beta)
@@ -162,6 +177,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ beta,
                                                            const float* __restrict__ s1,
                                                            const float* __restrict__ s2, float* __restrict__ dx,
+                                                           unsigned short* __restrict__ dx_hi,
+                                                           unsigned short* __restrict__ dx_lo,
                                                            long HW, int C, int G, int relu, long total4) {
   const int C4 = C / 4, cpg4 = C4 / G;
   const float inv_m = 1.f / ((float)HW * (float)(C / G));
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     o.z = rs * (ga.z * d.z - a - h.z * b);
     o.w = rs * (ga.w * d.w - a - h.w * b);
     st4(dx + i * 4, o);
+    if (dx_hi) put_planes4(dx_hi, dx_lo, i, o);
   }
 }
 
@@ -200,7 +218,9 @@ __device__ __forceinline__ Lerp lerp_of(int o, int n_src) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N,
+__global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      unsigned short* __restrict__ y_hi,
+                                                      unsigned short* __restrict__ y_lo, int N,
                                                       int H, int W, int C4, long total4) {
   const int Ho = 2 * H, Wo = 2 * W;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
@@ -222,6 +242,7 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ 
     o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
     o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
     st4(y + i * 4, o);
+    if (y_hi) put_planes4(y_hi, y_lo, i, o);
   }
 }
 
@@ -488,13 +509,15 @@ int jtsm_group_norm_forward_f32(const float* x, const float* gamma, const float*
 }
 
 int jtsm_group_norm_backward_f32(const float* x, const float* dy, const float* gamma, const float* beta,
-                                 const float* mean, const float* rstd, float* dx, float* dgamma, float* dbeta,
-                                 void* workspace, int N, long HW, int C, int G, int relu, void* stream) {
+                                 const float* mean, const float* rstd, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                 float* dgamma, float* dbeta, void* workspace, int N, long HW, int C, int G, int relu,
+                                 void* stream) {
   int rc = gn_check(N, HW, C, G);
   if (rc) return rc;
   if (N == 0) return JTSM_OK;
   JTSM_REQUIRE(x && dy && gamma && beta && mean && rstd && dx && dgamma && dbeta && workspace,
                "group_norm backward: null pointer");
+  JTSM_REQUIRE((dx_hi == nullptr) == (dx_lo == nullptr), "group_norm backward: give both output planes or neither");
   hipStream_t st = as_stream(stream);
   const int slabs = gn_slabs(HW);
   char* w = reinterpret_cast<char*>(workspace);
@@ -509,18 +532,20 @@ int jtsm_group_norm_backward_f32(const float* x, const float* dy, const float* g
                      s2, dgamma, dbeta, N, C, G, slabs);
   const long total4 = (long)N * HW * (C / 4);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, dy, mean, rstd, gamma, beta,
-                     s1, s2, dx, HW, C, G, relu, total4);
+                     s1, s2, dx, dx_hi, dx_lo, HW, C, G, relu, total4);
   JTSM_CHECK_LAUNCH("group_norm backward");
   return JTSM_OK;
 }
 
-int jtsm_upsample_bilinear2x_forward_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+int jtsm_upsample_bilinear2x_forward_f32(const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, int N, int H, int W,
+                                         int C, void* stream) {
   JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "upsample2x: bad sizes");
   const long total4 = (long)N * 2 * H * 2 * W * (C / 4);
   if (total4 == 0) return JTSM_OK;
   JTSM_REQUIRE(x && y, "upsample2x: null pointer");
-  hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, y, N, H, W, C / 4,
-                     total4);
+  JTSM_REQUIRE((y_hi == nullptr) == (y_lo == nullptr), "upsample2x forward: give both output planes or neither");
+  hipLaunchKernelGGL(up2_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, as_stream(stream), x, y, y_hi, y_lo, N, H, W,
+                     C / 4, total4);
   JTSM_CHECK_LAUNCH("upsample2x forward");
   return JTSM_OK;
 }

@@ -88,19 +88,25 @@ def split_bf16_transposed(w, row_scale=None):
 # Entries hold the tensor (detached), so its memory cannot be recycled under a live key; the model clears
 # the cache at the start of every forward (planes_clear).
 _PLANES = {}
-_PLANES_MAX = 4096
+_PLANES_MAX_BYTES = 16 << 30   # entries pin their tensors: a caller that never starts a new step is bounded here
+_planes_bytes = 0
 
 
 def planes_clear():
+    global _planes_bytes
     _PLANES.clear()
+    _planes_bytes = 0
     refresh_weight_planes()
 
 
 def planes_put(t, buf):
-    if len(_PLANES) >= _PLANES_MAX:
+    global _planes_bytes
+    if _planes_bytes > _PLANES_MAX_BYTES:
         _PLANES.clear()
+        _planes_bytes = 0
     # planes mirror the flat memory of a DENSE tensor, so any dense view of the same bytes shares them
     _PLANES[(t.data_ptr(), t.numel())] = (t.detach(), t._version, buf)
+    _planes_bytes += 8 * t.numel()
 
 
 def planes_of(t):

@@ -158,13 +158,19 @@ class _GroupNormReLU(torch.autograd.Function):
         n, c, h, w = x.shape
         dy = dy.contiguous(memory_format=CL)
         lib = L.lib()
+        from . import conv
         dx = torch.empty_like(x)
         dg, db = torch.empty_like(gamma), torch.empty_like(beta)
         ws = torch.empty(lib.jtsm_group_norm_workspace_bytes(n, C.c_long(h * w), c), dtype=torch.uint8, device=x.device)
+        # dx is the output gradient of the convolution in front of this norm: hand it its bf16 planes as well
+        buf = conv._planes_buf(dx.numel(), dx.device) if (conv.MATH == "bf16x3" and c % 8 == 0) else None
+        hi, lo = conv._hl(buf)
         L.check(lib.jtsm_group_norm_backward_f32(L.ptr(x), L.ptr(dy), L.ptr(gamma), L.ptr(beta), L.ptr(mean),
-                                                 L.ptr(rstd), L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(ws), n,
+                                                 L.ptr(rstd), L.ptr(dx), hi, lo, L.ptr(dg), L.ptr(db), L.ptr(ws), n,
                                                  C.c_long(h * w), c, groups, int(relu), L.stream()),
                 "group_norm_backward")
+        if buf is not None:
+            conv.planes_put(dx, buf)
         return dx, dg, db, None, None, None
 
 
@@ -178,8 +184,15 @@ class _UpBilinear2x(torch.autograd.Function):
     def forward(ctx, x):
         x = _cl4(x)
         n, c, h, w = x.shape
+        from . import conv
         y = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=CL)
-        L.check(L.lib().jtsm_upsample_bilinear2x_forward_f32(L.ptr(x), L.ptr(y), n, h, w, c, L.stream()), "upsample2x")
+        # the up-sampled map feeds the next convolution of the sem-seg head: emit its bf16 planes in the same pass
+        buf = conv._planes_buf(y.numel(), y.device) if (conv.MATH == "bf16x3" and c % 8 == 0) else None
+        hi, lo = conv._hl(buf)
+        L.check(L.lib().jtsm_upsample_bilinear2x_forward_f32(L.ptr(x), L.ptr(y), hi, lo, n, h, w, c, L.stream()),
+                "upsample2x")
+        if buf is not None:
+            conv.planes_put(y, buf)
         ctx.shape = (n, c, h, w)
         return y
 
