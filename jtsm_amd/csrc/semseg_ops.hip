@@ -40,15 +40,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 // mean / rstd per (n, group) from the partials, folded in slab order in double.
 __global__ void gn_fold_kernel(const float2* __restrict__ part, float* __restrict__ mean,
                                float* __restrict__ rstd, int HW, int C, int G, int slabs, float eps) {
-  const int n = blockIdx.x, g = threadIdx.x;
-  if (g >= G) return;
+  // blockDim = 64 * S: slice j of group g folds slabs j, j+S, ... in double; the slices are added in slice order
+  __shared__ double rs[16][64], rq[16][64];
+  const int n = blockIdx.x, g = threadIdx.x & 63, j = threadIdx.x >> 6, S = blockDim.x >> 6;
   const int C4 = C / 4, cpg4 = C4 / G;
   double s = 0.0, q = 0.0;
-  for (int sl = 0; sl < slabs; ++sl)
-    for (int k = 0; k < cpg4; ++k) {
-      const float2 v = part[((size_t)n * slabs + sl) * C4 + g * cpg4 + k];
-      s += v.x; q += v.y;
-    }
+  if (g < G)
+    for (int sl = j; sl < slabs; sl += S)
+      for (int k = 0; k < cpg4; ++k) {
+        const float2 v = part[((size_t)n * slabs + sl) * C4 + g * cpg4 + k];
+        s += v.x; q += v.y;
+      }
+  rs[j][g] = s; rq[j][g] = q;
+  __syncthreads();
+  if (j != 0 || g >= G) return;
+  s = 0.0; q = 0.0;
+  for (int jj = 0; jj < S; ++jj) { s += rs[jj][g]; q += rq[jj][g]; }
   const double m = (double)HW * (C / G);
   const double mu = s / m;
   double var = q / m - mu * mu;
@@ -141,32 +148,43 @@ __global__ __launch_bounds__(256) void gn_bwd_stats_kernel(const float* __restri
 }
 
 // Fold: per (n, c): A, B totals; per (n, g): S1 = sum gamma*A, S2 = sum gamma*B; dgamma/dbeta per channel.
-// One workgroup, thread = channel.
+// One workgroup of (channel, slab-slice) threads.
 __global__ void gn_bwd_fold_kernel(const float* __restrict__ partA, const float* __restrict__ partB,
                                    const float* __restrict__ gamma, float* __restrict__ s1,
                                    float* __restrict__ s2, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                   int N, int C, int G, int slabs) {
-  extern __shared__ float sh[];  // [2][C]
-  const int c = threadIdx.x, cpg = C / G;
+                                   int N, int C, int G, int slabs, int Cpad) {
+  // blockDim = Cpad * S: slice j of channel c folds slabs j, j+S, ...; the S slices are then added in slice order
+  extern __shared__ float sh[];  // [S][2][Cpad] slice sums, then [2][C] gamma-weighted totals
+  const int S = blockDim.x / Cpad;
+  const int c = threadIdx.x % Cpad, j = threadIdx.x / Cpad, cpg = C / G;
+  float* red = sh;
+  float* gw = sh + (size_t)S * 2 * Cpad;
   float dg = 0.f, db = 0.f;
   for (int n = 0; n < N; ++n) {
     float a = 0.f, b = 0.f;
     if (c < C)
-      for (int sl = 0; sl < slabs; ++sl) {
+      for (int sl = j; sl < slabs; sl += S) {
         a += partA[((size_t)n * slabs + sl) * C + c];
         b += partB[((size_t)n * slabs + sl) * C + c];
       }
-    dg += b; db += a;
     __syncthreads();
-    if (c < C) { sh[c] = gamma[c] * a; sh[C + c] = gamma[c] * b; }
+    red[(j * 2 + 0) * Cpad + c] = a;
+    red[(j * 2 + 1) * Cpad + c] = b;
     __syncthreads();
-    if (c < G) {
+    if (j == 0 && c < C) {
+      a = 0.f; b = 0.f;
+      for (int jj = 0; jj < S; ++jj) { a += red[(jj * 2 + 0) * Cpad + c]; b += red[(jj * 2 + 1) * Cpad + c]; }
+      dg += b; db += a;
+      gw[c] = gamma[c] * a; gw[C + c] = gamma[c] * b;
+    }
+    __syncthreads();
+    if (j == 0 && c < G) {
       float x1 = 0.f, x2 = 0.f;
-      for (int k = 0; k < cpg; ++k) { x1 += sh[c * cpg + k]; x2 += sh[C + c * cpg + k]; }
+      for (int k = 0; k < cpg; ++k) { x1 += gw[c * cpg + k]; x2 += gw[C + c * cpg + k]; }
       s1[n * G + c] = x1; s2[n * G + c] = x2;
     }
   }
-  if (c < C) { dgamma[c] = dg; dbeta[c] = db; }
+  if (j == 0 && c < C) { dgamma[c] = dg; dbeta[c] = db; }
 }
 
 // dx = rstd * (gamma * dyr - (S1 + xhat * S2) / m)
@@ -499,8 +517,8 @@ int jtsm_group_norm_forward_f32(const float* x, const float* gamma, const float*
   const int slabs = gn_slabs(HW);
   float2* part = reinterpret_cast<float2*>(workspace);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(slabs, N), dim3(256), 0, st, x, part, (int)HW, C, slabs);
-  hipLaunchKernelGGL(gn_fold_kernel, dim3(N), dim3(((G + 63) / 64) * 64), 0, st, part, mean, rstd, (int)HW, C, G,
-                     slabs, eps);
+  JTSM_REQUIRE(G <= 64, "group_norm: at most 64 groups (G=%d)", G);
+  hipLaunchKernelGGL(gn_fold_kernel, dim3(N), dim3(64 * 16), 0, st, part, mean, rstd, (int)HW, C, G, slabs, eps);
   const long total4 = (long)N * HW * (C / 4);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, mean, rstd, gamma, beta, y, HW,
                      C, G, relu, total4);
@@ -527,9 +545,9 @@ int jtsm_group_norm_backward_f32(const float* x, const float* dy, const float* g
   float* s2 = s1 + (size_t)N * C;
   hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(slabs, N), dim3(256), 0, st, x, dy, mean, rstd, gamma, beta,
                      reinterpret_cast<float4*>(partA), reinterpret_cast<float4*>(partB), (int)HW, C, G, slabs, relu);
-  const int threads = ((C + 63) / 64) * 64;
-  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(1), dim3(threads), 2 * C * sizeof(float), st, partA, partB, gamma, s1,
-                     s2, dgamma, dbeta, N, C, G, slabs);
+  const int cpad = ((C + 63) / 64) * 64, slices = 1024 / cpad;
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(1), dim3(cpad * slices), ((size_t)slices * 2 * cpad + 2 * C) * sizeof(float),
+                     st, partA, partB, gamma, s1, s2, dgamma, dbeta, N, C, G, slabs, cpad);
   const long total4 = (long)N * HW * (C / 4);
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, st, x, dy, mean, rstd, gamma, beta,
                      s1, s2, dx, dx_hi, dx_lo, HW, C, G, relu, total4);
