@@ -516,3 +516,41 @@ def linear_fused(x, w, bias=None, relu=False, bias_needs_grad=True):
     y = conv2d_fused(x.view(r, k, 1, 1), w.view(w.shape[0], k, 1, 1), None, bias, None, 1, 0, 1, relu,
                      bias_needs_grad)
     return y.view(r, w.shape[0])
+
+
+class _ColumnSplit(Function):
+    """Views of consecutive column ranges of a (R, C) matrix whose gradients come back as ONE concatenation —
+    instead of autograd's zero-filled (R, C) buffer plus an add per slice."""
+
+    @staticmethod
+    def forward(ctx, y, *sizes):
+        ctx.sizes, ctx.rows = sizes, y.shape[0]
+        outs, c0 = [], 0
+        for n in sizes:
+            outs.append(y[:, c0:c0 + n])
+            c0 += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros((ctx.rows, n)) for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, dim=1),) + (None,) * len(ctx.sizes)
+
+
+def linear_fused_split(x, weights, biases, relu=False):
+    """Several Linear layers on the same input as ONE GEMM (weights concatenated along `out`); returns one output
+    view per layer.  The column count is padded to a multiple of 4 for the kernels' 16-byte rows."""
+    r, k = x.shape
+    sizes = [w.shape[0] for w in weights]
+    total = sum(sizes)
+    pad = (-total) % 4
+    ws, bs = list(weights), list(biases)
+    if pad:
+        ws.append(weights[0].new_zeros((pad, k)))
+        bs.append(biases[0].new_zeros(pad))
+    w = torch.cat(ws).view(total + pad, k, 1, 1)
+    b = torch.cat(bs)
+    y = _ConvFused.apply(x.view(r, k, 1, 1), w, None, b, None, 1, 0, 1, relu, True, False).view(r, total + pad)
+    outs = _ColumnSplit.apply(y, *(sizes + ([pad] if pad else [])))
+    return list(outs[:len(sizes)])

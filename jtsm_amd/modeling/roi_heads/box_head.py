@@ -2,8 +2,9 @@
 
 flatten -> [Linear -> ReLU -> Dropout(0.5)] x len(fc_dims).  Each Linear+ReLU is one MFMA GEMM
 launch.  The pooled features arrive channels_last, i.e. flattened in (h, w, c) order, while the
-reference's fc1 weight columns are in (c, h, w) order; the parameter keeps the REFERENCE order
-(state_dict compatible) and is re-ordered on the fly (a 100 MB permute next to a 200 GFLOP GEMM).
+reference's fc1 weight columns are in (c, h, w) order: the PARAMETER is stored in (h, w, c) column order
+(no 100 MB permute on the step, planes cached like any other weight) and state_dict() / load_state_dict()
+convert to and from the reference order, so checkpoints are interchangeable.
 """
 import numpy as np
 import torch
@@ -44,25 +45,42 @@ class DiscriminativeAdaptionNeck(nn.Module):
             self.fcs.append(fc)
             self._output_size = fc_dim
         self.dropout_p = 0.5
+        self._register_load_state_dict_pre_hook(self._to_hwc_hook)
+        self._register_state_dict_hook(self._to_chw_hook)
         for layer in self.fcs:
             torch.nn.init.normal_(layer.weight, std=0.005)
             torch.nn.init.constant_(layer.bias, 0.1)
 
+    # fc1.weight is STORED with its input columns in (h, w, c) order — the order a channels_last pooled feature
+    # has in memory — so the 100 MB matrix is never re-ordered on the step.  Checkpoints keep the reference's
+    # (c, h, w) column order: the two hooks below convert on load / save.
+    def _hwc_cols(self, w, to_hwc):
+        c, h, ww = self._in_shape
+        if h * ww == 1:
+            return w
+        if to_hwc:
+            return w.reshape(-1, c, h, ww).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+        return w.reshape(-1, h, ww, c).permute(0, 3, 1, 2).reshape(w.shape[0], -1)
+
+    def _to_hwc_hook(self, state_dict, prefix, *args):
+        key = prefix + "fc1.weight"
+        if key in state_dict:
+            state_dict[key] = self._hwc_cols(state_dict[key], True)
+
+    @staticmethod
+    def _to_chw_hook(module, state_dict, prefix, local_metadata):
+        key = prefix + "fc1.weight"
+        if key in state_dict:
+            state_dict[key] = module._hwc_cols(state_dict[key], False)
+
     def forward(self, x):
         if x.dim() == 4:
-            c, h, w = x.shape[1:]
-            first = self.fcs[0]
-            if x.is_contiguous(memory_format=torch.channels_last) and h * w > 1:
-                x = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)                      # (h,w,c) order, a view
-                w1 = first.weight.view(-1, c, h, w).permute(0, 2, 3, 1).reshape(first.weight.shape[0], -1)
-            else:
-                x, w1 = x.flatten(1), first.weight
-        else:
-            w1 = self.fcs[0].weight
+            if x.shape[2] * x.shape[3] > 1:
+                x = x.permute(0, 2, 3, 1)               # (h,w,c) order: a view of a channels_last tensor
+            x = x.reshape(x.shape[0], -1)
         for k, fc in enumerate(self.fcs):
-            weight = w1 if k == 0 else fc.weight
             from ...layers.conv import linear_fused
-            x = linear_fused(x, weight, fc.bias, True, True)
+            x = linear_fused(x, fc.weight, fc.bias, True, True)
             if self.training and self.dropout_p > 0:
                 x = torch.nn.functional.dropout(x, self.dropout_p, True)
         return x

@@ -22,7 +22,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from ...layers.conv import linear_fused
+from ...layers.conv import linear_fused, linear_fused_split
 from ...layers.mining import match_label, mine_top1, pad_class_lists, row_lse
 from ...layers.roi_align import roi_align
 from ...layers.shape_spec import ShapeSpec
@@ -185,14 +185,7 @@ class JTSMROIHeads(ROIHeads):
         mods = [self.box_predictor.cls, self.box_predictor.det]
         for r in self.box_refinery:
             mods += [r.cls_score] + ([r.bbox_pred] if r.has_reg else [])
-        w = torch.cat([m.weight for m in mods])
-        b = torch.cat([m.bias for m in mods])
-        y = linear_fused(x, w, b, False, True)
-        outs, c0 = [], 0
-        for m in mods:
-            outs.append(y[:, c0:c0 + m.out_features])
-            c0 += m.out_features
-        return outs
+        return linear_fused_split(x, [m.weight for m in mods], [m.bias for m in mods])
 
     def _forward_box(self, features, proposals):
         feats = [features[f] for f in self.box_in_features]
