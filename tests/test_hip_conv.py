@@ -310,3 +310,30 @@ def test_empty_batch_through_conv_linear_and_mask_head(cuda):
     y = K.linear_fused(torch.zeros(0, 12, device=cuda), w, None, True, False)
     y.sum().backward()
     assert y.shape == (0, 8) and float(w.grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 256, 256, 256, 256, 3, 1, 1),      # FPN p2 output conv (256x256 tiles, no split)
+    (2, 1024, 64, 64, 256, 1, 1, 0),       # res4 1x1 (split-K, wide epilogue)
+    (2, 256, 64, 64, 256, 3, 1, 1),        # res4 3x3
+    (2, 512, 128, 128, 1024, 1, 2, 0),     # strided 1x1 shortcut (scatter data gradient)
+    (4000, 12544, 1, 1, 2048, 1, 1, 0),    # DAN fc1 at BASELINE size
+], ids=["p2_3x3", "res4_1x1", "res4_3x3", "shortcut_s2", "dan_fc1"])
+def test_full_size_adjointness(cuda, shape):
+    """BASELINE-size layers, no oracle needed: forward, data gradient and weight gradient are three views of one
+    trilinear form, so <conv(x,w), dy> = <x, dgrad(dy,w)> = <w, wgrad(dy,x)> (dots accumulated in fp64)."""
+    N, C_, H, W, O, k, s, p = shape
+    gen = torch.Generator(device=cuda).manual_seed(7)
+    x = torch.randn(N, C_, H, W, device=cuda, generator=gen).contiguous(memory_format=CL)
+    w = (torch.randn(O, C_, k, k, device=cuda, generator=gen) * (2.0 / (C_ * k * k)) ** 0.5).contiguous(memory_format=CL)
+    y = K.conv2d_forward(x, w, s, p, 1)
+    dy = torch.randn(y.shape, device=cuda, generator=gen).contiguous(memory_format=CL)
+    dx = K.conv2d_backward_data(dy, w, tuple(x.shape), s, p, 1)
+    dw = K.conv2d_backward_weight(dy, x, tuple(w.shape), s, p, 1)
+    dot = lambda a, b: float((a.double() * b.double()).sum())
+    f, d, g = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = float(y.double().norm() * dy.double().norm())
+    assert abs(f - d) <= REL * scale and abs(f - g) <= REL * scale, (f, d, g, scale)
+    # and the forward is linear in x
+    y2 = K.conv2d_forward(x * 0.5, w, s, p, 1)
+    assert float((y2 - 0.5 * y).abs().max()) <= REL * float(y.abs().max())
