@@ -349,6 +349,20 @@ int jtsm_oicr_backward_f32(const float* cls_logits, int ld_cls, int num_cls, con
                            float* d_box, int ld_dbox, void* stream);
 
 
+/* Mask loss — mask_rcnn_loss (detectron2/modeling/roi_heads/mask_head.py:31-112, used by
+ * projects/WSL/wsl/modeling/roi_heads/mask_head.py): mean binary cross-entropy with logits between the
+ * ground-truth-class channel of logits (N,side,side,ld) NHWC (num_classes <= ld; gt_classes NULL when
+ * class-agnostic, num_classes == 1) and target (N,side,side) 0/1 bytes.  out[0] = loss.  The backward writes the
+ * dense dlogits (zero off the class channel).  Deterministic (fixed-order two-stage sum). */
+size_t jtsm_mask_bce_workspace_bytes(void);
+int jtsm_mask_bce_forward_f32(const float* logits, int ld, int num_classes, const int64_t* gt_classes,
+                              const uint8_t* target, int N, int side, float* out, void* workspace,
+                              void* stream);
+int jtsm_mask_bce_backward_f32(const float* logits, int ld, int num_classes, const int64_t* gt_classes,
+                               const uint8_t* target, int N, int side, const float* upstream,
+                               float* dlogits, void* stream);
+
+
 /* ---------------------------------------------------------------------------
  * FPN-level variants (NHWC only) — what ROIPooler.forward does with nonzero + index +
  * scatter per level (detectron2/modeling/poolers.py:236-247,

@@ -1205,10 +1205,8 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
 
 // 256x256 tiles for the weight gradients whose output is large enough to fill the chip with them.
 static bool x3_wgrad_big(const Params& p) {
-  static const int force = getenv("JTSM_X3_WGRAD_TILE") ? atoi(getenv("JTSM_X3_WGRAD_TILE")) : -1;
   if (p.M < 256 || p.N < 256) return false;
-  if (force >= 0) return force == 2;
-  static const long min_work = getenv("JTSM_X3_WGRAD_BIG_MIN") ? atol(getenv("JTSM_X3_WGRAD_BIG_MIN")) : 2000;
+  constexpr long min_work = 2000;
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
   return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, scratch/wgrad_sweep.py)
 }

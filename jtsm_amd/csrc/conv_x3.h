@@ -34,8 +34,7 @@ __device__ __forceinline__ void dma16b(const void* g, void* lds_uniform_base) {
 // BM x BN = 32*WM*TM x 32*WN*TN outputs.  The loop is bound by how many operand bytes a CU can keep in
 // flight from L2 (measured: the same kernel without its MFMAs takes 67-90 % of the full time, and LDS limits
 // the bytes in flight), so the large layers use 256x256 (half the operand bytes per FLOP of 128x128).
-// DBG: ablation builds for profiling only (1 no MFMA, 2 no loads).
-template <int ROLE, int WM, int WN, int TM, int TN, int NBUF, int DBG = 0>
+template <int ROLE, int WM, int WN, int TM, int TN, int NBUF>
 __global__ __launch_bounds__(64 * WM * WN, (NBUF == 1 && WM * WN == 4) ? 4 : (WM * WN == 4 ? 2 : 2))
 void igemm_x3_kernel(const Params p, const X3Planes q) {
   static_assert(ROLE == FWD || ROLE == DGRAD, "bf16x3: forward and data-gradient roles");
@@ -115,7 +114,6 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
   // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups.
   constexpr int PIECES = 2 * A_INS + 2 * B_INS;
   auto issue_piece = [&](int idx, int k0, int buf) {
-    if (DBG == 2) return;
     char* St = lds + buf * STAGE;
     if (idx < 2 * A_INS) {
       const int j = idx >> 1, lo = idx & 1;
@@ -211,13 +209,9 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if (DBG == 1) {   // keep the operands alive without the matrix pipe
-            acc[i][j][0] += (float)al[i][0] + (float)bh[j][0] + (float)ah[i][1] + (float)bl[j][1];
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
           if (NBUF == 2) {
             const int slot = (st * TM + i) * TN + j;
             if (more) {
@@ -592,12 +586,7 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
-  static const int dbg = getenv("JTSM_X3_DBG") ? atoi(getenv("JTSM_X3_DBG")) : 0;
-  if (dbg == 1 && ROLE == FWD && NT == 512)
-    hipLaunchKernelGGL((igemm_x3_kernel<FWD, WM, WN, TM, TN, 2, 1>), grid, dim3(NT), 0, st, p, q);
-  else if (dbg == 2 && ROLE == FWD && NT == 512)
-    hipLaunchKernelGGL((igemm_x3_kernel<FWD, WM, WN, TM, TN, 2, 2>), grid, dim3(NT), 0, st, p, q);
-  else if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
+  if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
     // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
     // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 1>), grid, dim3(NT), 0, st, p, q);
@@ -611,13 +600,11 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
 
 // Tile choice.  0: 128x128 (4 waves), 1: 256x64 (4 waves, narrow outputs), 2: 256x256 (8 waves, large layers).
 inline int x3_tile_choice(const Params& p) {
-  static const int force = getenv("JTSM_X3_TILE") ? atoi(getenv("JTSM_X3_TILE")) : -1;
   if (p.N <= 64) return 1;
-  if (force >= 0) return force == 2 && p.N >= 192 ? 2 : 0;
   // 256x256 pays once its (fewer, larger) workgroups still fill the chip and K is deep enough to amortise them
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
   const int ktiles = ceil_div(p.K, XBK);
-  static const long min_work = getenv("JTSM_X3_BIG_MIN") ? atol(getenv("JTSM_X3_BIG_MIN")) : 9216;
+  constexpr long min_work = 9216;   // tiles x stages (measured crossover, scratch/x3_sweep.py + layer timings)
   if (p.N >= 192 && t256 * ktiles >= min_work && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
   return 0;
 }

@@ -397,6 +397,59 @@ inline MilWs mil_carve(void* ws, int nbags, int spb, int nc) {
   return k;
 }
 
+// ---- mask loss (mask_rcnn_loss, projects/WSL/wsl/modeling/roi_heads/mask_head.py:23-103 /
+// detectron2/modeling/roi_heads/mask_head.py:31-112): mean BCE-with-logits between the ground-truth class
+// channel of the (N,M,M,C) logits and a 0/1 target.  Thread per (roi, pixel); fixed-order two-stage sum.
+__global__ __launch_bounds__(256) void mask_bce_fwd(const float* __restrict__ z, int ld, const long* __restrict__ cls,
+                                                    const unsigned char* __restrict__ target, long npix, int pix_per_roi,
+                                                    float* __restrict__ part) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const long n = i / pix_per_roi;
+    const float x = z[i * ld + (cls ? (int)cls[n] : 0)];
+    const float t = target[i] ? 1.f : 0.f;
+    s += fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void mask_bce_finish(const float* __restrict__ part, int nblocks, long npix,
+                                                       float* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) s += part[b];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(red[0] / (double)npix);
+}
+
+// dz[i, c] = (sigmoid(z) - t) * upstream / npix on the class channel, zero elsewhere (dense, as the predictor's
+// backward wants it)
+__global__ __launch_bounds__(256) void mask_bce_bwd(const float* __restrict__ z, int ld, const long* __restrict__ cls,
+                                                    const unsigned char* __restrict__ target, long npix, int pix_per_roi,
+                                                    const float* __restrict__ upstream, float* __restrict__ dz) {
+  const float k = (upstream ? *upstream : 1.f) / (float)npix;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix; i += (long)gridDim.x * 256) {
+    const long n = i / pix_per_roi;
+    const int c = cls ? (int)cls[n] : 0;
+    const float x = z[i * ld + c];
+    const float g = (1.f / (1.f + expf(-x)) - (target[i] ? 1.f : 0.f)) * k;
+    float* row = dz + i * ld;
+    for (int j = 0; j < ld; ++j) row[j] = j == c ? g : 0.f;
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -485,6 +538,41 @@ int jtsm_oicr_backward_f32(const float* cls_logits, int ld_cls, int num_cls, con
                      box_deltas, ld_box, 4 * (num_cls - 1), labels, weights, proposals, gt_boxes, R, losses,
                      up_cls, up_box, d_cls, ld_dcls, d_box, ld_dbox);
   JTSM_CHECK_LAUNCH("oicr backward");
+  return JTSM_OK;
+}
+
+#define MASK_BCE_BLOCKS 256
+
+size_t jtsm_mask_bce_workspace_bytes(void) { return MASK_BCE_BLOCKS * sizeof(float); }
+
+int jtsm_mask_bce_forward_f32(const float* logits, int ld, int num_classes, const int64_t* gt_classes,
+                              const uint8_t* target, int N, int side, float* out, void* workspace, void* stream) {
+  JTSM_REQUIRE(N >= 0 && side > 0 && num_classes > 0 && ld >= num_classes, "mask_bce: bad sizes");
+  JTSM_REQUIRE(out, "mask_bce: null out");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(logits && target && workspace && (gt_classes || num_classes == 1), "mask_bce: null pointer");
+  hipStream_t st = as_stream(stream);
+  const long npix = (long)N * side * side;
+  const int blocks = (int)((npix + 255) / 256 < MASK_BCE_BLOCKS ? (npix + 255) / 256 : MASK_BCE_BLOCKS);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(mask_bce_fwd, dim3(blocks), dim3(256), 0, st, logits, ld, (const long*)gt_classes, target, npix,
+                     side * side, part);
+  hipLaunchKernelGGL(mask_bce_finish, dim3(1), dim3(256), 0, st, part, blocks, npix, out);
+  JTSM_CHECK_LAUNCH("mask_bce forward");
+  return JTSM_OK;
+}
+
+int jtsm_mask_bce_backward_f32(const float* logits, int ld, int num_classes, const int64_t* gt_classes,
+                               const uint8_t* target, int N, int side, const float* upstream, float* dlogits,
+                               void* stream) {
+  JTSM_REQUIRE(N >= 0 && side > 0 && num_classes > 0 && ld >= num_classes, "mask_bce backward: bad sizes");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(logits && target && dlogits && (gt_classes || num_classes == 1), "mask_bce backward: null pointer");
+  const long npix = (long)N * side * side;
+  const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+  hipLaunchKernelGGL(mask_bce_bwd, dim3(blocks), dim3(256), 0, as_stream(stream), logits, ld, (const long*)gt_classes,
+                     target, npix, side * side, upstream, dlogits);
+  JTSM_CHECK_LAUNCH("mask_bce backward");
   return JTSM_OK;
 }
 

@@ -110,3 +110,43 @@ class _OICRLoss(Function):
 def oicr_loss(cls_logits, box_deltas, labels, weights, proposals=None, gt_boxes=None):
     """(loss_cls, loss_box_reg) of one refinement branch.  box_deltas may be None."""
     return _OICRLoss.apply(cls_logits, box_deltas, labels, weights, proposals, gt_boxes)
+
+
+class _MaskBCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, gt_classes, target):
+        L.require_gpu(logits, target)
+        n, c, side, side2 = logits.shape
+        if side != side2 or tuple(target.shape) != (n, side, side):
+            raise RuntimeError("mask_bce: logits %s / target %s" % (tuple(logits.shape), tuple(target.shape)))
+        # channels_last storage with any channel pitch (a [:, :80] slice of a padded map is fine)
+        if not (logits.stride(1) == 1 and logits.stride(3) >= c and logits.stride(2) == side * logits.stride(3)
+                and logits.stride(0) == side * logits.stride(2)):
+            logits = logits.contiguous(memory_format=torch.channels_last)
+        ld = logits.stride(3)
+        target = target.to(torch.uint8).contiguous()
+        cls = gt_classes.to(torch.int64).contiguous() if c > 1 else None
+        lib = L.lib()
+        out = torch.empty(1, dtype=torch.float32, device=logits.device)
+        ws = torch.empty(lib.jtsm_mask_bce_workspace_bytes(), dtype=torch.uint8, device=logits.device)
+        L.check(lib.jtsm_mask_bce_forward_f32(L.ptr(logits), ld, c, L.ptr(cls), L.ptr(target), n, side, L.ptr(out),
+                                              L.ptr(ws), L.stream()), "mask_bce_forward")
+        ctx.save_for_backward(logits, cls, target)
+        ctx.cfg = (ld, c, n, side)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, cls, target = ctx.saved_tensors
+        ld, c, n, side = ctx.cfg
+        d = torch.empty((n, side, side, ld), dtype=torch.float32, device=logits.device)
+        g = g.to(torch.float32).contiguous()
+        L.check(L.lib().jtsm_mask_bce_backward_f32(L.ptr(logits), ld, c, L.ptr(cls), L.ptr(target), n, side, L.ptr(g),
+                                                   L.ptr(d), L.stream()), "mask_bce_backward")
+        return d.permute(0, 3, 1, 2)[:, :c], None, None
+
+
+def mask_bce_loss(logits, gt_classes, target):
+    """F.binary_cross_entropy_with_logits(logits[arange(N), gt_classes], target.float(), reduction="mean") in one
+    launch each way (libjtsm_hip.so: mask_bce_*)."""
+    return _MaskBCE.apply(logits, gt_classes, target)

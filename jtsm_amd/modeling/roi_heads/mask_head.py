@@ -9,6 +9,7 @@ from torch import nn
 
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d, ConvTranspose2d, cat
+from ...layers.wsl_losses import mask_bce_loss
 from ...utils.registry import Registry
 
 ROI_MASK_HEAD_REGISTRY = Registry("ROI_MASK_HEAD")
@@ -24,11 +25,7 @@ def mask_rcnn_loss(pred_mask_logits, gt_classes, gt_masks_bool):
     total_num_masks = pred_mask_logits.size(0)
     if total_num_masks == 0:
         return pred_mask_logits.sum() * 0
-    if pred_mask_logits.size(1) == 1:
-        sel = pred_mask_logits[:, 0]
-    else:
-        sel = pred_mask_logits[torch.arange(total_num_masks, device=pred_mask_logits.device), gt_classes]
-    return F.binary_cross_entropy_with_logits(sel, gt_masks_bool.to(dtype=torch.float32), reduction="mean")
+    return mask_bce_loss(pred_mask_logits, gt_classes, gt_masks_bool)     # one HIP launch each way (no CPU path)
 
 
 @ROI_MASK_HEAD_REGISTRY.register()

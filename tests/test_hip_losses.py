@@ -163,3 +163,27 @@ def test_fused_sgd_matches_torch_sgd(cuda):
             assert torch.allclose(m.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7), (step, tuple(r.shape))
     sd = o_mine.state_dict()
     assert len(sd["state"]) == 4 and "momentum_buffer" in next(iter(sd["state"].values()))
+
+
+@pytest.mark.parametrize("classes,pad", [(80, 0), (5, 3), (1, 0)])
+def test_mask_bce_matches_torch(cuda, classes, pad):
+    """mask_bce_loss (one launch each way) vs F.binary_cross_entropy_with_logits on the gathered class channel,
+    incl. a padded channel pitch and the class-agnostic case."""
+    from jtsm_amd.layers.wsl_losses import mask_bce_loss
+
+    g = torch.Generator().manual_seed(21)
+    n, side = 13, 28
+    z = torch.randn(n, classes + pad, side, side, generator=g) * 3
+    cls = torch.randint(0, classes, (n,), generator=g)
+    t = torch.rand(n, side, side, generator=g) > 0.6
+    z0 = z[:, :classes].clone().requires_grad_(True)
+    sel = z0[torch.arange(n), cls] if classes > 1 else z0[:, 0]
+    l0 = torch.nn.functional.binary_cross_entropy_with_logits(sel, t.float(), reduction="mean")
+    (l0 * 1.7).backward()
+    zd = z.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    l = mask_bce_loss(zd[:, :classes], cls.to(cuda), t.to(cuda))
+    (l * 1.7).backward()
+    assert abs(float(l) - float(l0)) <= 1e-6 * abs(float(l0))
+    gd = zd.grad.cpu()
+    assert torch.allclose(gd[:, :classes], z0.grad, rtol=1e-5, atol=1e-9)
+    assert float(gd[:, classes:].abs().sum()) == 0.0
