@@ -451,6 +451,15 @@ int jtsm_mine_top1_f32(const float* scores, int ld, const float* lse, const floa
                        const int32_t* classes, const int32_t* counts, int B, int Gmax,
                        const float* img_probs, int nprob, int32_t* out_idx, float* out_box,
                        float* out_score, float* out_weight, void* stream);
+/* Pseudo semantic target (get_pgt_sem_seg, projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:2025-2070, with
+ * the rectangle substitution of SURVEY F8): out (B,H,W) int64 <- 0, then every pseudo box j < counts[b] of image b
+ * paints the pixels whose centre lies in its rectangle shrunk by `erode` with classes[b,j] - class_base (1..63), in
+ * ascending scores[b,j] order (ties: lower j first); finally, in list order, a class left without a single pixel is
+ * painted once more.  boxes (B,G,4), classes / scores (B,G), G <= 64.  workspace: jtsm_paint_sem_seg_workspace_bytes. */
+size_t jtsm_paint_sem_seg_workspace_bytes(int B);
+int jtsm_paint_sem_seg(const float* boxes, const int32_t* classes, const float* scores, const int32_t* counts,
+                       int B, int G, int class_base, int H, int W, float erode, int64_t* out, void* workspace,
+                       void* stream);
 /* For every proposal: IoU against its image's pseudo boxes (first maximum wins), label = that box's
  * class if IoU >= iou_thresh else bg_label, plus the matched index / box / weight / (optional) score. */
 int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int B, int R,

@@ -150,6 +150,86 @@ __global__ __launch_bounds__(256) void match_label_kernel(const float* __restric
   if (gt_scores) gt_scores[r] = pgt_score[o];
 }
 
+// ---- pseudo semantic target (get_pgt_sem_seg, roi_heads_jtsm.py:2025-2070, with the rectangle substitution of
+// SURVEY F8): every pseudo box paints its rectangle shrunk by `erode` pixels with value class - class_base, in
+// ascending score order (the best box ends on top); then, in list order, a class whose pixels were all painted
+// over is painted once more.  Pass A is pixel-parallel (max score RANK among the covering boxes) and counts the
+// pixels of every value; pass B (one workgroup per image) replays the sequential "missing class" rule on those
+// counts, touching only the rectangles it repaints.  No host synchronisation: list lengths stay on the device.
+__device__ __forceinline__ bool paint_inside(const float* __restrict__ b, int x, int y, float erode) {
+  const float xs = (float)x + 0.5f, ys = (float)y + 0.5f;
+  return xs >= b[0] + erode && xs <= b[2] - erode && ys >= b[1] + erode && ys <= b[3] - erode;
+}
+
+constexpr int kPaintValues = 64;   // painted values are 1 .. 63 (0 = untouched)
+
+__global__ __launch_bounds__(256) void paint_top_kernel(const float* __restrict__ boxes, const int* __restrict__ classes,
+                                                        const float* __restrict__ scores, const int* __restrict__ counts,
+                                                        int G, int class_base, int H, int W, float erode,
+                                                        long* __restrict__ out, int* __restrict__ value_counts) {
+  __shared__ int hist[kPaintValues];
+  __shared__ float sb[64 * 4];
+  __shared__ int srank[64], sval[64];
+  const int b = blockIdx.y, n = min(counts[b], 64);
+  if (threadIdx.x < kPaintValues) hist[threadIdx.x] = 0;
+  if (threadIdx.x < n) {
+    const int j = threadIdx.x;
+    const float sj = scores[b * G + j];
+    int r = 0;   // position of box j in ascending (score, index) order
+    for (int k = 0; k < n; ++k) {
+      const float sk = scores[b * G + k];
+      r += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
+    }
+    srank[j] = r;
+    sval[j] = classes[b * G + j] - class_base;
+    for (int e = 0; e < 4; ++e) sb[j * 4 + e] = boxes[((size_t)b * G + j) * 4 + e];
+  }
+  __syncthreads();
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p < (long)H * W) {
+    const int y = (int)(p / W), x = (int)(p - (long)y * W);
+    int best = -1, val = 0;
+    for (int j = 0; j < n; ++j)
+      if (paint_inside(sb + j * 4, x, y, erode) && srank[j] > best) { best = srank[j]; val = sval[j]; }
+    out[(size_t)b * H * W + p] = val;
+    atomicAdd(&hist[val & (kPaintValues - 1)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < kPaintValues && hist[threadIdx.x]) atomicAdd(value_counts + b * kPaintValues + threadIdx.x, hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void paint_missing_kernel(const float* __restrict__ boxes, const int* __restrict__ classes,
+                                                            const int* __restrict__ counts, int G, int class_base, int H,
+                                                            int W, float erode, long* __restrict__ out,
+                                                            const int* __restrict__ value_counts) {
+  __shared__ int cnt[kPaintValues];
+  const int b = blockIdx.x, n = min(counts[b], 64);
+  if (threadIdx.x < kPaintValues) cnt[threadIdx.x] = value_counts[b * kPaintValues + threadIdx.x];
+  __syncthreads();
+  long* img = out + (size_t)b * H * W;
+  for (int j = 0; j < n; ++j) {
+    const int v = (classes[b * G + j] - class_base) & (kPaintValues - 1);
+    const bool missing = cnt[v] == 0;   // uniform: read before anyone updates it in this round
+    __syncthreads();
+    if (missing) {
+      const float* bx = boxes + ((size_t)b * G + j) * 4;
+      const int x0 = max(0, (int)floorf(bx[0] + erode - 0.5f)), x1 = min(W - 1, (int)ceilf(bx[2] - erode - 0.5f));
+      const int y0 = max(0, (int)floorf(bx[1] + erode - 0.5f)), y1 = min(H - 1, (int)ceilf(bx[3] - erode - 0.5f));
+      const int bw = x1 - x0 + 1, bh = y1 - y0 + 1;
+      if (bw > 0 && bh > 0)
+        for (long i = threadIdx.x; i < (long)bw * bh; i += 256) {
+          const int y = y0 + (int)(i / bw), x = x0 + (int)(i % bw);
+          if (!paint_inside(bx, x, y, erode)) continue;
+          const long old = img[(size_t)y * W + x];
+          img[(size_t)y * W + x] = v;
+          atomicSub(&cnt[(int)old & (kPaintValues - 1)], 1);
+          atomicAdd(&cnt[v], 1);
+        }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -193,6 +273,25 @@ int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int
                      bag_offsets, B, R, pgt_box, classes, counts, pgt_weight, pgt_score, Gmax, iou_thresh, bg_label,
                      labels, matched, gt_boxes, gt_weights, gt_scores);
   JTSM_CHECK_LAUNCH("match_label");
+  return JTSM_OK;
+}
+
+size_t jtsm_paint_sem_seg_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * kPaintValues * sizeof(int) + 16; }
+
+int jtsm_paint_sem_seg(const float* boxes, const int32_t* classes, const float* scores, const int32_t* counts, int B,
+                       int G, int class_base, int H, int W, float erode, int64_t* out, void* workspace, void* stream) {
+  JTSM_REQUIRE(B >= 0 && G > 0 && G <= 64 && H > 0 && W > 0, "paint_sem_seg: bad sizes (at most 64 boxes per image)");
+  if (B == 0) return JTSM_OK;
+  JTSM_REQUIRE(boxes && classes && scores && counts && out && workspace, "paint_sem_seg: null pointer");
+  hipStream_t st = as_stream(stream);
+  int* value_counts = reinterpret_cast<int*>(workspace);
+  JTSM_CHECK_HIP(hipMemsetAsync(value_counts, 0, (size_t)B * kPaintValues * sizeof(int), st));
+  const long hw = (long)H * W;
+  hipLaunchKernelGGL(paint_top_kernel, dim3((unsigned)((hw + 255) / 256), B), dim3(256), 0, st, boxes, classes, scores,
+                     counts, G, class_base, H, W, erode, reinterpret_cast<long*>(out), value_counts);
+  hipLaunchKernelGGL(paint_missing_kernel, dim3(B), dim3(256), 0, st, boxes, classes, counts, G, class_base, H, W, erode,
+                     reinterpret_cast<long*>(out), value_counts);
+  JTSM_CHECK_LAUNCH("paint_sem_seg");
   return JTSM_OK;
 }
 

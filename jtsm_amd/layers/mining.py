@@ -62,3 +62,20 @@ def match_label(proposals, bag_offsets, pgt, classes, counts, bg_label, iou_thre
         L.ptr(out["matched"]), L.ptr(out["boxes"]), L.ptr(out["weights"]), L.ptr(out["scores"]), L.stream()),
         "match_label")
     return out
+
+
+@torch.no_grad()
+def paint_sem_seg(boxes, classes, scores, counts, class_base, height, width, erode=2.0):
+    """Pseudo semantic target (B,H,W) int64 from per-image pseudo boxes (B,G,4) / classes (B,G) / scores (B,G) and
+    their counts (B,): rectangles shrunk by `erode`, value classes - class_base, best score on top, then classes
+    left without a pixel painted once more in list order (libjtsm_hip.so: jtsm_paint_sem_seg)."""
+    L.require_gpu(boxes, scores)
+    B, G = classes.shape
+    boxes, scores = boxes.contiguous(), scores.contiguous()
+    classes, counts = classes.to(torch.int32).contiguous(), counts.to(torch.int32).contiguous()
+    lib = L.lib()
+    out = torch.empty((B, height, width), dtype=torch.int64, device=boxes.device)
+    ws = torch.empty(lib.jtsm_paint_sem_seg_workspace_bytes(B), dtype=torch.uint8, device=boxes.device)
+    L.check(lib.jtsm_paint_sem_seg(L.ptr(boxes), L.ptr(classes), L.ptr(scores), L.ptr(counts), B, G, int(class_base),
+                                   height, width, L.f32(erode), L.ptr(out), L.ptr(ws), L.stream()), "paint_sem_seg")
+    return out

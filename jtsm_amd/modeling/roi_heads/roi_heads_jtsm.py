@@ -23,7 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from ...layers.conv import linear_fused, linear_fused_split
-from ...layers.mining import match_label, mine_top1, pad_class_lists, row_lse
+from ...layers.mining import match_label, mine_top1, pad_class_lists, paint_sem_seg, row_lse
 from ...layers.roi_align import roi_align
 from ...layers.shape_spec import ShapeSpec
 from ...structures import Boxes, ImageList, Instances
@@ -59,6 +59,36 @@ def eroded_rect_masks(boxes, height, width, erode=2.0):
     b = boxes.view(-1, 4, 1, 1)
     return ((xs >= b[:, 0] + erode) & (xs <= b[:, 2] - erode) & (ys >= b[:, 1] + erode) &
             (ys <= b[:, 3] - erode)).to(torch.float32)
+
+
+@torch.no_grad()
+def present_things(targets, num_classes):
+    """(B, num_classes) 0/1: which thing classes each image's instances contain (no host synchronisation)."""
+    oh = torch.zeros((len(targets), num_classes), dtype=torch.float32, device=targets[0].gt_classes.device)
+    for i, t in enumerate(targets):
+        oh[i, t.gt_classes.to(torch.int64)] = 1
+    return oh
+
+
+@torch.no_grad()
+def present_stuff(gt_sem_seg, num_classes_stuff):
+    """(B, num_classes_stuff - 1) 0/1: which stuff labels 1 .. num_classes_stuff-1 occur in each (B,H,W) map
+    (0 = things and 255 = ignore do not count) — one scatter instead of a sort-based unique per image."""
+    b = gt_sem_seg.shape[0]
+    flags = torch.zeros((b, 256), dtype=torch.float32, device=gt_sem_seg.device)
+    flags.scatter_(1, gt_sem_seg.reshape(b, -1).clamp(0, 255), 1.0)
+    return flags[:, 1:num_classes_stuff].contiguous()
+
+
+@torch.no_grad()
+def class_lists(oh, offset=0):
+    """Padded per-image class lists of a (B,C) presence matrix: classes (B,C) int32 — the present ones first, in
+    ascending order, each shifted by `offset` — and counts (B,) int32.  Lengths stay on the device."""
+    c = oh.shape[1]
+    ar = torch.arange(c, device=oh.device)
+    key = torch.where(oh > 0, ar, ar + c)
+    cls = (torch.sort(key, dim=1).values % c + offset).to(torch.int32)
+    return cls.contiguous(), oh.sum(dim=1).to(torch.int32)
 
 
 @ROI_HEADS_REGISTRY.register()
@@ -132,8 +162,9 @@ class JTSMROIHeads(ROIHeads):
     @torch.no_grad()
     def get_pgt_sem_seg(self, prev_pred_boxes, prev_pred_scores, proposals, height, width):
         """Reference-shaped entry (list-of-Instances mining, roi_heads_jtsm.py:2025-2070)."""
+        stuff_lists = [c[:int(n)].to(torch.int64) for c, n in zip(self.stuff_cls, self.stuff_cnt.tolist())]   # (syncs)
         targets = self.get_pgt_top_k(prev_pred_boxes, prev_pred_scores, proposals,
-                                     self.num_classes + self.num_classes_stuff - 1, self.gt_classes_img_int_stuff)
+                                     self.num_classes + self.num_classes_stuff - 1, stuff_lists)
         return self._paint_sem_seg([t.gt_boxes.tensor for t in targets], [t.gt_classes for t in targets],
                                    [t.gt_scores for t in targets], height, width)
 
@@ -171,10 +202,13 @@ class JTSMROIHeads(ROIHeads):
                                       "'next' row (SURVEY §8f row 4)")
         assert targets, "'targets' argument is required during training"
         self.proposals, self.superpixels, self.images = proposals, superpixels, images
-        self.gt_classes_img, self.gt_classes_img_int, self.gt_classes_img_oh = get_image_level_gt(
-            targets, self.num_classes)
-        (self.gt_classes_img_stuff, self.gt_classes_img_int_stuff,
-         self.gt_classes_img_oh_stuff) = get_image_level_gt_stuff(gt_sem_seg, self.num_classes_stuff, self.num_classes)
+        # image-level labels, entirely on the device (presence matrices + padded class lists with counts)
+        self.gt_classes_img_oh = present_things(targets, self.num_classes)
+        self.things_cls, self.things_cnt = class_lists(self.gt_classes_img_oh)
+        self.has_stuff = gt_sem_seg is not None
+        if self.has_stuff:
+            self.gt_classes_img_oh_stuff = present_stuff(gt_sem_seg, self.num_classes_stuff)
+            self.stuff_cls, self.stuff_cnt = class_lists(self.gt_classes_img_oh_stuff, offset=self.num_classes)
         losses = self._forward_box(features, proposals)
         if self.mask_on:
             losses.update(self._forward_mask(features, proposals))
@@ -206,24 +240,22 @@ class JTSMROIHeads(ROIHeads):
         cls_logits, det_logits = outs[0], outs[1]
         offsets = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).to(dev, non_blocking=True)
         labels_oh = (torch.cat([self.gt_classes_img_oh, self.gt_classes_img_oh_stuff], dim=1)
-                     if self.gt_classes_img_stuff else self.gt_classes_img_oh)
+                     if self.has_stuff else self.gt_classes_img_oh)
         losses, scores, img_probs = self.box_predictor.score_and_loss(cls_logits, det_logits, offsets, labels_oh,
                                                                       max(counts))
         self.pred_class_img_logits = img_probs
         self.aux = {"mil_scores": scores, "img_probs": img_probs, "pooled_argmax": argmax}
         all_boxes = torch.cat([p.proposal_boxes.tensor for p in proposals]).contiguous()
-        things_cls, things_cnt, _ = pad_class_lists(self.gt_classes_img_int, dev)
+        things_cls, things_cnt = self.things_cls, self.things_cnt
         self._mining = (all_boxes, offsets, things_cls, things_cnt, counts)
 
-        # pseudo semantic target from the top-1 box of every present stuff class (MIL scores)
-        if self.gt_classes_img_stuff:
-            stuff_cls, stuff_cnt, _ = pad_class_lists(self.gt_classes_img_int_stuff, dev)
-            pg = mine_top1(scores, all_boxes, offsets, stuff_cls, stuff_cnt, img_probs)
-            ns = [int(c.numel()) for c in self.gt_classes_img_int_stuff]
+        # pseudo semantic target from the top-1 box of every present stuff class (MIL scores), painted by
+        # libjtsm_hip.so (csrc/mining.hip: paint_*), list lengths never leaving the device
+        if self.has_stuff:
+            pg = mine_top1(scores, all_boxes, offsets, self.stuff_cls, self.stuff_cnt, img_probs)
             h, w = self.images.tensor.shape[-2:]
-            self.pgt_sem_seg = self._paint_sem_seg([pg["boxes"][i, :n] for i, n in enumerate(ns)],
-                                                   [stuff_cls[i, :n] for i, n in enumerate(ns)],
-                                                   [pg["scores"][i, :n] for i, n in enumerate(ns)], h, w)
+            self.pgt_sem_seg = paint_sem_seg(pg["boxes"], self.stuff_cls, pg["scores"], self.stuff_cnt,
+                                             self.num_classes - 1, h, w)
         else:
             self.pgt_sem_seg = None
 
@@ -243,9 +275,9 @@ class JTSMROIHeads(ROIHeads):
             col += 2 if refinery.has_reg else 1
             losses.update(refinery.losses((z, d), all_boxes, lab["labels"], lab["boxes"], lab["weights"]))
             prev_logits, prev_deltas = z.detach(), (d.detach() if d is not None else None)
-            self.aux["pgt_idx_r%d" % k] = [pg["idx"][i, :int(c.numel())].to(torch.int64)
-                                           for i, c in enumerate(self.gt_classes_img_int)]
+            self.aux["pgt_idx_r%d" % k] = pg["idx"]          # (B, num_classes) padded; valid: [:things_cnt[b]]
             self.aux["labels_r%d" % k] = lab["labels"].to(torch.int64)
+        self.aux["things_cnt"] = things_cnt
         self._last_branch = (prev_logits, prev_deltas)
         return losses
 
@@ -260,13 +292,14 @@ class JTSMROIHeads(ROIHeads):
         with torch.no_grad():
             # the head trains on foreground proposals only: a data-dependent count -> the step's one sync
             fg = torch.nonzero(lab["labels"] != self.num_classes)[:, 0]
+            gmax = max(1, int(things_cnt.max()))        # (host value: rides on the synchronisation above)
             gt_classes = lab["labels"][fg].to(torch.int64)
             fg_boxes = all_boxes[fg]
             img_of = torch.bucketize(fg, offsets[1:].to(torch.int64), right=True)          # image of each fg row
-            G = things_cls.shape[1]
+            G = gmax
             # targets: the matched pseudo-GT rectangle (eroded) cropped to the proposal at 28x28 with
             # ROIAlign(1.0, sampling 0, aligned) and thresholded at 0.5 (structures/masks.py:169-200)
-            rect = eroded_rect_masks(pg["boxes"].reshape(-1, 4), height, width)
+            rect = eroded_rect_masks(pg["boxes"][:, :gmax].reshape(-1, 4), height, width)
             rect = rect[:, None].contiguous(memory_format=torch.channels_last)
             gidx = (img_of * G + lab["matched"][fg].to(torch.int64)).to(torch.float32)
             side = 2 * self.mask_pooler.output_size[0]

@@ -77,9 +77,11 @@ def test_integer_artefacts_bit_exact(step):
     a, b = aux["pooled_argmax"].cpu().contiguous(), aux0["pooled_argmax"]
     assert torch.equal(a == -1, b == -1)
     assert (a != b).float().mean().item() < 2e-3
+    cnt = aux["things_cnt"].cpu().tolist()      # padded (B, num_classes) winners; image i has cnt[i] present classes
     for k in range(4):
-        for a, b in zip(aux["pgt_idx_r%d" % k], aux0["pgt_idx_r%d" % k]):
-            assert torch.equal(a.cpu(), b)
+        pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
+        for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
+            assert cnt[i] == b.numel() and torch.equal(pad[i, :cnt[i]], b)
         assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
     assert torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
