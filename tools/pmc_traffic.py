@@ -23,7 +23,7 @@ def label(name):
     m = re.search(r"igemm_x3_wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return "igemm_x3_wgrad_kernel<%s,%s,%s,%s,%s>" % m.groups()
-    m = re.search(r"igemm_x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), 0>", name)
+    m = re.search(r"igemm_x3_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         g = m.groups()
         return "igemm_x3_kernel<%s,%s,%s,%s,%s,%s>" % ((ROLE[g[0]],) + g[1:])
