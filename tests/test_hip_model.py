@@ -138,3 +138,38 @@ def test_full_size_step_is_reproducible_and_finite(cuda):
             continue  # exactly zero in exact arithmetic (see test_gradients_match): rounding noise only
         ref = float(g0[n].abs().max()) + 1e-12
         assert float((g0[n] - g1[n]).abs().max()) <= 1e-4 * ref, n
+
+
+def test_ragged_batch_losses_and_labels(cuda):
+    """Images with different proposal counts and different numbers of present thing / stuff classes (the padded
+    device-side class lists and the per-image bag offsets must cope): losses and integer artefacts vs the oracle."""
+    params = OM.init_params(seed=5, random_bn=True, input_gain=1.0 / 64)
+    batch = OM.synthetic_batch(4321, B=2, size=256, R=160, sp_block=8)
+    keep = 97                                            # image 1 keeps 97 of its 160 proposals
+    for k in ("boxes", "objectness", "oh_labels"):
+        batch[k][1] = batch[k][1][:keep].contiguous()
+    batch["gt_classes"][1] = batch["gt_classes"][1][:2].contiguous()     # 3 thing classes vs 2
+    sem = batch["sem_seg"]
+    stuff1 = [int(v) for v in torch.unique(sem[1]) if int(v) not in (0, 255)]
+    sem[1][sem[1] == stuff1[-1]] = 0                                      # 2 stuff classes vs 1
+    losses0, aux0 = OM.forward_losses(params, batch, return_aux=True)
+
+    model = build_model(jtsm_cfg("cuda"))
+    model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    losses = model(to_batched_inputs(batch))
+    assert set(losses) == set(losses0)
+    for k in sorted(losses0):
+        a, b = float(losses[k].detach()), float(losses0[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
+    aux = model.roi_heads.aux
+    cnt = aux["things_cnt"].cpu().tolist()
+    assert cnt == [3, 2]
+    for k in range(4):
+        pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
+        for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
+            assert torch.equal(pad[i, :cnt[i]], b)
+        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+    assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
+    assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
