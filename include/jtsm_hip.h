@@ -349,6 +349,14 @@ int jtsm_oicr_backward_f32(const float* cls_logits, int ld_cls, int num_cls, con
                            float* d_box, int ld_dbox, void* stream);
 
 
+/* Mask targets of rectangle pseudo ground truth (get_pgt_mask, roi_heads_jtsm.py:1928-1994, with the rectangle
+ * substitution of SURVEY F8; BitMasks.crop_and_resize, detectron2/structures/masks.py:169-200):
+ * out[n] (side x side, 0/1 bytes) = ROIAlign(1.0, sampling_ratio 0, aligned) of the H x W bitmask "pixel centre
+ * inside rects[n] shrunk by erode" over rois[n], thresholded at 0.5.  rois, rects: (N,4) boxes.  The bitmask is
+ * never materialised; the sampling arithmetic is that of jtsm_roi_align_forward_f32. */
+int jtsm_rect_mask_targets_f32(const float* rois, const float* rects, uint8_t* out, int N, int side, int H, int W,
+                               float erode, void* stream);
+
 /* Mask loss — mask_rcnn_loss (detectron2/modeling/roi_heads/mask_head.py:31-112, used by
  * projects/WSL/wsl/modeling/roi_heads/mask_head.py): mean binary cross-entropy with logits between the
  * ground-truth-class channel of logits (N,side,side,ld) NHWC (num_classes <= ld; gt_classes NULL when

@@ -335,6 +335,42 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
   return JTSM_OK;
 }
 
+// ---- mask targets of the pseudo-GT rectangles (get_pgt_mask with the rectangle substitution of SURVEY F8;
+// structures/masks.py:169-200 crop_and_resize = ROIAlign(1.0, sampling 0, aligned) of the instance bitmask).
+// The bitmask of a shrunk rectangle is an analytic image (pixel centre inside the box), so nothing is rasterised:
+// thread (roi, ph, pw) runs the very ROIAlign sampling arithmetic above on that image and thresholds at 0.5.
+__global__ __launch_bounds__(256) void rect_mask_targets_kernel(const float* __restrict__ rois,   // (N,4) boxes
+                                                                const float* __restrict__ rects,  // (N,4) matched pseudo GT
+                                                                unsigned char* __restrict__ out, long total, int side,
+                                                                int H, int W, float erode) {
+#pragma clang fp contract(off)
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % side), ph = (int)((idx / side) % side);
+    const long n = idx / side / side;
+    const float roi5[5] = {0.f, rois[n * 4], rois[n * 4 + 1], rois[n * 4 + 2], rois[n * 4 + 3]};
+    const RoiGeom<float> g = geom_box<float>(roi5, 1.0f, side, side, 0, true);
+    const float* r = rects + n * 4;
+    const float rx0 = r[0] + erode, ry0 = r[1] + erode, rx1 = r[2] - erode, ry1 = r[3] - erode;
+    const int cells = g.gh * g.gw;
+    const float count = (float)(cells > 1 ? cells : 1);
+    float acc = 0.f;
+    for (int iy = 0; iy < g.gh; ++iy)
+      for (int ix = 0; ix < g.gw; ++ix) {
+        const Tap<float> t = sample_tap<float, false>(g, H, W, ph, pw, iy, ix);
+        if (t.pos[0] < 0) continue;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int y = t.pos[k] / W, x = t.pos[k] - y * W;
+          const float xs = (float)x + 0.5f, ys = (float)y + 0.5f;
+          v[k] = (xs >= rx0 && xs <= rx1 && ys >= ry0 && ys <= ry1) ? 1.f : 0.f;
+        }
+        acc += t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
+      }
+    out[idx] = (acc / count) >= 0.5f ? 1 : 0;
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -434,6 +470,19 @@ int jtsm_roi_sample_table_f32(const float* rois, int rotated, int M, int H, int 
                        as_stream(stream), rois, M, H, W, spatial_scale, pooled_h, pooled_w,
                        sampling_ratio, aligned, grid, pos, w, cap);
   JTSM_CHECK_LAUNCH("roi_sample_table");
+  return JTSM_OK;
+}
+
+int jtsm_rect_mask_targets_f32(const float* rois, const float* rects, uint8_t* out, int N, int side, int H, int W,
+                               float erode, void* stream) {
+  JTSM_REQUIRE(N >= 0 && side > 0 && H > 0 && W > 0, "rect_mask_targets: bad sizes");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(rois && rects && out, "rect_mask_targets: null pointer");
+  const long total = (long)N * side * side;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(rect_mask_targets_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), rois, rects, out, total,
+                     side, H, W, erode);
+  JTSM_CHECK_LAUNCH("rect_mask_targets");
   return JTSM_OK;
 }
 

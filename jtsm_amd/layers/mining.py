@@ -79,3 +79,17 @@ def paint_sem_seg(boxes, classes, scores, counts, class_base, height, width, ero
     L.check(lib.jtsm_paint_sem_seg(L.ptr(boxes), L.ptr(classes), L.ptr(scores), L.ptr(counts), B, G, int(class_base),
                                    height, width, L.f32(erode), L.ptr(out), L.ptr(ws), L.stream()), "paint_sem_seg")
     return out
+
+
+@torch.no_grad()
+def rect_mask_targets(rois, rects, side, height, width, erode=2.0):
+    """(N, side, side) bool mask targets: the H x W bitmask of rects[n] shrunk by `erode`, cropped and resized to
+    rois[n] the way BitMasks.crop_and_resize does it (ROIAlign, aligned, adaptive sampling, >= 0.5) — evaluated
+    analytically, no bitmask is rasterised (libjtsm_hip.so: jtsm_rect_mask_targets_f32)."""
+    L.require_gpu(rois, rects)
+    rois, rects = rois.to(torch.float32).contiguous(), rects.to(torch.float32).contiguous()
+    n = rois.shape[0]
+    out = torch.empty((n, side, side), dtype=torch.uint8, device=rois.device)
+    L.check(L.lib().jtsm_rect_mask_targets_f32(L.ptr(rois), L.ptr(rects), L.ptr(out), n, side, height, width,
+                                               L.f32(erode), L.stream()), "rect_mask_targets")
+    return out.to(torch.bool)
