@@ -295,6 +295,12 @@ int jtsm_maxpool3x3s2_forward_f32(const float* x, float* y, int N, int H, int W,
 /* gx is zero-filled by the call; the gradient goes to the first maximum of each window. */
 int jtsm_maxpool3x3s2_backward_f32(const float* x, const float* gy, float* gx, int N, int H, int W,
                                    int C, void* stream);
+/* 2x2 max pooling of the WSL ResNet-v2 backbone (projects/WSL/wsl/modeling/backbone/resnet_wsl_v2.py:157-165,413):
+ * stride 2 = MaxPool2d(2, 2) -> (N, H/2, W/2, C); stride 1 = ZeroPad2d((0,1,0,1)) + MaxPool2d(2, 1) -> (N,H,W,C).
+ * NHWC; backward is a gather (first maximum of a window wins, as ATen). */
+int jtsm_maxpool2x2_forward_f32(const float* x, float* y, int N, int H, int W, int C, int stride, void* stream);
+int jtsm_maxpool2x2_backward_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C,
+                                 int stride, void* stream);
 /* out(N,H,W,C) = lateral(N,H,W,C) + top(N,H/2,W/2,C) repeated 2x2. */
 int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, int N, int H, int W,
                            int C, void* stream);

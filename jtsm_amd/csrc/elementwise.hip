@@ -218,6 +218,68 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdEntry* __restri
   }
 }
 
+// ---- 2x2 max pooling of the WSL ResNet-v2 backbone (projects/WSL/wsl/modeling/backbone/resnet_wsl_v2.py:157-165,
+// 413): MaxPool2d(2, stride 2), or ZeroPad2d((0,1,0,1)) + MaxPool2d(2, stride 1) in the dilated stages.  NHWC,
+// float4 of channels per thread.  Window cells outside the input read the pad value 0 (stride-1 form only).
+__device__ __forceinline__ float4 mp_load(const float4* __restrict__ x, int n, int h, int w, int H, int W, int C4, int c) {
+  if (h >= H || w >= W) return make_float4(0.f, 0.f, 0.f, 0.f);
+  return x[((size_t)(n * H + h) * W + w) * C4 + c];
+}
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(const float4* __restrict__ x, float4* __restrict__ y, int N,
+                                                             int H, int W, int C4, int stride, int Ho, int Wo, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long t = i / C4;
+    const int ow = (int)(t % Wo); t /= Wo;
+    const int oh = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int h = oh * stride, w = ow * stride;
+    const float4 a = mp_load(x, n, h, w, H, W, C4, c), b = mp_load(x, n, h, w + 1, H, W, C4, c);
+    const float4 d = mp_load(x, n, h + 1, w, H, W, C4, c), e = mp_load(x, n, h + 1, w + 1, H, W, C4, c);
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x));
+    o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+    o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z));
+    o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+    y[i] = o;
+  }
+}
+// Backward as a gather: input pixel (h,w) collects from the <= 4 windows that contain it and whose FIRST maximum
+// (window order (0,0),(0,1),(1,0),(1,1), as ATen's max_pool2d_with_indices) it is.
+__device__ __forceinline__ int mp_first_max(float a, float b, float d, float e) {
+  int k = 0; float m = a;
+  if (b > m) { m = b; k = 1; }
+  if (d > m) { m = d; k = 2; }
+  if (e > m) { m = e; k = 3; }
+  return k;
+}
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                             float* __restrict__ gx, int N, int H, int W, int C,
+                                                             int stride, int Ho, int Wo, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long t = i / C;
+    const int w = (int)(t % W); t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc = 0.f;
+    for (int dh = 0; dh < 2; ++dh)
+      for (int dw = 0; dw < 2; ++dw) {
+        const int th = h - dh, tw = w - dw;   // window top-left in input coordinates
+        if (th < 0 || tw < 0 || th % stride || tw % stride) continue;
+        const int oh = th / stride, ow = tw / stride;
+        if (oh >= Ho || ow >= Wo) continue;
+        float v[4];
+        for (int k = 0; k < 4; ++k) {
+          const int hh = th + (k >> 1), ww = tw + (k & 1);
+          v[k] = (hh < H && ww < W) ? x[((size_t)(n * H + hh) * W + ww) * C + c] : 0.f;
+        }
+        if (mp_first_max(v[0], v[1], v[2], v[3]) == dh * 2 + dw) acc += gy[((size_t)(n * Ho + oh) * Wo + ow) * C + c];
+      }
+    gx[i] = acc;
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -351,6 +413,34 @@ int jtsm_sgd_momentum_multi_f32(const void* table, int entries, long blocks, int
   hipLaunchKernelGGL(sgd_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                      reinterpret_cast<const SgdEntry*>(table), entries, first_step);
   JTSM_CHECK_LAUNCH("sgd_multi");
+  return JTSM_OK;
+}
+
+static int mp2_out(int in, int stride) { return stride == 1 ? in : in / 2; }
+
+int jtsm_maxpool2x2_forward_f32(const float* x, float* y, int N, int H, int W, int C, int stride, void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (stride == 1 || stride == 2), "maxpool2x2: bad sizes");
+  const int Ho = mp2_out(H, stride), Wo = mp2_out(W, stride);
+  const long total = (long)N * Ho * Wo * (C / 4);
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && y, "maxpool2x2: null pointer");
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)x, (float4*)y, N,
+                     H, W, C / 4, stride, Ho, Wo, total);
+  JTSM_CHECK_LAUNCH("maxpool2x2 forward");
+  return JTSM_OK;
+}
+
+int jtsm_maxpool2x2_backward_f32(const float* x, const float* gy, float* gx, int N, int H, int W, int C, int stride,
+                                 void* stream) {
+  JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && (stride == 1 || stride == 2), "maxpool2x2 backward: bad sizes");
+  const long total = (long)N * H * W * C;
+  if (total == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && gy && gx, "maxpool2x2 backward: null pointer");
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, gy, gx, N, H, W, C, stride,
+                     mp2_out(H, stride), mp2_out(W, stride), total);
+  JTSM_CHECK_LAUNCH("maxpool2x2 backward");
   return JTSM_OK;
 }
 

@@ -77,6 +77,37 @@ class _MaxPool3s2(torch.autograd.Function):
         return gx
 
 
+class _MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stride):
+        x = _cl4(x)
+        n, c, h, w = x.shape
+        ho, wo = (h, w) if stride == 1 else (h // 2, w // 2)
+        y = torch.empty((n, c, ho, wo), dtype=x.dtype, device=x.device, memory_format=CL)
+        L.check(L.lib().jtsm_maxpool2x2_forward_f32(L.ptr(x), L.ptr(y), n, h, w, c, stride, L.stream()), "maxpool2x2")
+        ctx.save_for_backward(x)
+        ctx.stride = stride
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        n, c, h, w = x.shape
+        gy = gy.contiguous(memory_format=CL)
+        gx = torch.empty_like(x)
+        L.check(L.lib().jtsm_maxpool2x2_backward_f32(L.ptr(x), L.ptr(gy), L.ptr(gx), n, h, w, c, ctx.stride,
+                                                     L.stream()), "maxpool2x2 backward")
+        return gx, None
+
+
+def max_pool_2x2(x, stride=2):
+    """stride 2: F.max_pool2d(x, 2, 2); stride 1: F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, 1) — the two pooling
+    forms of the WSL ResNet-v2 backbone — on a channels_last tensor."""
+    if stride not in (1, 2):
+        raise ValueError("max_pool_2x2: stride must be 1 or 2")
+    return _MaxPool2x2.apply(x, stride)
+
+
 def max_pool_3x3_s2(x):
     """F.max_pool2d(x, kernel_size=3, stride=2, padding=1) on a channels_last tensor."""
     return _MaxPool3s2.apply(x)

@@ -2,3 +2,4 @@ from .backbone import Backbone
 from .build import BACKBONE_REGISTRY, build_backbone
 from .fpn import FPN, LastLevelMaxPool, build_resnet_fpn_backbone
 from .resnet import BasicStem, BottleneckBlock, ResNet, build_resnet_backbone
+from .resnet_wsl_v2 import PooledBottleneckBlock, ThreeConvStem, build_wsl_resnet_v2_backbone

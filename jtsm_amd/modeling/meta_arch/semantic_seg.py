@@ -83,3 +83,34 @@ class SemSegFPNHead(nn.Module):
         else:
             raise NotImplementedError("semantic loss: <= 64 classes on the HIP device only")
         return {"loss_sem_seg": loss * self.loss_weight}
+
+
+@SEM_SEG_HEADS_REGISTRY.register()
+class TwoClassHead(nn.Module):
+    """The parameter-free semantic head of the shipped JTSM configs (projects/WSL/wsl/modeling/seg_heads/
+    seg_heads.py:231-275): a constant two-class map ("everything is class 1"), no loss — those configs train the
+    box and mask branches only."""
+
+    def __init__(self, cfg, input_shape: Dict[str, ShapeSpec]):
+        super().__init__()
+        self.in_features = cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES
+        self.ignore_value = cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE
+        self.common_stride = cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE
+        self.loss_weight = cfg.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT
+        self.scale = int(input_shape[self.in_features[0]].stride / self.common_stride)
+
+    def layers(self, features):
+        f = features[self.in_features[0]]
+        x = torch.zeros((f.size(0), 2, f.size(2) * self.scale, f.size(3) * self.scale), device=f.device,
+                        dtype=torch.float32)
+        x[:, 1] = 1
+        return x
+
+    def losses(self, predictions, targets):
+        return {}
+
+    def forward(self, features, targets=None):
+        if self.training:
+            return None, {}
+        x = self.layers(features)
+        return F.interpolate(x, scale_factor=self.common_stride, mode="bilinear", align_corners=False), {}

@@ -12,7 +12,8 @@ from ..structures import Boxes, Instances
 NUM_THINGS, NUM_STUFF = 80, 54
 
 
-def synthetic_inputs(seed, batch=2, size=1024, proposals=2000, sp_block=32, n_things=3, n_stuff=2, device="cpu"):
+def synthetic_inputs(seed, batch=2, size=1024, proposals=2000, sp_block=32, n_things=3, n_stuff=2, device="cpu",
+                     num_things=NUM_THINGS, num_stuff=NUM_STUFF):
     g = torch.Generator().manual_seed(seed)
     grid = size // sp_block
     ids = ((torch.arange(size)[:, None] // sp_block) * grid + (torch.arange(size)[None, :] // sp_block)).to(torch.int32)
@@ -30,10 +31,10 @@ def synthetic_inputs(seed, batch=2, size=1024, proposals=2000, sp_block=32, n_th
         iny = (centres[None, :] >= boxes[:, 1:2]) & (centres[None, :] <= boxes[:, 3:4])
         inx = (centres[None, :] >= boxes[:, 0:1]) & (centres[None, :] <= boxes[:, 2:3])
         oh = (iny[:, :, None] & inx[:, None, :]).reshape(proposals, -1).to(torch.int32)
-        things = torch.randperm(NUM_THINGS, generator=g)[:n_things].sort().values
-        stuff = torch.randperm(NUM_STUFF - 1, generator=g)[:n_stuff] + 1
+        things = torch.randperm(num_things, generator=g)[:n_things].sort().values
+        stuff = torch.randperm(num_stuff - 1, generator=g)[:min(n_stuff, num_stuff - 1)] + 1
         sem = torch.zeros(size, size, dtype=torch.int64)
-        band = size // (n_stuff + 1)
+        band = size // (len(stuff) + 1)
         for j, s in enumerate(stuff):
             sem[(j + 1) * band:(j + 2) * band] = s
         sem[:8] = 255

@@ -1,0 +1,106 @@
+"""GPU suite: the shipped JTSM configuration — ResNet-WS v2, dilated C5, frozen backbone,
+single-level MOIPool — on the HIP path.  The backbone is checked against the same architecture written with
+stock torch operators on the CPU (fp64) from the same weights; the composite is run for one training step."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+from jtsm_amd.config import add_wsl_config, get_cfg  # noqa: E402
+from jtsm_amd.layers.elementwise import max_pool_2x2  # noqa: E402
+from jtsm_amd.modeling import build_model  # noqa: E402
+from jtsm_amd.utils.synthetic import synthetic_inputs  # noqa: E402
+
+
+def dc5_cfg(device):
+    cfg = get_cfg()
+    add_wsl_config(cfg)
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "jtsm_WSR_50_DC5_1x.yaml"))
+    cfg.MODEL.DEVICE = device
+    return cfg
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_max_pool_2x2_matches_torch(cuda, stride):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 9, 11, generator=g)
+    x[0, :, 2:4, 2:4] = 1.5            # ties inside windows: the first maximum must take the gradient
+    x0 = x.clone().double().requires_grad_(True)
+    y0 = F.max_pool2d(x0, 2, 2) if stride == 2 else F.max_pool2d(F.pad(x0, (0, 1, 0, 1)), 2, 1)
+    gy = torch.randn(y0.shape, generator=g)
+    y0.backward(gy.double())
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = max_pool_2x2(xd, stride)
+    assert torch.equal(y.cpu(), y0.detach().float())
+    y.backward(gy.to(cuda))
+    assert torch.allclose(xd.grad.cpu(), x0.grad.float(), rtol=0, atol=1e-6)
+
+
+def _bn(x, norm):
+    scale = norm.weight * (norm.running_var + norm.eps).rsqrt()
+    return x * scale.view(1, -1, 1, 1) + (norm.bias - norm.running_mean * scale).view(1, -1, 1, 1)
+
+
+def _conv(x, m):
+    return _bn(F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation), m.norm)
+
+
+def stock_v2_forward(backbone, x):
+    """The ResNet-WS v2 forward written with stock operators (resnet_wsl_v2.py:230-251,418-429,499-523)."""
+    s = backbone.stem
+    x = F.relu(_conv(x, s.conv1)); x = F.relu(_conv(x, s.conv2)); x = F.relu(_conv(x, s.conv3))
+    x = F.max_pool2d(x, 2, 2)
+    for stage in backbone.stages:
+        for b in stage:
+            if b.has_pool:
+                x = F.max_pool2d(x, 2, 2) if b.pool_stride == 2 else F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, 1)
+            out = F.relu(_conv(x, b.conv1)); out = F.relu(_conv(out, b.conv2)); out = _conv(out, b.conv3)
+            x = F.relu(out + (_conv(x, b.shortcut) if b.shortcut is not None else x))
+    return x
+
+
+def test_dc5_backbone_features_match_stock_torch(cuda):
+    torch.manual_seed(0)
+    model = build_model(dc5_cfg("cuda"))
+    bb = model.backbone
+    with torch.no_grad():
+        for m in bb.modules():           # non-trivial frozen-BN statistics
+            if hasattr(m, "running_var"):
+                m.running_var.uniform_(0.5, 1.5); m.running_mean.normal_(0, 0.1)
+                m.weight.uniform_(0.8, 1.2); m.bias.normal_(0, 0.1)
+        bb.stem.conv1.weight.mul_(1.0 / 64)
+    assert bb.output_shape()["res5"].stride == 8 and bb.output_shape()["res5"].channels == 2048
+    assert not any(p.requires_grad for p in bb.parameters())           # FREEZE_AT 5
+    x = torch.rand(2, 3, 96, 128) * 255
+    y = bb(x.to(cuda).contiguous(memory_format=torch.channels_last))["res5"]
+    assert tuple(y.shape) == (2, 2048, 12, 16)
+    ref = stock_v2_forward(bb.double().cpu(), x.double())
+    err = (y.detach().cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 1e-4, err
+
+
+def test_dc5_composite_training_step(cuda):
+    """One training step of the shipped configuration: only head parameters train, every loss is finite, the
+    (parameter-free) semantic head contributes none."""
+    torch.manual_seed(0)
+    model = build_model(dc5_cfg("cuda"))
+    model.train()
+    with torch.no_grad():
+        model.backbone.stem.conv1.weight.mul_(1.0 / 64)
+    inputs = synthetic_inputs(99, batch=2, size=256, proposals=120, sp_block=8, device=cuda, num_things=20, num_stuff=2,
+                              n_stuff=1)
+    losses = model(inputs)
+    assert "loss_sem_seg" not in losses and {"loss_cls", "loss_mask", "loss_cls_r3", "loss_box_reg_r3"} <= set(losses)
+    total = sum(losses.values())
+    assert bool(torch.isfinite(total))
+    total.backward()
+    for n, p in model.named_parameters():
+        if n.startswith("backbone."):
+            assert p.grad is None, n
+        elif p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
