@@ -272,9 +272,24 @@ __device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short*
 // rows — 512 contiguous bytes per 32 lanes — through the scale / bias / residual / ReLU / gate chain.
 // Short-K layers (1x1 convolutions into wide outputs) are bound by exactly this traffic.
 // Needs N % 4 == 0, ldc % 4 == 0 and 16-byte aligned C / residual / mask / slab (checked by the launcher).
-template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256>
+// Which output row a tile row is: consecutive rows of the GEMM (the default), or a TH x TW block of pixels of one
+// image (the halo kernels, whose M tile is a 2-D patch).  -1 = outside the tensor.
+struct LinearRows {
+  int m0, M;
+  __device__ __forceinline__ int operator()(int row) const { const int m = m0 + row; return m < M ? m : -1; }
+};
+struct PatchRows {
+  int b, y0, x0, OH, OW, TW;
+  __device__ __forceinline__ int operator()(int row) const {
+    const int y = y0 + row / TW, x = x0 + row % TW;
+    return (y < OH && x < OW) ? (b * OH + y) * OW + x : -1;
+  }
+};
+
+template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256, class MAP = LinearRows>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
-                                                int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */) {
+                                                int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */,
+                                                const MAP* map = nullptr) {
   // PASSES > 1: the tile goes through a smaller LDS window in row bands of BM / PASSES (single-buffered kernels)
   constexpr int ROWS = BM / PASSES;
   static_assert(ROWS % (32 * TM) == 0, "a band holds whole wave tiles");
@@ -302,8 +317,9 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
     for (int it = 0; it < PIECES; ++it) {
       const int c = tid + NT * it;
       const int row = c / CPR, col = (c % CPR) * 4;
-      const int m = m0 + pass * ROWS + row, n = n0 + col;
-      if (m >= p.M || n >= p.N) continue;
+      const int m = map ? (*map)(pass * ROWS + row) : m0 + pass * ROWS + row;
+      const int n = n0 + col;
+      if (m < 0 || m >= p.M || n >= p.N) continue;
       float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
       if (raw) {
         *reinterpret_cast<float4*>(p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n) = v;

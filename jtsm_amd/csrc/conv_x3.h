@@ -234,6 +234,216 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
     store_tile<ROLE, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- k x k convolutions with an LDS-resident input halo -----------------------------------------------
+// The generic kernel above fetches the A operand once per filter tap: a 3x3 layer moves its activations nine
+// times from L2 to LDS.  Here the M tile is a TH x TW patch of output pixels of one image; for each block of 32
+// channels the (TH + (KH-1)d) x (TW + (KW-1)d) input halo is loaded ONCE and the taps read it at shifted row
+// offsets, so only the weights are streamed per tap: ~42 % fewer operand bytes for 3x3 at 128 x 128.
+// Stride 1 only.  FWD: source X, tap (kh,kw) reads halo row + kh*d.  DGRAD: source dY, taps mirrored.
+// K order: channel block outer, taps inner (any order sums to the same product; split-K cuts channel blocks).
+template <int ROLE, int HP16 /* 16-row groups of the halo image */>
+__global__ __launch_bounds__(256, 2) void igemm_x3_halo_kernel(const Params p, const X3Planes q) {
+  static_assert(ROLE == FWD || ROLE == DGRAD, "halo kernel: forward and data-gradient roles");
+  constexpr int TH = 8, TW = 16, BM = TH * TW, BN = 128, TM = 2, TN = 2, WN = 2;
+  constexpr int A_PL = HP16 * 1024;          // bytes per plane of one halo buffer
+  constexpr int B_PL = BN * 64;              // bytes per plane of one weight stage
+  constexpr int A_BUF = 2 * A_PL, B_BUF = 2 * B_PL;
+  constexpr int A_J = (HP16 + 3) / 4;        // halo loads per wavefront per plane
+  __shared__ __attribute__((aligned(16))) char lds[2 * A_BUF + 2 * B_BUF];
+  char* const Abase = lds;
+  char* const Bbase = lds + 2 * A_BUF;
+
+  const ConvShape& s = p.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int half = lane >> 5, li = lane & 31;
+  const int d = s.dil, taps = s.KH * s.KW;
+  const int HPW = TW + (s.KW - 1) * d, HP = (TH + (s.KH - 1) * d) * HPW;
+  // source / output geometry of this role
+  const int SH = ROLE == FWD ? s.H : s.Ho, SW = ROLE == FWD ? s.W : s.Wo;     // source image
+  const int OH = ROLE == FWD ? s.Ho : s.H, OW = ROLE == FWD ? s.Wo : s.W;     // output image
+  const int Cdim = ROLE == FWD ? s.Cin : s.Cout;
+
+  const int ntn = (p.N + BN - 1) / BN;
+  const int tH = (OH + TH - 1) / TH, tW = (OW + TW - 1) / TW;
+  const int ntiles = ntn * s.Bn * tH * tW;
+  int tile = blockIdx.x;
+  {
+    const int qq = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
+    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+  }
+  const int n0 = (tile % ntn) * BN;
+  int mt = tile / ntn;
+  const int tx = mt % tW; mt /= tW;
+  const int ty = mt % tH;
+  const int b = mt / tH;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  // halo origin in the source image
+  const int hy0 = ROLE == FWD ? oy0 - s.pad : oy0 + s.pad - (s.KH - 1) * d;
+  const int hx0 = ROLE == FWD ? ox0 - s.pad : ox0 + s.pad - (s.KW - 1) * d;
+
+  const int Cb = Cdim / XBK;
+  int cb0 = 0, cb1 = Cb;
+  if (gridDim.y > 1) {
+    cb0 = blockIdx.y * p.ktiles_per_split;
+    cb1 = min(Cb, cb0 + p.ktiles_per_split);
+  }
+  const int nstage = cb0 < cb1 ? (cb1 - cb0) * taps : 0;
+
+  // ---- halo loads: load T = wave + 4j covers halo rows 16T .. 16T+15; this lane owns row 16T + lane/4
+  int a_base[A_J];
+  bool a_ok[A_J];
+#pragma unroll
+  for (int j = 0; j < A_J; ++j) {
+    const int T = wave + 4 * j;
+    const int hp = 16 * T + (lane >> 2);
+    const int hy = hp / HPW, hx = hp - hy * HPW;
+    const int y = hy0 + hy, x = hx0 + hx;
+    a_ok[j] = T < HP16 && hp < HP && (unsigned)y < (unsigned)SH && (unsigned)x < (unsigned)SW;
+    a_base[j] = ((b * SH + y) * SW + x) * Cdim + 8 * ((lane & 3) ^ ((hp >> 2) & 3));
+  }
+  int b_off[2], b_chunk[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = (wave * 2 + j) * 16 + (lane >> 2);
+    b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
+    b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
+  }
+  const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
+
+  constexpr int A_PIECES = 2 * A_J, B_PIECES = 4;
+  auto issue_a_piece = [&](int idx, int cb, int buf) {
+    const int j = idx >> 1, lo = idx & 1;
+    const int T = wave + 4 * j;
+    if (T >= HP16) return;   // wave-uniform
+    const __bf16* src = q.A_hi + (a_base[j] + cb * XBK) + (lo ? lo_delta_a : 0);
+    dma16b(a_ok[j] ? (const void*)src : (const void*)g_zero_page, Abase + buf * A_BUF + lo * A_PL + T * 1024);
+  };
+  auto issue_b_piece = [&](int idx, int cb, int tap, int buf) {
+    const int j = idx >> 1, lo = idx & 1;
+    const __bf16* src = q.B_hi + (b_off[j] + tap * Cdim + cb * XBK + b_chunk[j]) + (lo ? lo_delta_b : 0);
+    dma16b(b_off[j] >= 0 ? (const void*)src : (const void*)g_zero_page,
+           Bbase + buf * B_BUF + lo * B_PL + (wave * 2 + j) * 1024);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment rows: A row = local output pixel -> halo pixel of tap (0,0); B as in the generic kernel
+  int hp0[TM], bb_off[TN], b_swz[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int ml = (wm * TM + t) * 32 + li;
+    hp0[t] = (ml / TW) * HPW + (ml % TW);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int br = (wn * TN + t) * 32 + li;
+    bb_off[t] = br * 64;
+    b_swz[t] = (br >> 2) & 3;
+  }
+
+  if (nstage > 0) {
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) issue_a_piece(i, cb0, 0);
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) issue_b_piece(i, cb0, 0, 0);
+  }
+  int cb = cb0, tap = 0, kh = 0, kw = 0;
+  for (int st = 0; st < nstage; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the stage after this one
+    int ntap = tap + 1, ncb = cb;
+    if (ntap == taps) { ntap = 0; ++ncb; }
+    const bool more = st + 1 < nstage;          // wave-uniform
+    const bool new_halo = more && ntap == 0;
+    const int abuf = (cb - cb0) & 1, bbuf = st & 1;
+    const char* Ab = Abase + abuf * A_BUF;
+    const char* Bb = Bbase + bbuf * B_BUF;
+    const int dy = (ROLE == FWD ? kh : s.KH - 1 - kh) * d, dx = (ROLE == FWD ? kw : s.KW - 1 - kw) * d;
+    int a_row[TM], a_swz[TM];
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int hp = hp0[t] + dy * HPW + dx;
+      a_row[t] = hp * 64;
+      a_swz[t] = (hp >> 2) & 3;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = 2 * ks + half;
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int u = 0; u < TM; ++u) {
+        const int ao = a_row[u] + ((c ^ a_swz[u]) << 4);
+        ah[u] = *reinterpret_cast<const bf16x8*>(Ab + ao);
+        al[u] = *reinterpret_cast<const bf16x8*>(Ab + A_PL + ao);
+      }
+#pragma unroll
+      for (int u = 0; u < TN; ++u) {
+        const int bo = bb_off[u] + ((c ^ b_swz[u]) << 4);
+        bh[u] = *reinterpret_cast<const bf16x8*>(Bb + bo);
+        bl[u] = *reinterpret_cast<const bf16x8*>(Bb + B_PL + bo);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          const int slot = (ks * TM + i) * TN + j;   // 0..7: one weight load behind groups 0-3, halo loads behind 4-7
+          if (more) {
+            if (slot < B_PIECES) issue_b_piece(slot, ncb, ntap, bbuf ^ 1);
+            else if (new_halo) {
+#pragma unroll
+              for (int e = 0; e < (A_PIECES + 3) / 4; ++e) {
+                const int idx = (slot - B_PIECES) * ((A_PIECES + 3) / 4) + e;
+                if (idx < A_PIECES) issue_a_piece(idx, ncb, abuf ^ 1);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    tap = ntap; cb = ncb;
+    if (++kw == s.KW) { kw = 0; if (++kh == s.KH) kh = 0; }
+  }
+  const PatchRows rows = {b, oy0, ox0, OH, OW, TW};
+  if (p.wide)
+    store_tile_wide<ROLE, BM, BN, 1, TM, TN, 256, PatchRows>(p, acc, 0, n0, wm, wn, lane, tid,
+                                                             reinterpret_cast<float*>(lds), &rows);
+  else {
+    // (narrow fallback: scalar stores through the same row map)
+    const Epilogue& e = p.e;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = rows((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+          if (m < 0) continue;
+          float v = acc[i][j][r];
+          if (gridDim.y > 1) { p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v; continue; }
+          const size_t o = (size_t)m * p.ldc + n;
+          v = v * (e.scale ? e.scale[n] : 1.f) + (e.bias ? e.bias[n] : 0.f);
+          if (e.residual) v += e.residual[o];
+          if (e.relu) v = fmaxf(v, 0.f);
+          if (e.mask) v = e.mask[o] > 0.f ? v : 0.f;
+          p.C[o] = v;
+        }
+    }
+  }
+}
+
 // ---- weight gradient ------------------------------------------------------------------------------
 // dW[co][tap][ci] += sum_p dY[p][co] * X[pix(p,tap)][ci]: K runs over pixels, and both operands are
 // CHANNEL-contiguous in memory, i.e. k-major.  A stage holds 32 pixels x 128 channels per plane as plain
@@ -616,8 +826,49 @@ inline int x3_wanted_splits(const Params& p) {
   return plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ceil_div(p.K, XBK), c == 2 ? 256 : 512);
 }
 
+// The halo kernel serves k x k (k > 1), stride-1, undilated layers whose contracted channels come in blocks of 32
+// and whose (8+k-1) x (16+k-1) halo fits twelve 16-row groups (3x3).
+inline bool x3_halo_ok(int role, const Params& p) {
+  const ConvShape& s = p.s;
+  const int c = role == FWD ? s.Cin : s.Cout;
+  const int OH = role == FWD ? s.Ho : s.H, OW = role == FWD ? s.Wo : s.W;
+  // maps below 32 x 32 waste too much of the 8 x 16 patches; layers large enough for 256 x 256 tiles stay there
+  // (measured equal or better, scratch/x3_sweep.py)
+  return !p.scatter && s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && c % XBK == 0 && p.N > 64 &&
+         OH >= 32 && OW >= 32 && x3_tile_choice(p) != 2;
+}
+
+template <int ROLE>
+int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  const ConvShape& s = p.s;
+  const int OH = ROLE == FWD ? s.Ho : s.H, OW = ROLE == FWD ? s.Wo : s.W;
+  const int ntiles = ceil_div(p.N, 128) * s.Bn * ceil_div(OH, 8) * ceil_div(OW, 16);
+  const int Cb = (ROLE == FWD ? s.Cin : s.Cout) / XBK;
+  // split-K cuts whole channel blocks (nine stages each): aim at one round of 512 workgroups
+  int splits = ntiles >= 512 ? 1 : 512 / ntiles;
+  if (splits > Cb) splits = Cb;
+  if (splits > 16) splits = 16;
+  if (splits < 1) splits = 1;
+  if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
+  if (splits > 1) {
+    p.ktiles_per_split = ceil_div(Cb, splits);
+    splits = ceil_div(Cb, p.ktiles_per_split);
+    p.slab = reinterpret_cast<float*>(workspace);
+  }
+  p.wide = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && (splits <= 1 || aligned16(p.slab)) &&
+           (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
+           (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
+  JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
+  hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 12>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
+  JTSM_CHECK_LAUNCH("igemm bf16x3 halo");
+  record_mid(st);
+  if (splits > 1) return finish_split(p, splits, st);
+  return JTSM_OK;
+}
+
 template <int ROLE>
 int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
+  if (x3_halo_ok(ROLE, p)) return launch_x3_halo<ROLE>(p, q, workspace, workspace_bytes, st);
   switch (x3_tile_choice(p)) {
     case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2>(p, q, workspace, workspace_bytes, 512, st);
     case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4>(p, q, workspace, workspace_bytes, 256, st);
