@@ -241,7 +241,8 @@ int jtsm_split_bf16_multi_f32(const void* table, int entries, long blocks, int t
 int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role);
 /* What a bf16x3 call of this shape launches (given the advertised workspace): the template arguments of
  * igemm_x3_kernel<role,WM,WN,TM,TN,NBUF> (role 0/1) or igemm_x3_wgrad_kernel<WM,WN,TM,TN,NBUF> (role 2) —
- * WM x WN wavefronts of TM x TN 32x32 MFMA tiles — and the number of K slices. */
+ * WM x WN wavefronts of TM x TN 32x32 MFMA tiles — and the number of K slices.  *nbuf == 0 reports the LDS-halo
+ * 3x3 kernel igemm_x3_halo_kernel<role,TH,WM,WN,TN,HP16> (TH = 8 * WM / 2 patch rows, HP16 = 12 or 21). */
 int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, int* tm, int* tn, int* nbuf,
                           int* splits);
 /* y_hi / y_lo (both or neither; needs out_c % 4 == 0): the planes of the finished output y, written by the

@@ -1337,11 +1337,24 @@ int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, 
     const int c = x3_tile_choice(p);
     if (c == 1) { cfg[0] = 4; cfg[1] = 1; }
     if (c == 2) { cfg[0] = 4; cfg[1] = 2; cfg[2] = 2; cfg[3] = 4; }
-    sp = x3_wanted_splits(p);
-    const int ktiles = ceil_div(p.K, XBK);
-    const int kps = ceil_div(ktiles, sp);
-    sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
-    if (c != 2 && ceil_div(ktiles, sp) <= 4) nb = 1;
+    if (x3_halo_ok(role, p)) {   // reported as NBUF = 0: igemm_x3_halo_kernel<role, TH, WM, WN, TN, HP16>
+      const bool big = c == 2;
+      const int OH = role == FWD ? p.s.Ho : p.s.H, OW = role == FWD ? p.s.Wo : p.s.W;
+      const int ntiles = ceil_div(p.N, big ? 256 : 128) * p.s.Bn * ceil_div(OH, big ? 16 : 8) * ceil_div(OW, 16);
+      const int Cb = (role == FWD ? p.s.Cin : p.s.Cout) / XBK, round_blocks = big ? 256 : 512;
+      sp = ntiles >= round_blocks ? 1 : round_blocks / ntiles;
+      if (sp > Cb) sp = Cb;
+      if (sp > 16) sp = 16;
+      if (sp < 1) sp = 1;
+      sp = ceil_div(Cb, ceil_div(Cb, sp));
+      nb = 0;
+    } else {
+      sp = x3_wanted_splits(p);
+      const int ktiles = ceil_div(p.K, XBK);
+      const int kps = ceil_div(ktiles, sp);
+      sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
+      if (c != 2 && ceil_div(ktiles, sp) <= 4) nb = 1;
+    }
   }
   if (wm) *wm = cfg[0];
   if (wn) *wn = cfg[1];

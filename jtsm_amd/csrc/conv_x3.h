@@ -241,14 +241,19 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
 // offsets, so only the weights are streamed per tap: ~42 % fewer operand bytes for 3x3 at 128 x 128.
 // Stride 1 only.  FWD: source X, tap (kh,kw) reads halo row + kh*d.  DGRAD: source dY, taps mirrored.
 // K order: channel block outer, taps inner (any order sums to the same product; split-K cuts channel blocks).
-template <int ROLE, int HP16 /* 16-row groups of the halo image */>
-__global__ __launch_bounds__(256, 2) void igemm_x3_halo_kernel(const Params p, const X3Planes q) {
+// Two shapes: 8 x 16 pixels x 128 channels (4 wavefronts, 80 KiB, two workgroups per CU) and 16 x 16 pixels x 256
+// channels (8 wavefronts, 148 KiB) for the layers that fill the chip with 256-wide tiles.
+template <int ROLE, int TH, int WM, int WN, int TN, int HP16 /* 16-row groups of the halo image */>
+__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Params p, const X3Planes q) {
   static_assert(ROLE == FWD || ROLE == DGRAD, "halo kernel: forward and data-gradient roles");
-  constexpr int TH = 8, TW = 16, BM = TH * TW, BN = 128, TM = 2, TN = 2, WN = 2;
+  constexpr int TW = 16, TM = 2, NW = WM * WN, NT = 64 * NW;
+  constexpr int BM = TH * TW, BN = 32 * WN * TN;
+  static_assert(BM == 32 * WM * TM, "patch rows = wavefront rows");
   constexpr int A_PL = HP16 * 1024;          // bytes per plane of one halo buffer
   constexpr int B_PL = BN * 64;              // bytes per plane of one weight stage
   constexpr int A_BUF = 2 * A_PL, B_BUF = 2 * B_PL;
-  constexpr int A_J = (HP16 + 3) / 4;        // halo loads per wavefront per plane
+  constexpr int A_J = (HP16 + NW - 1) / NW;  // halo loads per wavefront per plane
+  constexpr int B_J = BN / 16 / NW;          // weight loads per wavefront per plane
   __shared__ __attribute__((aligned(16))) char lds[2 * A_BUF + 2 * B_BUF];
   char* const Abase = lds;
   char* const Bbase = lds + 2 * A_BUF;
@@ -295,26 +300,26 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_halo_kernel(const Params p, c
   bool a_ok[A_J];
 #pragma unroll
   for (int j = 0; j < A_J; ++j) {
-    const int T = wave + 4 * j;
+    const int T = wave + NW * j;
     const int hp = 16 * T + (lane >> 2);
     const int hy = hp / HPW, hx = hp - hy * HPW;
     const int y = hy0 + hy, x = hx0 + hx;
     a_ok[j] = T < HP16 && hp < HP && (unsigned)y < (unsigned)SH && (unsigned)x < (unsigned)SW;
     a_base[j] = ((b * SH + y) * SW + x) * Cdim + 8 * ((lane & 3) ^ ((hp >> 2) & 3));
   }
-  int b_off[2], b_chunk[2];
+  int b_off[B_J], b_chunk[B_J];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int r = (wave * 2 + j) * 16 + (lane >> 2);
+  for (int j = 0; j < B_J; ++j) {
+    const int r = (wave * B_J + j) * 16 + (lane >> 2);
     b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
     b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
   }
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
 
-  constexpr int A_PIECES = 2 * A_J, B_PIECES = 4;
+  constexpr int A_PIECES = 2 * A_J, B_PIECES = 2 * B_J;
   auto issue_a_piece = [&](int idx, int cb, int buf) {
     const int j = idx >> 1, lo = idx & 1;
-    const int T = wave + 4 * j;
+    const int T = wave + NW * j;
     if (T >= HP16) return;   // wave-uniform
     const __bf16* src = q.A_hi + (a_base[j] + cb * XBK) + (lo ? lo_delta_a : 0);
     dma16b(a_ok[j] ? (const void*)src : (const void*)g_zero_page, Abase + buf * A_BUF + lo * A_PL + T * 1024);
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_halo_kernel(const Params p, c
     const int j = idx >> 1, lo = idx & 1;
     const __bf16* src = q.B_hi + (b_off[j] + tap * Cdim + cb * XBK + b_chunk[j]) + (lo ? lo_delta_b : 0);
     dma16b(b_off[j] >= 0 ? (const void*)src : (const void*)g_zero_page,
-           Bbase + buf * B_BUF + lo * B_PL + (wave * 2 + j) * 1024);
+           Bbase + buf * B_BUF + lo * B_PL + (wave * B_J + j) * 1024);
   };
 
   f32x16 acc[TM][TN];
@@ -397,13 +402,16 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_halo_kernel(const Params p, c
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          const int slot = (ks * TM + i) * TN + j;   // 0..7: one weight load behind groups 0-3, halo loads behind 4-7
+          // MFMA groups 0 .. B_PIECES-1 are each followed by one weight load of the next stage, the remaining
+          // groups by the next channel block's halo loads (when the next stage starts one)
+          constexpr int SLOTS = 2 * TM * TN, A_SLOTS = SLOTS - B_PIECES, A_PER = (A_PIECES + A_SLOTS - 1) / A_SLOTS;
+          const int slot = (ks * TM + i) * TN + j;
           if (more) {
             if (slot < B_PIECES) issue_b_piece(slot, ncb, ntap, bbuf ^ 1);
             else if (new_halo) {
 #pragma unroll
-              for (int e = 0; e < (A_PIECES + 3) / 4; ++e) {
-                const int idx = (slot - B_PIECES) * ((A_PIECES + 3) / 4) + e;
+              for (int e = 0; e < A_PER; ++e) {
+                const int idx = (slot - B_PIECES) * A_PER + e;
                 if (idx < A_PIECES) issue_a_piece(idx, ncb, abuf ^ 1);
               }
             }
@@ -415,9 +423,12 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_halo_kernel(const Params p, c
     if (++kw == s.KW) { kw = 0; if (++kh == s.KH) kh = 0; }
   }
   const PatchRows rows = {b, oy0, ox0, OH, OW, TW};
+  constexpr int LDSB = 2 * A_BUF + 2 * B_BUF;
+  constexpr int PASSES = LDSB >= BM * BN * 4 ? 1 : 2;
+  static_assert(LDSB >= BM * BN * 4 / PASSES, "epilogue band does not fit");
   if (p.wide)
-    store_tile_wide<ROLE, BM, BN, 1, TM, TN, 256, PatchRows>(p, acc, 0, n0, wm, wn, lane, tid,
-                                                             reinterpret_cast<float*>(lds), &rows);
+    store_tile_wide<ROLE, BM, BN, PASSES, TM, TN, NT, PatchRows>(p, acc, 0, n0, wm, wn, lane, tid,
+                                                                 reinterpret_cast<float*>(lds), &rows);
   else {
     // (narrow fallback: scalar stores through the same row map)
     const Epilogue& e = p.e;
@@ -835,17 +846,19 @@ inline bool x3_halo_ok(int role, const Params& p) {
   // maps below 32 x 32 waste too much of the 8 x 16 patches; layers large enough for 256 x 256 tiles stay there
   // (measured equal or better, scratch/x3_sweep.py)
   return !p.scatter && s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && c % XBK == 0 && p.N > 64 &&
-         OH >= 32 && OW >= 32 && x3_tile_choice(p) != 2;
+         OH >= 32 && OW >= 32;
 }
 
-template <int ROLE>
+template <int ROLE, bool BIG>
 int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const ConvShape& s = p.s;
+  constexpr int TH = BIG ? 16 : 8, BN = BIG ? 256 : 128;
   const int OH = ROLE == FWD ? s.Ho : s.H, OW = ROLE == FWD ? s.Wo : s.W;
-  const int ntiles = ceil_div(p.N, 128) * s.Bn * ceil_div(OH, 8) * ceil_div(OW, 16);
+  const int ntiles = ceil_div(p.N, BN) * s.Bn * ceil_div(OH, TH) * ceil_div(OW, 16);
   const int Cb = (ROLE == FWD ? s.Cin : s.Cout) / XBK;
-  // split-K cuts whole channel blocks (nine stages each): aim at one round of 512 workgroups
-  int splits = ntiles >= 512 ? 1 : 512 / ntiles;
+  // split-K cuts whole channel blocks (nine stages each): aim at one round of resident workgroups
+  const int round_blocks = BIG ? 256 : 512;
+  int splits = ntiles >= round_blocks ? 1 : round_blocks / ntiles;
   if (splits > Cb) splits = Cb;
   if (splits > 16) splits = 16;
   if (splits < 1) splits = 1;
@@ -859,7 +872,9 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
-  hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 12>), dim3(ntiles, splits > 1 ? splits : 1), dim3(256), 0, st, p, q);
+  const dim3 grid(ntiles, splits > 1 ? splits : 1);
+  if (BIG) hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 16, 4, 2, 4, 21>), grid, dim3(512), 0, st, p, q);
+  else hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 8, 2, 2, 2, 12>), grid, dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 halo");
   record_mid(st);
   if (splits > 1) return finish_split(p, splits, st);
@@ -868,7 +883,10 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
 
 template <int ROLE>
 int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  if (x3_halo_ok(ROLE, p)) return launch_x3_halo<ROLE>(p, q, workspace, workspace_bytes, st);
+  if (x3_halo_ok(ROLE, p)) {
+    if (x3_tile_choice(p) == 2) return launch_x3_halo<ROLE, true>(p, q, workspace, workspace_bytes, st);
+    return launch_x3_halo<ROLE, false>(p, q, workspace, workspace_bytes, st);
+  }
   switch (x3_tile_choice(p)) {
     case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2>(p, q, workspace, workspace_bytes, 512, st);
     case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4>(p, q, workspace, workspace_bytes, 256, st);

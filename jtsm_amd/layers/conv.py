@@ -247,6 +247,9 @@ def _x3_variant(s, role):
     wm, wn, tm, tn, nbuf, _ = [x.value for x in v]
     if role == 2:
         return "igemm_x3_wgrad_kernel<%d,%d,%d,%d,%d>" % (wm, wn, tm, tn, nbuf)
+    if nbuf == 0:   # the LDS-halo 3x3 kernel
+        return "igemm_x3_halo_kernel<%s,%d,%d,%d,%d,%d>" % (_ROLE_NAME[role], 16 if wm == 4 else 8, wm, wn, tn,
+                                                           21 if wm == 4 else 12)
     return "igemm_x3_kernel<%s,%d,%d,%d,%d,%d>" % (_ROLE_NAME[role], wm, wn, tm, tn, nbuf)
 
 

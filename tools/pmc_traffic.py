@@ -27,6 +27,10 @@ def label(name):
     if m:
         g = m.groups()
         return "igemm_x3_kernel<%s,%s,%s,%s,%s,%s>" % ((ROLE[g[0]],) + g[1:])
+    m = re.search(r"igemm_x3_halo_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", name)
+    if m:
+        g = m.groups()
+        return "igemm_x3_halo_kernel<%s,%s,%s,%s,%s,%s>" % ((ROLE[g[0]],) + g[1:])
     m = re.search(r"igemm_dma_kernel<(\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         g = m.groups()
