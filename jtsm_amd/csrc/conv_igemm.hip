@@ -1227,7 +1227,24 @@ static bool x3_wgrad_big(const Params& p) {
   return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, scratch/wgrad_sweep.py)
 }
 
+// The LDS-halo weight gradient: 3x3, stride 1, undilated, 32-channel input blocks, output rows of whole 32-pixel
+// segments, and enough pixels to feed the split.
+static bool x3_wgrad_halo(const Params& p) {
+  static const bool on = !(getenv("JTSM_X3_WGRAD_HALO") && atoi(getenv("JTSM_X3_WGRAD_HALO")) == 0);
+  const ConvShape& s = p.s;
+  return on && s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && s.Cin % 32 == 0 && s.Wo % 32 == 0 &&
+         s.Cout % 8 == 0 && p.K >= 2048;
+}
+
 static int x3_wgrad_splits(const Params& p) {
+  if (x3_wgrad_halo(p)) {
+    const int ntiles = ceil_div(p.M, 128) * (p.s.Cin / 32), segs = p.K / 32;
+    int splits = ntiles >= 512 ? 1 : ceil_div(512, ntiles);
+    if (splits > segs / 8) splits = segs / 8;   // at least 8 segments per workgroup
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    return ceil_div(segs, ceil_div(segs, splits));
+  }
   const bool big = x3_wgrad_big(p);
   const int t = big ? 256 : 128;
   const int ntiles = ceil_div(p.N, t) * ceil_div(p.M, t);
@@ -1292,7 +1309,10 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
   p.ktiles_per_split = ceil_div(ceil_div(p.K, XBK), splits);
   p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   p.wide = 1;   // N = taps * in_c is a multiple of 8, dw / slab 16-byte aligned
-  if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
+  if (x3_wgrad_halo(p)) {
+    const int halo_tiles = ceil_div(p.M, 128) * (p.s.Cin / 32);
+    hipLaunchKernelGGL(igemm_x3_wgrad_halo_kernel, dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
+  } else if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
   else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
   record_mid(st);
@@ -1326,7 +1346,8 @@ int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, 
   int cfg[4] = {2, 2, 2, 2}, nb = 2, sp = 1;
   if (role == WGRAD) {
     p.M = p.s.Cout; p.N = p.s.KH * p.s.KW * p.s.Cin; p.K = p.s.Bn * p.s.Ho * p.s.Wo;
-    if (x3_wgrad_big(p)) { cfg[0] = 4; cfg[1] = 2; cfg[2] = 2; cfg[3] = 4; }
+    if (x3_wgrad_halo(p)) nb = 0;   // igemm_x3_wgrad_halo_kernel
+    else if (x3_wgrad_big(p)) { cfg[0] = 4; cfg[1] = 2; cfg[2] = 2; cfg[3] = 4; }
     sp = p.K > 0 ? x3_wgrad_splits(p) : 1;
   } else {
     if (role == FWD) { p.M = p.s.Bn * p.s.Ho * p.s.Wo; p.N = p.s.Cout; p.K = p.s.KH * p.s.KW * p.s.Cin; }

@@ -651,6 +651,152 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
     store_tile<WGRAD, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+// ---- 3x3 weight gradient with an LDS-resident input halo --------------------------------------------------
+// dW[co][kh][kw][ci] = sum_p dY[p][co] * X[pix(p)+(kh,kw)][ci].  The generic kernel gives every (tap, ci) column
+// group its own workgroup, so X is fetched nine times.  Here a workgroup owns 128 output channels x ONE block of 32
+// input channels x ALL nine taps (nine 32x32 accumulator tiles per wavefront): a K stage is a segment of 32
+// consecutive pixels of one image row, for which dY (32 px x 128 co) and the 3 x 34-pixel X halo (32 ci) are
+// loaded once and the taps read the halo at shifted pixel rows — 7.5 loads per wavefront per 54 MFMAs instead of
+// 8 per 24.  Needs stride 1, no dilation, in_c % 32 == 0 and an output width that is a multiple of 32 (segments
+// never wrap); everything else keeps the generic kernel.
+// Halo image: [102 pixel rows][64 B] per plane, UNswizzled — a transposed read of 4 consecutive pixel rows x 32
+// channels is one contiguous 256-byte run (all 64 banks) wherever it starts.
+__global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Params p, const X3Planes q) {
+  constexpr int SEG = 32, HPW = SEG + 2, HP = 3 * HPW;          // 102 halo pixels
+  constexpr int A_PL = SEG * 256;                                 // dY stage plane: 32 px x 128 co
+  constexpr int B_G = (HP + 15) / 16, B_PL = B_G * 1024;          // halo plane: 7 groups of 16 pixel rows
+  constexpr int STAGE = 2 * A_PL + 2 * B_PL;                      // 30 KiB
+  constexpr int TAPS = 9;
+  __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+
+  const ConvShape& s = p.s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncb = s.Cin / 32;
+  const int tile = blockIdx.x;
+  const int m0 = (tile / ncb) * 128, ci0 = (tile % ncb) * 32;
+
+  int kbeg = 0, kend = p.K;   // K = output pixels, in stages of one 32-pixel segment
+  if (gridDim.y > 1) {
+    kbeg = blockIdx.y * p.ktiles_per_split * SEG;
+    kend = min(p.K, kbeg + p.ktiles_per_split * SEG);
+  }
+  const int nstage = kbeg < kend ? (kend - kbeg) / SEG : 0;
+
+  // segment position (wave-uniform), advanced one segment per stage
+  int sx = kbeg % s.Wo, t0 = kbeg / s.Wo;
+  int sy = t0 % s.Ho, sb = t0 / s.Ho;
+
+  // ---- dY loads: as the generic weight gradient (rows of 128 channels, swizzled), 2 row groups per wavefront
+  int a_col[2], a_rowk[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int r = 4 * (wave * 2 + j) + (lane >> 4);
+    const int ch = (lane & 15) ^ (((r & 3) << 2) | ((r >> 2) & 3));
+    a_rowk[j] = r;
+    a_col[j] = m0 + 8 * ch;
+    a_ok[j] = a_col[j] < p.M;
+  }
+  // ---- halo loads: group T = wave + 4j covers halo pixels 16T .. 16T+15; this lane owns pixel 16T + lane/4
+  int b_ry[2], b_rx[2], b_c[2];
+  bool b_in[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int T = wave + 4 * j;
+    const int hp = 16 * T + (lane >> 2);
+    b_in[j] = T < B_G && hp < HP;
+    b_ry[j] = hp / HPW - s.pad;
+    b_rx[j] = hp % HPW - s.pad;
+    b_c[j] = ci0 + 8 * (lane & 3);
+  }
+  const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
+
+  auto issue = [&](int k0, int buf) {
+    char* St = lds + buf * STAGE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const long aoff = (long)(k0 + a_rowk[j]) * s.Cout + a_col[j];
+      const int dst = (wave * 2 + j) * 1024;
+      dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff) : (const void*)g_zero_page, St + dst);
+      dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff + lo_delta_a) : (const void*)g_zero_page, St + A_PL + dst);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int T = wave + 4 * j;
+      if (T >= B_G) continue;   // wave-uniform
+      const int y = sy * s.stride + b_ry[j], x = sx * s.stride + b_rx[j];
+      const bool ok = b_in[j] && (unsigned)y < (unsigned)s.H && (unsigned)x < (unsigned)s.W;
+      const long boff = ((long)(sb * s.H + y) * s.W + x) * s.Cin + b_c[j];
+      dma16b(ok ? (const void*)(q.B_hi + boff) : (const void*)g_zero_page, St + 2 * A_PL + T * 1024);
+      dma16b(ok ? (const void*)(q.B_hi + boff + lo_delta_b) : (const void*)g_zero_page, St + 2 * A_PL + B_PL + T * 1024);
+    }
+    sx += SEG;   // next segment (the output width is a multiple of 32)
+    if (sx >= s.Wo) { sx = 0; if (++sy == s.Ho) { sy = 0; ++sb; } }
+  };
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposed fragment reads (lane = 32h + 16g + 4ql + pl supplies row 8h + 4r2 + ql, receives column 16g + lane%16)
+  const int h = lane >> 5, g = (lane >> 4) & 1, ql = (lane >> 2) & 3, pl = lane & 3;
+  int a_rd[2];   // dY: this wavefront's 32 output channels start at channel 32*wave of the 128-channel image
+#pragma unroll
+  for (int r2 = 0; r2 < 2; ++r2) {
+    const int row = 8 * h + 4 * r2 + ql;
+    const int swz = ((row & 3) << 2) | ((row >> 2) & 3);
+    const int ch = (wave * 32) / 8 + 2 * g + (pl >> 1);
+    a_rd[r2] = 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
+  }
+  const int b_rd = (8 * h + ql) * 64 + g * 32 + pl * 8;   // halo: row (8h + ql) [+ 4 r2 + 16 step + tap shift], 32 ci
+
+  if (nstage > 0) issue(kbeg, 0);
+  for (int st = 0; st < nstage; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (st + 1 < nstage) issue(kbeg + (st + 1) * SEG, (st + 1) & 1);
+    const char* St = lds + (st & 1) * STAGE;
+    const char* Bh = St + 2 * A_PL;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const char* As = St + ks * 16 * 256;
+      const bf16x8 ah = lds_tr8(As + a_rd[0], As + a_rd[1]);
+      const bf16x8 al = lds_tr8(As + A_PL + a_rd[0], As + A_PL + a_rd[1]);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int kh = t / 3, kw = t % 3;
+        const char* Bs = Bh + ((kh * HPW + kw + 16 * ks) * 64) + b_rd;
+        const bf16x8 bh = lds_tr8(Bs, Bs + 4 * 64);
+        const bf16x8 bl = lds_tr8(Bs + B_PL, Bs + B_PL + 4 * 64);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: tile t of this wavefront is dW[m0 + 32*wave + row][tap t][ci0 + col]
+  const Epilogue& e = p.e;
+  const int col = ci0 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    const int n = t * s.Cin + col;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m >= p.M) continue;
+      float v = acc[t][r];
+      if (gridDim.y > 1) { p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v; continue; }
+      const size_t o = (size_t)m * p.ldc + n;
+      if (e.scale) v *= e.scale[m];
+      if (e.residual) v += e.residual[o];
+      p.C[o] = v;
+    }
+  }
+}
+
 // ---- the splitting pre-passes ---------------------------------------------------------------------
 __device__ __forceinline__ void split1(float v, __bf16& h, __bf16& l) {
   h = (__bf16)v;

@@ -246,6 +246,8 @@ def _x3_variant(s, role):
     L.check(L.lib().jtsm_conv_bf16x3_plan(C.byref(s), role, *[C.byref(x) for x in v]), "conv_bf16x3_plan")
     wm, wn, tm, tn, nbuf, _ = [x.value for x in v]
     if role == 2:
+        if nbuf == 0:
+            return "igemm_x3_wgrad_halo_kernel"
         return "igemm_x3_wgrad_kernel<%d,%d,%d,%d,%d>" % (wm, wn, tm, tn, nbuf)
     if nbuf == 0:   # the LDS-halo 3x3 kernel
         return "igemm_x3_halo_kernel<%s,%d,%d,%d,%d,%d>" % (_ROLE_NAME[role], 16 if wm == 4 else 8, wm, wn, tn,

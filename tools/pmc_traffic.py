@@ -20,6 +20,8 @@ ROLE = {"0": "FWD", "1": "DGRAD", "2": "WGRAD"}
 
 
 def label(name):
+    if "igemm_x3_wgrad_halo_kernel" in name:
+        return "igemm_x3_wgrad_halo_kernel"
     m = re.search(r"igemm_x3_wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)>", name)
     if m:
         return "igemm_x3_wgrad_kernel<%s,%s,%s,%s,%s>" % m.groups()
