@@ -284,9 +284,13 @@ class LaunchSpan(object):
             pass
 
 
-def _timed(variant, flops, call, shape=None):
+def _timed(variant, flops, call, shape=None, extra_elems=0):
+    """`extra_elems`: elements of the fused epilogue's extra fp32 operands (residual, accumulate, ReLU mask) — part
+    of the launch's algorithmic bytes."""
     if LAUNCH_LOG is None:
         return call()
+    if shape is not None and extra_elems:
+        shape = shape[:-1] + (shape[-1] + 4.0 * extra_elems,)
     lib = L.lib()
     span = LaunchSpan()
     st = L.stream()
@@ -302,6 +306,10 @@ def _timed(variant, flops, call, shape=None):
 _ROLE_NAME = ("FWD", "DGRAD", "WGRAD")
 
 
+def _numel(t):
+    return 0 if t is None else t.numel()
+
+
 def _variant(s, role, has_kscale=False):
     """Exact kernel instantiation the library will launch for this call (mirrors its dispatch)."""
     if LAUNCH_LOG is None:
@@ -315,7 +323,11 @@ def _variant(s, role, has_kscale=False):
 
 
 def _desc(s):
-    return (s.batch, s.in_h, s.in_w, s.in_c, s.out_c, s.kernel_h, s.stride)
+    """(shape..., algorithmic bytes): every contraction role reads two of {x, y, w} once and writes the third once,
+    4 B per element either way (fp32, or a bf16 hi + lo pair)."""
+    oh, ow = out_hw(s)
+    elems = s.batch * (s.in_h * s.in_w * s.in_c + oh * ow * s.out_c) + s.out_c * s.in_c * s.kernel_h * s.kernel_w
+    return (s.batch, s.in_h, s.in_w, s.in_c, s.out_c, s.kernel_h, s.stride, 4.0 * elems)
 
 
 def _flops(s):
@@ -375,13 +387,13 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
         yh, yl = _hl(ybuf)
         L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
             xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-            L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_forward_bf16x3")
+            L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward_bf16x3")
         if ybuf is not None:
             planes_put(y, ybuf)
         return y
     L.check(_timed(_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f32(
         L.ptr(x), L.ptr(w), L.ptr(y), pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_forward")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward")
     return y
 
 
@@ -409,13 +421,15 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         dh, dl = _hl(dbuf)
         L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
             gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws),
-            C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_backward_data_bf16x3")
+            C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
+                "conv2d_backward_data_bf16x3")
         if dbuf is not None:
             planes_put(dx, dbuf)
         return dx
     L.check(_timed(_variant(s, 1, kscale is not None), pl.flops, lambda: lib.jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), pl.ref, L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc), "conv2d_backward_data")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
+            "conv2d_backward_data")
     return dx
 
 
