@@ -483,6 +483,76 @@ int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int
                          int bg_label, int32_t* labels, int32_t* matched, float* gt_boxes,
                          float* gt_weights, float* gt_scores, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Inference / post-processing.  None of these entry points synchronises with the host: counts
+ * that depend on the data are written to device memory.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* OICROutputLayers.predict_probs_K + predict_boxes_K (projects/WSL/wsl/modeling/roi_heads/fast_rcnn_oicr.py:712-783):
+ * probs (R, C1) <- mean over `heads` of softmax(logits[h] (R, C1)); boxes (R, Kb*4) <- Box2BoxTransform(weights)
+ * .apply_deltas(mean over heads of deltas[h] (R, Kb*4), proposals (R, 4)) (detectron2/modeling/box_regression.py:78-113).
+ * `logits` / `deltas` are HOST arrays of `heads` (<= 8) device pointers; boxes == NULL skips the box part. */
+int jtsm_oicr_predict_f32(const float* const* logits, const float* const* deltas, int heads, int R, int C1, int Kb,
+                          const float* proposals, const float* weights /* host, 4 */, float scale_clamp, float* probs,
+                          float* boxes, void* stream);
+
+/* batched_nms (detectron2/layers/nms.py:10-31 -> torchvision.ops.boxes.batched_nms / nms, pinned 0.8.1 by
+ * docker/Dockerfile:25): greedy NMS within each class.  boxes (n,4) xyxy, scores (n), idxs (n) int64 in
+ * [0, num_classes) (anything else drops the element), max_per_class >= the largest class population.
+ * coordinate_trick: 1 = torchvision's `boxes + idxs * (boxes.max() + 1)` fp32 offsets (the n < 40000 branch),
+ * 0 = plain per-class NMS (the n >= 40000 branch), 2 = choose by the number of valid elements as nms.py does.
+ * keep (n) int64 <- element indices, survivors first in descending score order (equal scores: lower index first),
+ * *num_keep (device) <- number of survivors; *overflow (device, optional) <- 1 if a class exceeded max_per_class
+ * (the result is then invalid).  IoU test: inter / (area_a + area_b - inter) > iou_threshold, as nms_cuda.cu. */
+size_t jtsm_batched_nms_workspace_bytes(int n, int num_classes, int max_per_class);
+int jtsm_batched_nms_f32(const float* boxes, const float* scores, const int64_t* idxs, int n, int num_classes,
+                         int max_per_class, float iou_threshold, int coordinate_trick, int64_t* keep,
+                         int32_t* num_keep, int32_t* overflow, void* workspace, size_t workspace_bytes, void* stream);
+
+/* fast_rcnn_inference_single_image (projects/WSL/wsl/modeling/roi_heads/fast_rcnn_oicr.py:100-163) in one call:
+ * rows with a non-finite box or score are dropped, boxes (R, Kb*4), Kb in {1, K}, are clipped to (img_h, img_w),
+ * every (row, class < K) with scores (R, K+1) > score_thresh becomes a candidate, batched_nms (above, trick mode 2),
+ * top `topk` (< 0: all).  Outputs have `cap` slots (unused slots: zeros / -1): boxes (cap,4), scores, classes,
+ * rows (the proposal row of each detection) and *out_count (device). */
+size_t jtsm_fast_rcnn_inference_workspace_bytes(int R, int K);
+int jtsm_fast_rcnn_inference_f32(const float* boxes, const float* scores, int R, int K, int Kb, float img_h,
+                                 float img_w, float score_thresh, float nms_thresh, int topk, int cap,
+                                 float* out_boxes, float* out_scores, int64_t* out_classes, int64_t* out_rows,
+                                 int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
+
+/* mask_rcnn_inference (projects/WSL/wsl/modeling/roi_heads/mask_head.py:106-147) on the head average of
+ * roi_heads_jtsm.py:949-961: out (N, M, M) <- sigmoid((sum_h logits[h][n, c_n]) / heads), c_n = classes[n] (0 when
+ * C == 1).  `logits`: HOST array of device pointers to (N, C, M, M). */
+int jtsm_mask_probs_f32(const float* const* logits, int heads, const int64_t* classes, int N, int C, int M,
+                        float* out, void* stream);
+
+/* paste_masks_in_image (detectron2/layers/mask_ops.py:74-145; GPU branch of _do_paste_mask :17-71): out (N, img_h,
+ * img_w) <- grid_sample(masks (N, M, M), bilinear, zeros, align_corners=False) over the whole image, then
+ * `>= threshold` as 0/1 (threshold >= 0) or `* 255` truncated to uint8 (threshold < 0). */
+int jtsm_paste_masks_f32(const float* masks, const float* boxes, int N, int M, int img_h, int img_w, float threshold,
+                         uint8_t* out, void* stream);
+
+/* F.interpolate(x[..., :crop_h, :crop_w], mode="bilinear", align_corners=False) into planar y (N, C, out_h, out_w);
+ * scale_h / scale_w are the source-index scales (1 / scale_factor, or crop / out): SemSegFPNHead's x common_stride
+ * upsampling (detectron2/modeling/meta_arch/semantic_seg.py:172-176) and sem_seg_postprocess
+ * (detectron2/modeling/postprocessing.py:75-100). */
+int jtsm_resize_bilinear_f32(const float* x, int layout, int N, int C, int H, int W, int crop_h, int crop_w,
+                             int out_h, int out_w, float scale_h, float scale_w, float* y, void* stream);
+/* out (HW) int64 <- argmax over c of planar x (C, HW); first maximum wins (sem_seg_r.argmax(dim=0), mcnn.py:352). */
+int jtsm_argmax_channels_f32(const float* x, int C, long HW, int64_t* out, void* stream);
+
+/* combine_semantic_and_instance_outputs (detectron2/modeling/meta_arch/panoptic_fpn.py:133-218).  masks (N, H, W)
+ * uint8, order (N) int32 = instance indices by descending score, scores / classes (N), sem (H, W) int64 in [0, S),
+ * S <= 256.  panoptic (H, W) int32 <- segment ids; seg_table (N + S, 5) int32 rows {id, isthing, category_id,
+ * instance_id or -1, area (stuff: unpainted area; things: newly painted pixels)}, seg_score (N + S),
+ * *num_segments (device). */
+size_t jtsm_panoptic_combine_workspace_bytes(int N, int S);
+int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const float* scores, const int64_t* classes,
+                          int N, int H, int W, const int64_t* sem, int S, double overlap_threshold,
+                          int stuff_area_limit, float instances_confidence_threshold, int32_t* panoptic,
+                          int32_t* seg_table, float* seg_score, int32_t* num_segments, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,10 @@ _DEFAULTS = {
                           "POOLER_TYPE": "ROIAlignV2"},
         "SEM_SEG_HEAD": {"NAME": "SemSegFPNHead", "IN_FEATURES": ["p2", "p3", "p4", "p5"], "IGNORE_VALUE": 255,
                          "NUM_CLASSES": 54, "CONVS_DIM": 128, "COMMON_STRIDE": 4, "NORM": "GN", "LOSS_WEIGHT": 1.0},
+        # detectron2/config/defaults.py:398-406 (combine_semantic_and_instance_outputs thresholds)
+        "PANOPTIC_FPN": {"INSTANCE_LOSS_WEIGHT": 1.0,
+                         "COMBINE": {"ENABLED": True, "OVERLAP_THRESH": 0.5, "STUFF_AREA_LIMIT": 4096,
+                                     "INSTANCES_CONFIDENCE_THRESH": 0.5}},
     },
 }
 

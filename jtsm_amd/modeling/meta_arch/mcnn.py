@@ -1,6 +1,7 @@
-"""GeneralizedMCNNWSL — the training forward of projects/WSL/wsl/modeling/meta_arch/mcnn.py:157-234
+"""GeneralizedMCNNWSL — projects/WSL/wsl/modeling/meta_arch/mcnn.py: the training forward :157-234
 (+ preprocess_image :303-318): backbone -> roi_heads(images, features, proposals, gt, sem_seg,
-superpixels) -> sem_seg_head(features, roi_heads.pgt_sem_seg).
+superpixels) -> sem_seg_head(features, roi_heads.pgt_sem_seg); and inference :236-301 with its
+post-processing (_postprocess :320-336, _postprocess_ps :338-365).
 
 Input contract (mcnn.py:163-171,185-207): a list of dicts with `image` (3,H,W), `instances`
 (gt_classes[, gt_boxes]), `sem_seg` (H,W) long, `proposals` Instances(proposal_boxes, objectness_logits,
@@ -15,6 +16,9 @@ from ..roi_heads import build_roi_heads
 from .build import META_ARCH_REGISTRY
 from .semantic_seg import build_sem_seg_head
 from ...layers.conv import planes_clear
+from ...layers.postprocess import argmax_channels
+from ..postprocessing import detector_postprocess, sem_seg_postprocess
+from .panoptic_fpn import combine_semantic_and_instance_outputs
 
 
 @META_ARCH_REGISTRY.register()
@@ -31,6 +35,12 @@ class GeneralizedMCNNWSL(nn.Module):
         self.register_buffer("pixel_mean", torch.Tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1))
         self.input_format = cfg.INPUT.FORMAT
+        self.ps_on = cfg.WSL.PS_ON
+        combine = cfg.MODEL.PANOPTIC_FPN.COMBINE
+        self.combine_on = combine.ENABLED
+        self.combine_overlap_threshold = combine.OVERLAP_THRESH
+        self.combine_stuff_area_limit = combine.STUFF_AREA_LIMIT
+        self.combine_instances_confidence_threshold = combine.INSTANCES_CONFIDENCE_THRESH
 
     @property
     def device(self):
@@ -43,7 +53,7 @@ class GeneralizedMCNNWSL(nn.Module):
 
     def forward(self, batched_inputs):
         if not self.training:
-            raise NotImplementedError("jtsm_amd implements the training step; inference is a 'next' row (§8f)")
+            return self.inference(batched_inputs)
         planes_clear()   # bf16x3 operand planes are cached per step (layers/conv.py)
         images = self.preprocess_image(batched_inputs)
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
@@ -59,3 +69,56 @@ class GeneralizedMCNNWSL(nn.Module):
         losses.update(sem_seg_losses)
         losses.update(detector_losses)
         return losses
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, only_sem_seg=False):
+        """mcnn.py:236-301.  Returns, per image, {"instances", "sem_seg"[, "panoptic_seg"]} when PS_ON, else
+        {"instances"}; with do_postprocess=False the raw (results, all_scores, all_boxes)."""
+        assert not self.training
+        planes_clear()
+        images = self.preprocess_image(batched_inputs)
+        features = self.backbone(images.tensor)
+        assert "superpixels" in batched_inputs[0] and "proposals" in batched_inputs[0]
+        superpixels = ImageList.from_tensors([x["superpixels"].to(self.device) for x in batched_inputs],
+                                             self.backbone.size_divisibility)
+        proposals = [x["proposals"].to(self.device) for x in batched_inputs]
+        if only_sem_seg:
+            sem_seg_results, _ = self.sem_seg_head(features, None)
+            return sem_seg_results, None, None
+        if detected_instances is None:
+            results, _, all_scores, all_boxes = self.roi_heads(images, features, proposals, None, None, superpixels)
+        else:
+            detected_instances = [x.to(self.device) for x in detected_instances]
+            self.roi_heads.proposals, self.roi_heads.superpixels, self.roi_heads.images = proposals, superpixels, images
+            results, all_scores, all_boxes = self.roi_heads.forward_with_given_boxes(features, detected_instances)
+        sem_seg_results, _ = self.sem_seg_head(features, None)
+        if do_postprocess and self.ps_on:
+            return self._postprocess_ps(sem_seg_results, results, batched_inputs, images.image_sizes)
+        if do_postprocess:
+            return GeneralizedMCNNWSL._postprocess(results, batched_inputs, images.image_sizes)
+        return results, all_scores, all_boxes
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        processed_results = []
+        for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
+            height = input_per_image.get("height", image_size[0])
+            width = input_per_image.get("width", image_size[1])
+            processed_results.append({"instances": detector_postprocess(results_per_image, height, width)})
+        return processed_results
+
+    def _postprocess_ps(self, sem_seg_results, detector_results, batched_inputs, image_sizes):
+        processed_results = []
+        for sem_seg_result, detector_result, input_per_image, image_size in zip(sem_seg_results, detector_results,
+                                                                              batched_inputs, image_sizes):
+            height = input_per_image.get("height", image_size[0])
+            width = input_per_image.get("width", image_size[1])
+            sem_seg_r = sem_seg_postprocess(sem_seg_result, image_size, height, width)
+            detector_r = detector_postprocess(detector_result, height, width)
+            processed_results.append({"sem_seg": sem_seg_r, "instances": detector_r})
+            if self.combine_on:
+                processed_results[-1]["panoptic_seg"] = combine_semantic_and_instance_outputs(
+                    detector_r, argmax_channels(sem_seg_r), self.combine_overlap_threshold,
+                    self.combine_stuff_area_limit, self.combine_instances_confidence_threshold,
+                    num_sem_classes=sem_seg_r.shape[0])
+        return processed_results

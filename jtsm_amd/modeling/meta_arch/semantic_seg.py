@@ -26,6 +26,14 @@ class UpsampleBilinear2x(nn.Module):
         return upsample_bilinear2x(x)
 
 
+def _upsample_logits(x, stride):
+    """F.interpolate(x, scale_factor=stride, mode="bilinear", align_corners=False) (semantic_seg.py:172-176) as one
+    library launch; result planar (N, C, H*stride, W*stride)."""
+    from ...layers.postprocess import resize_bilinear
+    s = int(stride)
+    return resize_bilinear(x, (x.shape[2] * s, x.shape[3] * s), scale_factor=s)
+
+
 def build_sem_seg_head(cfg, input_shape):
     return SEM_SEG_HEADS_REGISTRY.get(cfg.MODEL.SEM_SEG_HEAD.NAME)(cfg, input_shape)
 
@@ -67,7 +75,7 @@ class SemSegFPNHead(nn.Module):
         x = self.layers(features)
         if self.training:
             return None, self.losses(x, targets)
-        return F.interpolate(x, scale_factor=self.common_stride, mode="bilinear", align_corners=False), {}
+        return _upsample_logits(x, self.common_stride), {}
 
     def layers(self, features):
         x = None
@@ -113,4 +121,4 @@ class TwoClassHead(nn.Module):
         if self.training:
             return None, {}
         x = self.layers(features)
-        return F.interpolate(x, scale_factor=self.common_stride, mode="bilinear", align_corners=False), {}
+        return _upsample_logits(x, self.common_stride), {}

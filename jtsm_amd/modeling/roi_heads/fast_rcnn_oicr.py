@@ -1,18 +1,54 @@
 """OICROutputLayers — surface of projects/WSL/wsl/modeling/roi_heads/fast_rcnn_oicr.py:448-586 (layers,
-losses) and :684-783 (predict_probs / predict_boxes).  `cls_score: Linear(in, K+1)`,
-`bbox_pred: Linear(in, 4K)`; losses = instance-weighted CE and L1 (jtsm_amd/csrc/wsl_losses.hip)."""
+losses), :684-783 (predict_probs / predict_boxes and their K-head averages), :616-646 (inference) and the
+module-level fast_rcnn_inference / fast_rcnn_inference_single_image (:48-163).  `cls_score: Linear(in, K+1)`,
+`bbox_pred: Linear(in, 4K)`; losses = instance-weighted CE and L1 (jtsm_amd/csrc/wsl_losses.hip); inference =
+one fused predict launch + one per-image detection call (jtsm_amd/csrc/postprocess.hip)."""
+from typing import List, Tuple
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ...layers.postprocess import fast_rcnn_inference_device, oicr_predict
 from ...layers.wrappers import Linear
 from ...layers.wsl_losses import oicr_loss
+from ...structures import Boxes, Instances
 from ..box_regression import Box2BoxTransform
 
 
+def fast_rcnn_inference(boxes: List[torch.Tensor], scores: List[torch.Tensor], image_shapes: List[Tuple[int, int]],
+                        score_thresh: float, nms_thresh: float, topk_per_image: int):
+    """Per image: (Instances, kept proposal rows, all_scores (1,R,K+1), all_boxes (1,R,4K)) — as the reference."""
+    per_image = [fast_rcnn_inference_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image)
+                 for s, b, shape in zip(scores, boxes, image_shapes)]
+    return tuple([x[i] for x in per_image] for i in range(4))
+
+
+@torch.no_grad()
+def fast_rcnn_inference_single_image(boxes, scores, image_shape: Tuple[int, int], score_thresh: float,
+                                     nms_thresh: float, topk_per_image: int):
+    """Score threshold, per-class NMS and top-k of one image, in one library call
+    (jtsm_fast_rcnn_inference_f32).  `pred_inds` / the second return value are proposal rows of the INPUT (the
+    reference's second value indexes the rows left after dropping non-finite predictions; identical when all
+    predictions are finite)."""
+    all_scores, all_boxes = scores.clone().unsqueeze(0), boxes.clone().unsqueeze(0)
+    out = fast_rcnn_inference_device(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image)
+    n = int(out["count"].item())          # the data-dependent length (the reference synchronises in nonzero())
+    result = Instances(image_shape)
+    result.pred_boxes = Boxes(out["boxes"][:n])
+    result.scores = out["scores"][:n]
+    result.pred_classes = out["classes"][:n]
+    result.pred_inds = out["rows"][:n]
+    return result, out["rows"][:n], all_scores, all_boxes
+
+
 class OICROutputLayers(nn.Module):
-    def __init__(self, input_size, *, num_classes, box2box_transform, refine_k, refine_reg, loss_weight=1.0):
+    def __init__(self, input_size, *, num_classes, box2box_transform, refine_k, refine_reg, loss_weight=1.0,
+                 test_score_thresh=0.0, test_nms_thresh=0.5, test_topk_per_image=100):
         super().__init__()
+        self.test_score_thresh = test_score_thresh
+        self.test_nms_thresh = test_nms_thresh
+        self.test_topk_per_image = test_topk_per_image
         self.num_classes = num_classes
         self.box_dim = len(box2box_transform.weights)
         self.num_bbox_reg_classes = num_classes
@@ -32,7 +68,10 @@ class OICROutputLayers(nn.Module):
         return cls(input_size, num_classes=cfg.MODEL.ROI_HEADS.NUM_CLASSES,
                    box2box_transform=Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS),
                    refine_k=refine_k, refine_reg=cfg.WSL.REFINE_REG,
-                   loss_weight={"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT})
+                   loss_weight={"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT},
+                   test_score_thresh=cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                   test_nms_thresh=cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
+                   test_topk_per_image=cfg.TEST.DETECTIONS_PER_IMAGE)
 
     @property
     def has_reg(self):
@@ -63,3 +102,16 @@ class OICROutputLayers(nn.Module):
 
     def predict_boxes(self, predictions, proposal_boxes, counts):
         return self.box2box_transform.apply_deltas(predictions[1], proposal_boxes).split(counts)
+
+    def inference(self, predictions, proposals: List[Instances]):
+        """`predictions`: (logits, deltas) of this head, or a list of such pairs — then probabilities and deltas
+        are averaged over the heads (predict_probs_K / predict_boxes_K).  Returns what fast_rcnn_inference does."""
+        heads = list(predictions) if isinstance(predictions[0], (tuple, list)) else [predictions]
+        if not len(proposals):
+            return [], [], [], []
+        counts = [len(p) for p in proposals]
+        prop = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        probs, boxes = oicr_predict([h[0] for h in heads], [h[1] for h in heads], prop,
+                                    self.box2box_transform.weights, self.box2box_transform.scale_clamp)
+        return fast_rcnn_inference(boxes.split(counts), probs.split(counts), [x.image_size for x in proposals],
+                                   self.test_score_thresh, self.test_nms_thresh, self.test_topk_per_image)

@@ -9,6 +9,7 @@ from torch import nn
 
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d, ConvTranspose2d, cat
+from ...layers.postprocess import mask_probs
 from ...layers.wsl_losses import mask_bce_loss
 from ...utils.registry import Registry
 
@@ -26,6 +27,20 @@ def mask_rcnn_loss(pred_mask_logits, gt_classes, gt_masks_bool):
     if total_num_masks == 0:
         return pred_mask_logits.sum() * 0
     return mask_bce_loss(pred_mask_logits, gt_classes, gt_masks_bool)     # one HIP launch each way (no CPU path)
+
+
+@torch.no_grad()
+def mask_rcnn_inference(pred_mask_logits, pred_instances):
+    """mask_head.py:106-147: sigmoid of each detection's predicted-class channel, stored per image as
+    `pred_masks` (Ri, 1, M, M).  `pred_mask_logits` may be a list of heads' logits: they are averaged first
+    (roi_heads_jtsm.py:949-961) inside the same launch."""
+    heads = list(pred_mask_logits) if isinstance(pred_mask_logits, (list, tuple)) else [pred_mask_logits]
+    if heads[0].size(0) == 0:
+        probs = heads[0].new_zeros((0, 1) + tuple(heads[0].shape[2:]))
+    else:
+        probs = mask_probs(heads, cat([i.pred_classes for i in pred_instances]))
+    for prob, instances in zip(probs.split([len(i) for i in pred_instances], dim=0), pred_instances):
+        instances.pred_masks = prob
 
 
 @ROI_MASK_HEAD_REGISTRY.register()

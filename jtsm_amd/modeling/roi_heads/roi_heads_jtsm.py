@@ -1,6 +1,7 @@
-"""JTSMROIHeads — the training path of projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:
-forward :502-552, _forward_box :590-737, _forward_mask :754-948, get_pgt_top_k :1167-1338 (top_k = 1,
-thres = 0), get_pgt_sem_seg :2025-2070, get_image_level_gt_stuff :165-194.
+"""JTSMROIHeads — projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py: the training path (forward :502-552,
+_forward_box :590-737, _forward_mask :754-948, get_pgt_top_k :1167-1338 (top_k = 1, thres = 0), get_pgt_sem_seg
+:2025-2070, get_image_level_gt_stuff :165-194) and the inference path (forward :553-561, _forward_box :738-752,
+forward_with_given_boxes :563-588, _forward_mask :949-961).
 
 MI355X mapping of the box branch (the reference issues ~40 small launches + K+1 GEMM pairs here):
   MOIPool on all FPN levels, no host sync           -> 4 launches (+2 tiny bit-set builders each)
@@ -31,7 +32,7 @@ from ..poolers import ROIPooler
 from .box_head import build_box_head
 from .fast_rcnn_oicr import OICROutputLayers
 from .fast_rcnn_tsm import TSMOutputLayers
-from .mask_head import build_mask_head, mask_rcnn_loss
+from .mask_head import build_mask_head, mask_rcnn_inference, mask_rcnn_loss
 from .roi_heads import ROI_HEADS_REGISTRY, ROIHeads, get_image_level_gt, select_foreground_proposals
 
 
@@ -198,8 +199,11 @@ class JTSMROIHeads(ROIHeads):
                 targets: Optional[List[Instances]] = None, gt_sem_seg: Optional[torch.Tensor] = None,
                 superpixels: ImageList = None):
         if not self.training:
-            raise NotImplementedError("jtsm_amd implements the JTSM TRAINING hot path; inference/TTA is a "
-                                      "'next' row (SURVEY §8f row 4)")
+            # roi_heads_jtsm.py:553-561: K-head averaged detections, then the mask heads on the detected boxes
+            self.proposals, self.superpixels, self.images = proposals, superpixels, images
+            pred_instances, all_scores, all_boxes = self._forward_box_inference(features, proposals)
+            pred_instances, _, _ = self.forward_with_given_boxes(features, pred_instances)
+            return pred_instances, {}, all_scores, all_boxes
         assert targets, "'targets' argument is required during training"
         self.proposals, self.superpixels, self.images = proposals, superpixels, images
         # image-level labels, entirely on the device (presence matrices + padded class lists with counts)
@@ -221,10 +225,9 @@ class JTSMROIHeads(ROIHeads):
             mods += [r.cls_score] + ([r.bbox_pred] if r.has_reg else [])
         return linear_fused_split(x, [m.weight for m in mods], [m.bias for m in mods])
 
-    def _forward_box(self, features, proposals):
+    def _box_features(self, features, proposals):
+        """MOIPool -> per-roi rescale -> DAN -> every predictor in one GEMM (roi_heads_jtsm.py:607-633)."""
         feats = [features[f] for f in self.box_in_features]
-        counts = [len(p) for p in proposals]
-        dev = feats[0].device
         box_features, argmax = self.box_pooler(feats, [x.proposal_boxes for x in proposals],
                                                oh_labels_list=[x.oh_labels for x in proposals],
                                                superpixels=self.superpixels)
@@ -236,7 +239,39 @@ class JTSMROIHeads(ROIHeads):
         # reference: (features * mask_scale) * (objectness + 1), two passes; here one combined factor
         box_features = box_features * roi_scale.view(-1, 1, 1, 1)
         box_features = self.box_head(box_features)
-        outs = self._predictor_gemm(box_features)
+        return self._predictor_gemm(box_features), argmax
+
+    @torch.no_grad()
+    def _forward_box_inference(self, features, proposals):
+        """roi_heads_jtsm.py:736-752: every refinement head's prediction, averaged inside
+        OICROutputLayers.inference."""
+        outs, _ = self._box_features(features, proposals)
+        if not all(r.has_reg for r in self.box_refinery):
+            raise NotImplementedError("inference averages the box deltas of every refinement head "
+                                      "(fast_rcnn_oicr.py:729-733): WSL.REFINE_REG must be all True")
+        predictions_K, col = [], 2
+        for _ in self.box_refinery:
+            predictions_K.append((outs[col], outs[col + 1]))
+            col += 2
+        pred_instances, _, all_scores, all_boxes = self.box_refinery[-1].inference(predictions_K, proposals)
+        return pred_instances, all_scores, all_boxes
+
+    @torch.no_grad()
+    def forward_with_given_boxes(self, features, instances):
+        """Mask prediction for given `pred_boxes` / `pred_classes` (roi_heads_jtsm.py:563-588, 949-961): the logits
+        of the refinement mask heads are averaged, then the class channel's sigmoid."""
+        assert not self.training
+        assert instances[0].has("pred_boxes") and instances[0].has("pred_classes")
+        if self.mask_on:
+            feats = [features[f] for f in self.mask_in_features]
+            mask_features = self.mask_pooler(feats, [x.pred_boxes for x in instances])
+            mask_rcnn_inference([head.layers(mask_features)[0] for head in self.mask_refinery], instances)
+        return instances, [], []
+
+    def _forward_box(self, features, proposals):
+        counts = [len(p) for p in proposals]
+        outs, argmax = self._box_features(features, proposals)
+        dev = outs[0].device
         cls_logits, det_logits = outs[0], outs[1]
         offsets = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).to(dev, non_blocking=True)
         labels_oh = (torch.cat([self.gt_classes_img_oh, self.gt_classes_img_oh_stuff], dim=1)

@@ -1,0 +1,381 @@
+"""GPU suite: the inference / post-processing row on the HIP path (jtsm_amd/csrc/postprocess.hip
+through the reference-shaped API) against oracle/inference.py.
+
+Integer / index results (NMS survivors and their order, detections, pasted byte masks away from the threshold, panoptic
+ids, segment tables) are compared bit-exactly; floating-point results (probabilities, decoded boxes, mask
+probabilities, resized logits) to 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from model_util import jtsm_cfg, to_batched_inputs
+from oracle import inference as OI
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+
+from jtsm_amd.layers import postprocess as PP  # noqa: E402
+from jtsm_amd.layers.mask_ops import paste_masks_in_image  # noqa: E402
+from jtsm_amd.layers.nms import batched_nms  # noqa: E402
+from jtsm_amd.modeling import build_model  # noqa: E402
+from jtsm_amd.modeling.meta_arch.panoptic_fpn import combine_semantic_and_instance_outputs  # noqa: E402
+from jtsm_amd.modeling.postprocessing import detector_postprocess, sem_seg_postprocess  # noqa: E402
+from jtsm_amd.modeling.roi_heads.fast_rcnn_oicr import fast_rcnn_inference_single_image  # noqa: E402
+from jtsm_amd.structures import Boxes, Instances  # noqa: E402
+
+
+def _random_boxes(n, size, g):
+    xy = torch.rand(n, 2, generator=g) * size * 0.8
+    wh = torch.rand(n, 2, generator=g) * size * 0.3 + 1.0
+    return torch.cat([xy, xy + wh], dim=1)
+
+
+# ------------------------------------------------------------------------------------------------ NMS
+@pytest.mark.parametrize("n,classes,thr", [(1, 1, 0.5), (63, 3, 0.5), (64, 1, 0.2), (65, 2, 0.8), (2000, 50, 0.5),
+                                           (2000, 50, 0.2), (2000, 50, 0.8), (5000, 7, 0.3), (3000, 1, 0.5)])
+def test_batched_nms_matches_oracle(cuda, n, classes, thr):
+    """Sizes around the 64-box tile edges, the reference test's N=2000 / 50 classes / IoU {0.2, 0.5, 0.8}
+    (tests/layers/test_nms.py:19-31), one big class."""
+    g = torch.Generator().manual_seed(n * 31 + classes)
+    boxes, scores = _random_boxes(n, 200, g), torch.rand(n, generator=g)
+    idxs = torch.randint(0, classes, (n,), generator=g)
+    want = OI.batched_nms(boxes, scores, idxs, thr)
+    got = batched_nms(boxes.cuda(), scores.cuda(), idxs.cuda(), thr)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+
+
+def test_batched_nms_equal_scores_and_duplicates(cuda):
+    g = torch.Generator().manual_seed(5)
+    boxes = _random_boxes(300, 100, g)
+    boxes[100:200] = boxes[:100]                       # exact duplicates: IoU 1
+    scores = torch.rand(300, generator=g)
+    scores[::3] = 0.5                                  # many equal scores: lower index must come first
+    idxs = torch.randint(0, 4, (300,), generator=g)
+    want = OI.batched_nms(boxes, scores, idxs, 0.5)
+    got = batched_nms(boxes.cuda(), scores.cuda(), idxs.cuda(), 0.5)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_batched_nms_plain_per_class_branch(cuda):
+    """The reference switches to a per-class loop (no coordinate offsets) at 40000 boxes: both modes are reachable
+    through the library; at 41000 boxes the wrapper takes the second."""
+    g = torch.Generator().manual_seed(6)
+    n = 41000
+    boxes, scores = _random_boxes(n, 1000, g), torch.rand(n, generator=g)
+    idxs = torch.randint(0, 80, (n,), generator=g)
+    want = OI.batched_nms(boxes, scores, idxs, 0.3)
+    got = batched_nms(boxes.cuda(), scores.cuda(), idxs.cuda(), 0.3)
+    assert torch.equal(got.cpu(), want)
+    # forced modes on a small set: offsets (1) and plain (0) both agree with their restatements
+    b, s, i = boxes[:3000], scores[:3000], idxs[:3000]
+    per = torch.bincount(i)
+    for mode in (0, 1):
+        keep, num, ovf = PP.batched_nms_device(b.cuda(), s.cuda(), i.cuda(), 0.3, per.numel(), int(per.max()), mode)
+        k = keep[: int(num)].cpu()
+        if mode == 1:
+            ref = OI.batched_nms(b, s, i, 0.3)
+        else:
+            res = torch.zeros(3000, dtype=torch.bool)
+            for c in torch.unique(i).tolist():
+                m = torch.nonzero(i == c).view(-1)
+                res[m[OI.nms(b[m], s[m], 0.3)]] = True
+            ref = torch.nonzero(res).view(-1)
+            ref = ref[torch.sort(s[ref], descending=True, stable=True).indices]
+        assert int(ovf) == 0 and torch.equal(k, ref), mode
+
+
+def test_batched_nms_properties_full_size(cuda):
+    """R*K = 4000 x 80 candidates (PRECOMPUTED_PROPOSAL_TOPK_TEST x NUM_CLASSES): too big for the Python oracle —
+    size-independent properties instead: idempotence, survivors are mutually below the threshold within a class,
+    every suppressed box has a better-scored survivor of its class above the threshold."""
+    g = torch.Generator().manual_seed(7)
+    n, K, thr = 320000, 80, 0.3
+    boxes, scores = _random_boxes(n, 1333, g).cuda(), torch.rand(n, generator=g).cuda()
+    idxs = (torch.arange(n) % K).cuda()
+    keep = batched_nms(boxes, scores, idxs, thr)
+    assert torch.equal(scores[keep], torch.sort(scores[keep], descending=True, stable=True).values)
+    again = batched_nms(boxes[keep], scores[keep], idxs[keep], thr)
+    assert torch.equal(again, torch.arange(len(keep), device="cuda"))
+    from jtsm_amd.structures import pairwise_iou
+    kept = torch.zeros(n, dtype=torch.bool, device="cuda")
+    kept[keep] = True
+    for c in (0, 17, 79):
+        m = torch.nonzero(idxs == c).view(-1)
+        km, sm = m[kept[m]], m[~kept[m]]
+        iou = pairwise_iou(Boxes(boxes[km]), Boxes(boxes[km]))
+        iou.fill_diagonal_(0)
+        assert float(iou.max()) <= thr + 1e-6
+        cover = pairwise_iou(Boxes(boxes[sm]), Boxes(boxes[km]))
+        better = scores[km][None, :] >= scores[sm][:, None]
+        assert bool(((cover > thr - 1e-6) & better).any(dim=1).all())
+
+
+def test_batched_nms_empty(cuda):
+    out = batched_nms(torch.zeros(0, 4).cuda(), torch.zeros(0).cuda(), torch.zeros(0, dtype=torch.int64).cuda(), 0.5)
+    assert out.shape == (0,) and out.dtype == torch.int64
+
+
+# ------------------------------------------------------------------------------------------------ detections
+@pytest.mark.parametrize("R,K,agnostic,thresh,topk", [(200, 20, False, 0.05, 100), (200, 20, True, 1e-5, 100),
+                                                      (500, 80, False, 1e-5, 100), (64, 3, False, 0.0, -1)])
+def test_fast_rcnn_inference_matches_oracle(cuda, R, K, agnostic, thresh, topk):
+    g = torch.Generator().manual_seed(R + K)
+    kb = 1 if agnostic else K
+    boxes = _random_boxes(R * kb, 300, g).view(R, kb * 4) - 10.0          # some coordinates outside the image
+    scores = torch.softmax(torch.randn(R, K + 1, generator=g) * 2, dim=1)
+    scores[5, 0] = float("nan")
+    boxes[9, -1] = float("-inf")
+    want = OI.fast_rcnn_inference_single_image(boxes, scores, (240, 280), thresh, 0.3, topk)
+    inst, rows, all_scores, all_boxes = fast_rcnn_inference_single_image(boxes.cuda(), scores.cuda(), (240, 280),
+                                                                         thresh, 0.3, topk)
+    assert len(inst) == len(want["boxes"])
+    assert torch.equal(inst.pred_classes.cpu(), want["classes"]) and torch.equal(rows.cpu(), want["rows"])
+    assert torch.equal(inst.scores.cpu(), want["scores"]) and torch.equal(inst.pred_boxes.tensor.cpu(), want["boxes"])
+    assert all_scores.shape == (1, R, K + 1) and all_boxes.shape == (1, R, kb * 4)
+
+
+def test_fast_rcnn_inference_empty(cuda):
+    inst, rows, _, _ = fast_rcnn_inference_single_image(torch.zeros(0, 8).cuda(), torch.zeros(0, 3).cuda(), (10, 10),
+                                                        0.05, 0.5, 100)
+    assert len(inst) == 0 and rows.numel() == 0
+    # nothing above the threshold
+    inst, _, _, _ = fast_rcnn_inference_single_image(torch.rand(5, 8).cuda(), torch.full((5, 3), 0.01).cuda(), (10, 10),
+                                                     0.05, 0.5, 100)
+    assert len(inst) == 0
+
+
+def test_oicr_predict_matches_oracle(cuda):
+    g = torch.Generator().manual_seed(11)
+    R, K = 300, 80
+    zs = [torch.randn(R, K + 1, generator=g) * 3 for _ in range(4)]
+    ds = [torch.randn(R, 4 * K, generator=g) * 0.5 for _ in range(4)]
+    ds[0][0, 2] = 100.0                                                    # exercises the scale clamp
+    prop = _random_boxes(R, 500, g)
+    want_p, want_b = OI.predict_K(zs, ds, prop)
+    probs, boxes = PP.oicr_predict([z.cuda() for z in zs], [d.cuda() for d in ds], prop.cuda(), OM.BBOX_W,
+                                   OM.SCALE_CLAMP)
+    assert torch.allclose(probs.cpu(), want_p, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(boxes.cpu(), want_b, rtol=1e-5, atol=1e-3)
+    one_p, _ = PP.oicr_predict([zs[0].cuda()], None, None, None, 0.0)
+    assert torch.allclose(one_p.cpu(), torch.softmax(zs[0], 1), rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------------------------------------ masks
+def test_mask_probs_matches_oracle(cuda):
+    g = torch.Generator().manual_seed(12)
+    heads = [torch.randn(37, 80, 28, 28, generator=g) * 4 for _ in range(2)]
+    cls = torch.randint(0, 80, (37,), generator=g)
+    want = OI.mask_rcnn_inference(heads, cls)
+    got = PP.mask_probs([h.cuda() for h in heads], cls.cuda())
+    assert got.shape == (37, 1, 28, 28) and torch.allclose(got.cpu(), want, rtol=1e-5, atol=1e-7)
+    agn = PP.mask_probs([heads[0][:, :1].contiguous().cuda()], cls.cuda())
+    assert torch.allclose(agn.cpu(), heads[0][:, :1].sigmoid(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,M,H,W", [(1, 28, 64, 64), (7, 28, 97, 131), (40, 28, 240, 320), (3, 14, 33, 50)])
+def test_paste_masks_matches_grid_sample(cuda, N, M, H, W):
+    g = torch.Generator().manual_seed(N * 7 + H)
+    masks = torch.rand(N, M, M, generator=g)
+    boxes = _random_boxes(N, min(H, W), g)
+    boxes[0] = torch.tensor([-5.0, -3.0, W + 4.0, H + 2.0])               # larger than the image
+    soft = OI.paste_masks_soft(masks, boxes, H, W)
+    got = paste_masks_in_image(masks.cuda(), Boxes(boxes.cuda()), (H, W), threshold=0.5)
+    assert got.dtype == torch.bool and got.shape == (N, H, W)
+    sure = (soft - 0.5).abs() > 1e-5                                      # away from the threshold: exact
+    assert torch.equal(got.cpu()[sure], (soft >= 0.5)[sure])
+    vis = paste_masks_in_image(masks.cuda(), boxes.cuda(), (H, W), threshold=-1)
+    assert vis.dtype == torch.uint8
+    assert (vis.cpu().int() - (soft * 255).to(torch.uint8).int()).abs().max() <= 1
+
+
+def test_paste_masks_empty_and_degenerate(cuda):
+    out = paste_masks_in_image(torch.zeros(0, 28, 28).cuda(), torch.zeros(0, 4).cuda(), (20, 30))
+    assert out.shape == (0, 20, 30)
+    masks = torch.ones(1, 28, 28)
+    box = torch.tensor([[5.0, 5.0, 5.0, 9.0]])                            # zero width: NaN grid -> all zeros
+    want = OI.paste_masks_in_image(masks, box, (16, 16))
+    got = paste_masks_in_image(masks.cuda(), box.cuda(), (16, 16))
+    assert torch.equal(got.cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------ semantic maps
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+def test_resize_bilinear_matches_interpolate(cuda, layout):
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 54, 24, 40, generator=g)
+    xin = x.cuda().contiguous(memory_format=torch.channels_last) if layout == "nhwc" else x.cuda()
+    up = PP.resize_bilinear(xin, (96, 160), scale_factor=4)
+    want = torch.nn.functional.interpolate(x, scale_factor=4, mode="bilinear", align_corners=False)
+    assert torch.allclose(up.cpu(), want, rtol=1e-5, atol=1e-6)
+    # sem_seg_postprocess: crop the padding, resize to an arbitrary output size
+    # (non-integer scale: the source coordinates are rounded differently by torch's CPU and GPU kernels, the
+    # product follows upsample_bilinear2d's GPU arithmetic -> absolute tolerance 2e-5 on O(1) values)
+    r = sem_seg_postprocess(x[0].cuda(), (20, 33), 75, 111)
+    assert torch.allclose(r.cpu(), OI.sem_seg_postprocess(x[0], (20, 33), 75, 111), rtol=1e-5, atol=2e-5)
+    same = sem_seg_postprocess(x[0].cuda(), (24, 40), 24, 40)
+    assert torch.equal(same.cpu(), x[0])
+
+
+def test_argmax_channels(cuda):
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(54, 61, 67, generator=g)
+    x[3, 5, 5] = x[9, 5, 5] = 100.0                                       # tie: the first maximum wins
+    got = PP.argmax_channels(x.cuda())
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), x.argmax(dim=0))
+
+
+# ------------------------------------------------------------------------------------------------ panoptic merge
+def _instances(masks, scores, classes, size):
+    return Instances(size, pred_masks=masks, scores=scores, pred_classes=classes)
+
+
+@pytest.mark.parametrize("H,W,N", [(8, 8, 3), (61, 67, 12), (256, 320, 40)])
+def test_panoptic_combine_matches_oracle(cuda, H, W, N):
+    g = torch.Generator().manual_seed(H + N)
+    sem = torch.randint(0, 6, (H // 4 + 1, W // 4 + 1), generator=g).repeat_interleave(4, 0).repeat_interleave(4, 1)
+    sem = sem[:H, :W].contiguous()
+    boxes = _random_boxes(N, min(H, W), g)
+    masks = torch.zeros(N, H, W, dtype=torch.bool)
+    for i, b in enumerate(boxes.long().tolist()):
+        masks[i, b[1]:b[3] + 1, b[0]:b[2] + 1] = True
+    masks[N - 1] = False                                                  # an empty mask is skipped
+    scores = torch.rand(N, generator=g)
+    scores[1] = scores[0]                                                 # equal scores: lower index first
+    classes = torch.randint(0, 80, (N,), generator=g)
+    for conf, limit in ((0.5, 16), (0.0, 0), (0.3, 100000)):
+        want_pan, want_info = OI.combine_semantic_and_instance_outputs(masks, scores, classes, sem, 0.5, limit, conf)
+        pan, info = combine_semantic_and_instance_outputs(
+            _instances(masks.cuda(), scores.cuda(), classes.cuda(), (H, W)), sem.cuda(), 0.5, limit, conf,
+            num_sem_classes=6)
+        assert pan.dtype == torch.int32 and torch.equal(pan.cpu(), want_pan)
+        assert len(info) == len(want_info)
+        for a, b in zip(info, want_info):
+            assert a["id"] == b["id"] and a["isthing"] == b["isthing"] and a["category_id"] == b["category_id"]
+            if b["isthing"]:
+                assert a["instance_id"] == b["instance_id"] and abs(a["score"] - b["score"]) < 1e-7
+            else:
+                assert a["area"] == b["area"]
+
+
+def test_panoptic_combine_no_instances(cuda):
+    sem = torch.ones(32, 32, dtype=torch.int64)
+    pan, info = combine_semantic_and_instance_outputs(
+        _instances(torch.zeros(0, 32, 32, dtype=torch.bool).cuda(), torch.zeros(0).cuda(),
+                   torch.zeros(0, dtype=torch.int64).cuda(), (32, 32)), sem.cuda(), 0.5, 10, 0.5, num_sem_classes=2)
+    assert (pan == 1).all() and info == [{"id": 1, "isthing": False, "category_id": 1, "area": 1024}]
+
+
+def test_detector_postprocess_matches_oracle(cuda):
+    g = torch.Generator().manual_seed(15)
+    N = 9
+    boxes = _random_boxes(N, 100, g)
+    boxes[4] = torch.tensor([50.0, 20.0, 50.0, 60.0])                     # empty after scaling: dropped
+    det = dict(boxes=boxes, scores=torch.rand(N, generator=g), classes=torch.randint(0, 80, (N,), generator=g),
+               masks=torch.rand(N, 1, 28, 28, generator=g))
+    want = OI.detector_postprocess(det, (120, 130), 200, 180)
+    inst = Instances((120, 130), pred_boxes=Boxes(boxes.clone().cuda()), scores=det["scores"].cuda(),
+                     pred_classes=det["classes"].cuda(), pred_masks=det["masks"].cuda())
+    got = detector_postprocess(inst, 200, 180)
+    assert got.image_size == (200, 180) and len(got) == len(want["boxes"]) == N - 1
+    assert torch.allclose(got.pred_boxes.tensor.cpu(), want["boxes"], rtol=1e-6, atol=1e-5)
+    sure = (want["soft_masks"] - 0.5).abs() > 1e-4
+    assert torch.equal(got.pred_masks.cpu()[sure], want["masks"][sure])
+
+
+# ------------------------------------------------------------------------------------------------ the whole pass
+@pytest.fixture(scope="module")
+def passes(cuda):
+    torch.manual_seed(0)
+    params = OM.init_params(seed=3, random_bn=True, input_gain=1.0 / 64)
+    with torch.no_grad():   # random-init regression heads predict ~zero deltas: make the decoded boxes move
+        for k in range(4):
+            params["roi_heads.box_refinery_%d.bbox_pred.weight" % k] *= 3.0
+    batch = OM.synthetic_batch(1234, B=2, size=256, R=160, sp_block=8)
+    cfg = jtsm_cfg("cuda")
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 1e-5      # projects/WSL/configs/PascalVOC-Detection/oicr_WSR_18_DC5_1x.yaml:24-25
+    cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.3
+    cfg.MODEL.PANOPTIC_FPN.COMBINE.INSTANCES_CONFIDENCE_THRESH = 0.02
+    cfg.MODEL.PANOPTIC_FPN.COMBINE.STUFF_AREA_LIMIT = 64
+    model = build_model(cfg)
+    model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    model.eval()
+    inputs = to_batched_inputs(batch)
+    raw = model.inference(inputs, do_postprocess=False)
+    full = model(inputs)
+    ref = OI.forward_inference(params, batch, score_thresh=1e-5, nms_thresh=0.3, return_raw=True)
+    return params, batch, model, raw, full, ref
+
+
+def test_inference_scores_and_boxes(passes):
+    _, batch, _, raw, _, ref = passes
+    results, all_scores, all_boxes = raw
+    probs = torch.cat([s[0] for s in all_scores]).cpu()
+    boxes = torch.cat([b[0] for b in all_boxes]).cpu()
+    assert torch.allclose(probs, ref["probs"], rtol=2e-3, atol=1e-6)
+    assert torch.allclose(boxes, ref["boxes"], rtol=1e-3, atol=2e-2)      # pixels, on 256-px images
+
+
+def test_inference_detections_exact_given_scores(passes):
+    """The discrete part, on identical inputs: the oracle's detection routine fed with the PRODUCT's averaged
+    probabilities / boxes must select exactly the product's detections."""
+    _, batch, _, raw, _, _ = passes
+    results, all_scores, all_boxes = raw
+    for inst, s, b, img in zip(results, all_scores, all_boxes, batch["images"]):
+        want = OI.fast_rcnn_inference_single_image(b[0].cpu(), s[0].cpu(), tuple(img.shape[-2:]), 1e-5, 0.3, 100)
+        assert len(inst) == len(want["boxes"]) == 100
+        assert torch.equal(inst.pred_classes.cpu(), want["classes"]) and torch.equal(inst.pred_inds.cpu(), want["rows"])
+        assert torch.equal(inst.scores.cpu(), want["scores"])
+        assert torch.equal(inst.pred_boxes.tensor.cpu(), want["boxes"])
+        assert inst.pred_masks.shape == (100, 1, 28, 28)
+
+
+def test_inference_mask_probabilities(passes):
+    """Mask head on the product's detections vs the oracle's mask branch on the same boxes."""
+    params, batch, _, raw, _, _ = passes
+    results = raw[0]
+    x = OM.preprocess(params, batch["images"])
+    feats = OM.resnet_fpn(params, x, 50)
+    levels = [feats["p%d" % l] for l in (2, 3, 4, 5)]
+    rois = torch.cat([torch.cat([torch.full((len(r), 1), float(i)), r.pred_boxes.tensor.cpu()], 1)
+                      for i, r in enumerate(results)])
+    with torch.no_grad():
+        logits = OM.mask_head_layers(params, "roi_heads.mask_refinery_0.", OM.roi_align_levels(levels, rois, x.shape[2], 14))
+    want = OI.mask_rcnn_inference([logits], torch.cat([r.pred_classes.cpu() for r in results]))
+    got = torch.cat([r.pred_masks for r in results]).cpu()
+    assert (got - want).abs().max() < 2e-4
+
+
+def test_inference_postprocessed_outputs(passes):
+    """The public output contract (mcnn.py:338-365) and its consistency with the oracle's post-processing applied
+    to the product's raw results."""
+    _, batch, model, raw, full, _ = passes
+    assert len(full) == 2
+    for out, img in zip(full, batch["images"]):
+        H, W = img.shape[-2:]
+        assert set(out) == {"instances", "sem_seg", "panoptic_seg"}
+        inst, sem, (pan, info) = out["instances"], out["sem_seg"], out["panoptic_seg"]
+        assert sem.shape == (54, H, W) and pan.shape == (H, W) and pan.dtype == torch.int32
+        assert inst.pred_masks.shape[1:] == (H, W) and inst.pred_masks.dtype == torch.bool
+        want_pan, want_info = OI.combine_semantic_and_instance_outputs(
+            inst.pred_masks.cpu(), inst.scores.cpu(), inst.pred_classes.cpu(), sem.cpu().argmax(dim=0), 0.5, 64, 0.02)
+        assert torch.equal(pan.cpu(), want_pan)
+        assert [(s["id"], s["isthing"], s["category_id"]) for s in info] == \
+               [(s["id"], s["isthing"], s["category_id"]) for s in want_info]
+        assert any(s["isthing"] for s in info)
+
+
+def test_inference_semantic_logits(passes):
+    _, _, _, _, full, ref = passes
+    got = torch.stack([o["sem_seg"] for o in full]).cpu()
+    scale = ref["sem_logits"].abs().max()
+    assert (got - ref["sem_logits"]).abs().max() < 1e-3 * scale
+
+
+def test_inference_with_given_boxes(passes):
+    """forward_with_given_boxes path (mcnn.py:277-282): masks for caller-supplied detections."""
+    _, batch, model, raw, _, _ = passes
+    given = [Instances(r.image_size, pred_boxes=Boxes(r.pred_boxes.tensor[:5].clone()), pred_classes=r.pred_classes[:5])
+             for r in raw[0]]
+    results, _, _ = model.inference(to_batched_inputs(batch), detected_instances=given, do_postprocess=False)
+    for r, full in zip(results, raw[0]):
+        assert torch.allclose(r.pred_masks, full.pred_masks[:5], rtol=1e-4, atol=1e-5)
