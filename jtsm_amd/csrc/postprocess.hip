@@ -307,12 +307,12 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const u64* __restrict__ ma
     if (valid) kept[p] = (uint8_t)((keptbits >> lane) & 1);
     total += __popcll(keptbits);
     for (int w = 1 + lane; w < W; w += 64) {
-      u64 acc = 0, kb = keptbits;
-      while (kb) {
-        const int j = __ffsll((long long)kb) - 1;
-        kb &= kb - 1;
-        acc |= mask[(size_t)(b * 64 + j) * W + w];
-      }
+      // every row of the block is read (independent loads, all in flight together) and masked by its kept bit:
+      // cheaper than a dependent load per kept row
+      const u64* col = mask + (size_t)b * 64 * W + w;
+      u64 acc = 0;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) acc |= col[(size_t)j * W] & (0ull - ((keptbits >> j) & 1ull));
       removed[b - b0 + w] |= acc;
     }
     __syncthreads();
@@ -551,41 +551,80 @@ __global__ __launch_bounds__(256) void argmax_channels_kernel(const float* __res
 // combine_semantic_and_instance_outputs (detectron2/modeling/meta_arch/panoptic_fpn.py:133-218).  Instances are
 // visited in descending-score order; each visit is two launches (count, then decide + paint) whose decisions read
 // only counters written by earlier launches of the stream.
+__device__ __forceinline__ int nonzero_bytes(unsigned v) {
+  return __popc(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu | v) & 0x80808080u);
+}
+
+// Pre-pass over all masks: area and the range of rows that hold any set pixel (one wavefront per row).
+__global__ __launch_bounds__(256) void pan_extent_kernel(const uint8_t* __restrict__ masks, int N, int H, int W,
+                                                         int* __restrict__ extent /* (N, 3): area, row_min, row_max */) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= (long)N * H) return;
+  const int inst = (int)(row / H), y = (int)(row % H);
+  const uint8_t* m = masks + (size_t)row * W;
+  int cnt = 0;
+  if ((W & 15) == 0 && ((size_t)masks & 15) == 0) {   // 16 pixels per lane and load
+    for (int x = lane * 16; x < W; x += 64 * 16) {
+      const uint4 v = *reinterpret_cast<const uint4*>(m + x);
+      cnt += nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
+    }
+  } else {
+    for (int x = lane; x < W; x += 64) cnt += m[x] != 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+  if (lane == 0 && cnt) {
+    atomicAdd(&extent[3 * inst], cnt);
+    atomicMin(&extent[3 * inst + 1], y);
+    atomicMax(&extent[3 * inst + 2], y);
+  }
+}
+
+__global__ void pan_extent_init_kernel(int* __restrict__ extent, int N, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) { extent[3 * i] = 0; extent[3 * i + 1] = H; extent[3 * i + 2] = -1; }
+}
+
+constexpr int kPanBlocks = 128;   // 512 rows per sweep; a visit only walks its mask's rows
+
 __global__ __launch_bounds__(256) void pan_count_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ order,
-                                                        const float* __restrict__ scores, int visit, long HW,
+                                                        const float* __restrict__ scores, int visit, int H, int W,
                                                         float conf, const int* __restrict__ panoptic,
-                                                        int* __restrict__ counters) {
+                                                        const int* __restrict__ extent, int* __restrict__ counters) {
   const int inst = order[visit];
   if (scores[inst] < conf) return;   // sorted descending: this and every later visit is past the `break`
-  const uint8_t* m = masks + (size_t)inst * HW;
-  int area = 0, inter = 0;
-  const bool vec = (HW & 3) == 0;   // every mask then starts 4-byte aligned
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += (long)gridDim.x * blockDim.x * 4) {
+  const int y0 = extent[3 * inst + 1], y1 = extent[3 * inst + 2];
+  const int lane = threadIdx.x & 63;
+  const bool vec = (W & 3) == 0 && ((size_t)masks & 3) == 0 && ((size_t)panoptic & 15) == 0;
+  int inter = 0;
+  for (int y = y0 + blockIdx.x * 4 + (threadIdx.x >> 6); y <= y1; y += gridDim.x * 4) {
+    const uint8_t* m = masks + ((size_t)inst * H + y) * W;
+    const int* p = panoptic + (size_t)y * W;
     if (vec) {
-      const uchar4 v = *reinterpret_cast<const uchar4*>(m + i);
-      const int4 p = *reinterpret_cast<const int4*>(panoptic + i);
-      area += (v.x != 0) + (v.y != 0) + (v.z != 0) + (v.w != 0);
-      inter += (v.x != 0 && p.x > 0) + (v.y != 0 && p.y > 0) + (v.z != 0 && p.z > 0) + (v.w != 0 && p.w > 0);
+      for (int x = lane * 4; x < W; x += 256) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(m + x);
+        if (!(v.x | v.y | v.z | v.w)) continue;
+        const int4 q = *reinterpret_cast<const int4*>(p + x);
+        inter += (v.x && q.x > 0) + (v.y && q.y > 0) + (v.z && q.z > 0) + (v.w && q.w > 0);
+      }
     } else {
-      for (long j = i; j < HW && j < i + 4; ++j) { area += m[j] != 0; inter += (m[j] != 0 && panoptic[j] > 0); }
+      for (int x = lane; x < W; x += 64) inter += (m[x] != 0 && p[x] > 0);
     }
   }
-  for (int o = 32; o > 0; o >>= 1) { area += __shfl_xor(area, o); inter += __shfl_xor(inter, o); }
-  if ((threadIdx.x & 63) == 0 && area) {
-    atomicAdd(&counters[2 * visit], area);
-    if (inter) atomicAdd(&counters[2 * visit + 1], inter);
-  }
+  for (int o = 32; o > 0; o >>= 1) inter += __shfl_xor(inter, o);
+  if (lane == 0 && inter) atomicAdd(&counters[visit], inter);
 }
 
 __global__ __launch_bounds__(256) void pan_paint_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ order,
                                                         const float* __restrict__ scores,
-                                                        const int64_t* __restrict__ classes, int visit, long HW,
-                                                        float conf, double overlap, const int* __restrict__ counters,
-                                                        int* __restrict__ next_id, int* __restrict__ panoptic,
+                                                        const int64_t* __restrict__ classes, int visit, int H, int W,
+                                                        float conf, double overlap, const int* __restrict__ extent,
+                                                        const int* __restrict__ counters, int* __restrict__ next_id,
+                                                        int* __restrict__ panoptic,
                                                         int* __restrict__ seg_table /* (rows, 5) */,
                                                         float* __restrict__ seg_score) {
   const int inst = order[visit];
-  const int area = counters[2 * visit], inter = counters[2 * visit + 1];
+  const int area = extent[3 * inst], inter = counters[visit];
   const bool accept = !(scores[inst] < conf) && area > 0 && !((double)inter * 1.0 / (double)area > overlap);
   const int id = next_id[visit] + 1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -597,20 +636,26 @@ __global__ __launch_bounds__(256) void pan_paint_kernel(const uint8_t* __restric
     }
   }
   if (!accept) return;
-  const uint8_t* m = masks + (size_t)inst * HW;
-  const bool vec = (HW & 3) == 0;
-  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < HW; i += (long)gridDim.x * blockDim.x * 4) {
+  const int y0 = extent[3 * inst + 1], y1 = extent[3 * inst + 2];
+  const int lane = threadIdx.x & 63;
+  const bool vec = (W & 3) == 0 && ((size_t)masks & 3) == 0 && ((size_t)panoptic & 15) == 0;
+  for (int y = y0 + blockIdx.x * 4 + (threadIdx.x >> 6); y <= y1; y += gridDim.x * 4) {
+    const uint8_t* m = masks + ((size_t)inst * H + y) * W;
+    int* p = panoptic + (size_t)y * W;
     if (vec) {
-      const uchar4 v = *reinterpret_cast<const uchar4*>(m + i);
-      if (!(v.x | v.y | v.z | v.w)) continue;
-      int4 p = *reinterpret_cast<int4*>(panoptic + i);
-      if (v.x && p.x == 0) p.x = id;
-      if (v.y && p.y == 0) p.y = id;
-      if (v.z && p.z == 0) p.z = id;
-      if (v.w && p.w == 0) p.w = id;
-      *reinterpret_cast<int4*>(panoptic + i) = p;
+      for (int x = lane * 4; x < W; x += 256) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(m + x);
+        if (!(v.x | v.y | v.z | v.w)) continue;
+        int4 q = *reinterpret_cast<int4*>(p + x);
+        if (v.x && q.x == 0) q.x = id;
+        if (v.y && q.y == 0) q.y = id;
+        if (v.z && q.z == 0) q.z = id;
+        if (v.w && q.w == 0) q.w = id;
+        *reinterpret_cast<int4*>(p + x) = q;
+      }
     } else {
-      for (long j = i; j < HW && j < i + 4; ++j) if (m[j] && panoptic[j] == 0) panoptic[j] = id;
+      for (int x = lane; x < W; x += 64)
+        if (m[x] && p[x] == 0) p[x] = id;
     }
   }
 }
@@ -834,8 +879,9 @@ int jtsm_argmax_channels_f32(const float* x, int C, long HW, int64_t* out, void*
 }
 
 size_t jtsm_panoptic_combine_workspace_bytes(int N, int S) {
-  // counters (2N) + next_id (N + 1) + order is the caller's + hist (2S) + label_id (S)
-  return align256((size_t)(2 * (N > 0 ? N : 0) + (N > 0 ? N : 0) + 1 + 3 * (S > 0 ? S : 0) + 8) * sizeof(int));
+  // counters (N) + next_id (N + 1) + extent (3N) + hist (2S) + label_id (S)
+  const size_t n = N > 0 ? N : 0, s = S > 0 ? S : 0;
+  return align256((5 * n + 1 + 3 * s + 8) * sizeof(int));
 }
 
 int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const float* scores, const int64_t* classes,
@@ -846,25 +892,29 @@ int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const floa
   JTSM_REQUIRE(N >= 0 && H >= 1 && W >= 1 && S >= 1 && S <= kMaxSem, "panoptic_combine: bad sizes (S <= %d)", kMaxSem);
   JTSM_REQUIRE(sem && panoptic && seg_table && seg_score && num_segments, "panoptic_combine: null pointer");
   JTSM_REQUIRE(N == 0 || (masks && order && scores && classes), "panoptic_combine: null instance arrays");
-  JTSM_REQUIRE(((size_t)panoptic & 15) == 0 && ((size_t)masks & 3) == 0,
-               "panoptic_combine: panoptic must be 16-byte, masks 4-byte aligned");
+  JTSM_REQUIRE((long)N * H < 2147483647L * 4, "panoptic_combine: too many mask rows");
   const size_t need = jtsm_panoptic_combine_workspace_bytes(N, S);
   JTSM_REQUIRE(workspace && workspace_bytes >= need, "panoptic_combine: workspace of %zu bytes needed", need);
   hipStream_t st = as_stream(stream);
   const long HW = (long)H * W;
   int* counters = reinterpret_cast<int*>(workspace);
-  int* next_id = counters + 2 * N;
-  int* hist = next_id + N + 1;
+  int* next_id = counters + N;
+  int* extent = next_id + N + 1;
+  int* hist = extent + 3 * N;
   int* label_id = hist + 2 * S;
   JTSM_CHECK_HIP(hipMemsetAsync(workspace, 0, need, st));
   JTSM_CHECK_HIP(hipMemsetAsync(panoptic, 0, (size_t)HW * sizeof(int32_t), st));
-  const int blocks = (int)std::min<long>(ceil_div(ceil_div(HW, 4), 256), 2048);
+  const int blocks = (int)std::min<long>(ceil_div(HW, 256), 2048);
+  if (N > 0) {
+    hipLaunchKernelGGL(pan_extent_init_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, extent, N, H);
+    hipLaunchKernelGGL(pan_extent_kernel, dim3(ceil_div((long)N * H, 4)), dim3(256), 0, st, masks, N, H, W, extent);
+  }
   for (int v = 0; v < N; ++v) {
-    hipLaunchKernelGGL(pan_count_kernel, dim3(blocks), dim3(256), 0, st, masks, order, scores, v, HW,
-                       instances_confidence_threshold, panoptic, counters);
-    hipLaunchKernelGGL(pan_paint_kernel, dim3(blocks), dim3(256), 0, st, masks, order, scores, classes, v, HW,
-                       instances_confidence_threshold, overlap_threshold, counters, next_id, panoptic, seg_table,
-                       seg_score);
+    hipLaunchKernelGGL(pan_count_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, v, H, W,
+                       instances_confidence_threshold, panoptic, extent, counters);
+    hipLaunchKernelGGL(pan_paint_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, classes, v, H, W,
+                       instances_confidence_threshold, overlap_threshold, extent, counters, next_id, panoptic,
+                       seg_table, seg_score);
   }
   JTSM_CHECK_LAUNCH("panoptic instances");
   hipLaunchKernelGGL(pan_stuff_hist_kernel, dim3(blocks), dim3(256), 0, st, sem, panoptic, HW, S, hist);

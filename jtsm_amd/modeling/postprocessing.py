@@ -30,4 +30,6 @@ def detector_postprocess(results: Instances, output_height: int, output_width: i
 @torch.no_grad()
 def sem_seg_postprocess(result, img_size, output_height, output_width):
     """(C, H, W) logits: crop the padding away, bilinear resize to the output resolution -> (C, oh, ow)."""
+    if tuple(result.shape[-2:]) == tuple(img_size) == (output_height, output_width):
+        return result          # scale 1, no padding: the interpolation is the identity (weights 1 and 0)
     return resize_bilinear(result.unsqueeze(0), (output_height, output_width), crop_hw=img_size)[0]
