@@ -553,6 +553,15 @@ int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const floa
                           int32_t* seg_table, float* seg_score, int32_t* num_segments, void* workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Model input boundary: GeneralizedMCNNWSL.preprocess_image
+ * (projects/WSL/wsl/modeling/meta_arch/mcnn.py:303-318) + ImageList.from_tensors
+ * (detectron2/structures/image_list.py:71-125) in one launch: images[b] is the mapper's uint8 (C, h_b, w_b) planar
+ * image on the device (`images`, `heights`, `widths`, `mean`, `stdv` are HOST arrays); out (B, Hp, Wp, C) float32
+ * channels-last <- (x - mean[c]) / stdv[c] inside the image, pad_value in the bottom / right padding. */
+int jtsm_preprocess_images_u8(const uint8_t* const* images, const int32_t* heights, const int32_t* widths, int B,
+                              int C, const float* mean, const float* stdv, float pad_value, int Hp, int Wp,
+                              float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

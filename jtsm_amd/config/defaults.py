@@ -8,9 +8,13 @@ _DEFAULTS = {
     "OUTPUT_DIR": "./output",
     "VIS_PERIOD": 0,
     "SEED": -1,
-    "INPUT": {"FORMAT": "BGR", "MASK_FORMAT": "polygon"},
-    "DATASETS": {},
-    "TEST": {"DETECTIONS_PER_IMAGE": 100},
+    # detectron2/config/defaults.py:40-60 (INPUT), :84-96 (DATASETS), :607-620 (TEST.AUG)
+    "INPUT": {"FORMAT": "BGR", "MASK_FORMAT": "polygon", "MIN_SIZE_TRAIN": (800,), "MIN_SIZE_TRAIN_SAMPLING": "choice",
+              "MAX_SIZE_TRAIN": 1333, "MIN_SIZE_TEST": 800, "MAX_SIZE_TEST": 1333},
+    "DATASETS": {"PRECOMPUTED_PROPOSAL_TOPK_TRAIN": 2000, "PRECOMPUTED_PROPOSAL_TOPK_TEST": 1000},
+    "TEST": {"DETECTIONS_PER_IMAGE": 100,
+             "AUG": {"ENABLED": False, "MIN_SIZES": (400, 500, 600, 700, 800, 900, 1000, 1100, 1200), "MAX_SIZE": 4000,
+                     "FLIP": True}},
     "SOLVER": {"MAX_ITER": 40000, "BASE_LR": 0.001, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.0001,
                "WEIGHT_DECAY_NORM": 0.0, "BIAS_LR_FACTOR": 1.0, "WEIGHT_DECAY_BIAS": 0.0001, "IMS_PER_BATCH": 16},
     "MODEL": {

@@ -187,3 +187,26 @@ def panoptic_combine(masks, scores, classes, sem, num_sem_classes, overlap_thres
                                       L.ptr(nseg), L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "panoptic_combine")
     n = int(nseg.item())
     return pan, table[:n], tscore[:n]
+
+
+@torch.no_grad()
+def preprocess_images_u8(images, mean, std, size_divisibility=0, pad_value=0.0):
+    """uint8 (C, h, w) device images -> ((B, C, Hp, Wp) float32 in channels-last storage, image_sizes):
+    (x - mean) / std, zero padding, one launch (mcnn.py:303-318 + ImageList.from_tensors)."""
+    L.require_gpu(*images)
+    images = [im.contiguous() for im in images]
+    Cc = images[0].shape[0]
+    sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
+    hp, wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
+    if size_divisibility > 1:
+        hp = (hp + size_divisibility - 1) // size_divisibility * size_divisibility
+        wp = (wp + size_divisibility - 1) // size_divisibility * size_divisibility
+    B = len(images)
+    out = torch.empty((B, Cc, hp, wp), dtype=torch.float32, device=images[0].device, memory_format=torch.channels_last)
+    hs = (C.c_int32 * B)(*[s[0] for s in sizes])
+    ws = (C.c_int32 * B)(*[s[1] for s in sizes])
+    m = (C.c_float * Cc)(*[float(v) for v in mean])
+    sd = (C.c_float * Cc)(*[float(v) for v in std])
+    L.check(L.lib().jtsm_preprocess_images_u8(_ptr_array(images), hs, ws, B, Cc, m, sd, L.f32(pad_value), hp, wp,
+                                              L.ptr(out), L.stream()), "preprocess_images")
+    return out, sizes

@@ -16,7 +16,7 @@ from ..roi_heads import build_roi_heads
 from .build import META_ARCH_REGISTRY
 from .semantic_seg import build_sem_seg_head
 from ...layers.conv import planes_clear
-from ...layers.postprocess import argmax_channels
+from ...layers.postprocess import argmax_channels, preprocess_images_u8
 from ..postprocessing import detector_postprocess, sem_seg_postprocess
 from .panoptic_fpn import combine_semantic_and_instance_outputs
 
@@ -48,8 +48,20 @@ class GeneralizedMCNNWSL(nn.Module):
 
     def preprocess_image(self, batched_inputs):
         images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
+        if images[0].dtype == torch.uint8 and images[0].is_cuda:
+            # the mappers' uint8 planes: normalise + pad + channels-last in one launch (csrc/postprocess.hip)
+            mean, std = self._pixel_stats()
+            tensor, sizes = preprocess_images_u8(images, mean, std, self.backbone.size_divisibility)
+            return ImageList(tensor, sizes)
         images = [(x - self.pixel_mean) / self.pixel_std for x in images]
         return ImageList.from_tensors(images, self.backbone.size_divisibility, channels_last=True)
+
+    def _pixel_stats(self):
+        """Host copies of the normalisation constants (read from the buffers once, then cached)."""
+        cached = getattr(self, "_pixel_stats_cache", None)
+        if cached is None:
+            cached = self._pixel_stats_cache = (self.pixel_mean.flatten().tolist(), self.pixel_std.flatten().tolist())
+        return cached
 
     def forward(self, batched_inputs):
         if not self.training:
