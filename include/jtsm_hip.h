@@ -538,6 +538,12 @@ int jtsm_paste_masks_f32(const float* masks, const float* boxes, int N, int M, i
  * (detectron2/modeling/postprocessing.py:75-100). */
 int jtsm_resize_bilinear_f32(const float* x, int layout, int N, int C, int H, int W, int crop_h, int crop_w,
                              int out_h, int out_w, float scale_h, float scale_w, float* y, void* stream);
+/* F.interpolate(x, size=(out_h, out_w), mode="nearest") of a planar (C, H, W) map, optionally reading the source
+ * columns mirrored: the resize + un-flip of GeneralizedRCNNWithTTAAVG._reduce_pred_sem_seg
+ * (projects/WSL/wsl/modeling/test_time_augmentation_avg.py:428-442; ResizeTransform.apply_segmentation on float
+ * arrays, detectron2/data/transforms/transform.py:116-141). */
+int jtsm_resize_nearest_f32(const float* x, int C, int H, int W, int out_h, int out_w, int flip_source, float* y,
+                            void* stream);
 /* out (HW) int64 <- argmax over c of planar x (C, HW); first maximum wins (sem_seg_r.argmax(dim=0), mcnn.py:352). */
 int jtsm_argmax_channels_f32(const float* x, int C, long HW, int64_t* out, void* stream);
 

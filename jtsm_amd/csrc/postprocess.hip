@@ -533,6 +533,19 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     o[(size_t)c * OH * OW] = ly0 * (lx0 * p00[c * sc] + lx1 * p01[c * sc]) + ly1 * (lx0 * p10[c * sc] + lx1 * p11[c * sc]);
 }
 
+// F.interpolate(mode="nearest"): src = min(floor(dst * scale), in - 1), scale = in / out in float
+// (upsample_nearest2d).  Planar (C, H, W) -> (C, OH, OW), optional horizontal flip of the SOURCE columns.
+__global__ __launch_bounds__(256) void resize_nearest_kernel(const float* __restrict__ x, int C, int H, int Wd, int OH,
+                                                             int OW, float sh, float sw, int flip,
+                                                             float* __restrict__ y) {
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y;
+  if (ox >= OW) return;
+  const int sy = min((int)floorf((float)oy * sh), H - 1);
+  int sx = min((int)floorf((float)ox * sw), Wd - 1);
+  if (flip) sx = Wd - 1 - sx;
+  for (int c = 0; c < C; ++c) y[((size_t)c * OH + oy) * OW + ox] = x[((size_t)c * H + sy) * Wd + sx];
+}
+
 // arg-max over the channel axis of a planar (C, HW) array; the first maximum wins (torch.argmax); NaN is a maximum
 __global__ __launch_bounds__(256) void argmax_channels_kernel(const float* __restrict__ x, int C, long HW,
                                                               int64_t* __restrict__ out) {
@@ -866,6 +879,18 @@ int jtsm_resize_bilinear_f32(const float* x, int layout, int N, int C, int H, in
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(ceil_div(out_w, 256), out_h, N), dim3(256), 0, as_stream(stream), x,
                      layout == JTSM_NHWC ? 1 : 0, C, H, W, crop_h, crop_w, out_h, out_w, scale_h, scale_w, y);
   JTSM_CHECK_LAUNCH("resize_bilinear");
+  return JTSM_OK;
+}
+
+int jtsm_resize_nearest_f32(const float* x, int C, int H, int W, int out_h, int out_w, int flip_source, float* y,
+                            void* stream) {
+  JTSM_REQUIRE(C >= 1 && H >= 1 && W >= 1 && out_h >= 0 && out_w >= 0, "resize_nearest: bad sizes");
+  if (out_h == 0 || out_w == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && y, "resize_nearest: null pointer");
+  JTSM_REQUIRE(out_h <= 65535, "resize_nearest: at most 65535 rows");
+  hipLaunchKernelGGL(resize_nearest_kernel, dim3(ceil_div(out_w, 256), out_h), dim3(256), 0, as_stream(stream), x, C, H, W,
+                     out_h, out_w, (float)H / (float)out_h, (float)W / (float)out_w, flip_source ? 1 : 0, y);
+  JTSM_CHECK_LAUNCH("resize_nearest");
   return JTSM_OK;
 }
 

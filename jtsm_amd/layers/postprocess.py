@@ -210,3 +210,16 @@ def preprocess_images_u8(images, mean, std, size_divisibility=0, pad_value=0.0):
     L.check(L.lib().jtsm_preprocess_images_u8(_ptr_array(images), hs, ws, B, Cc, m, sd, L.f32(pad_value), hp, wp,
                                               L.ptr(out), L.stream()), "preprocess_images")
     return out, sizes
+
+
+@torch.no_grad()
+def resize_nearest(x, out_hw, flip_source=False):
+    """F.interpolate(x[None], size=out_hw, mode="nearest")[0] of a planar (C, H, W) float map (source columns
+    optionally mirrored first)."""
+    L.require_gpu(x)
+    x = x.to(torch.float32).contiguous()
+    Cc, H, W = x.shape
+    y = torch.empty((Cc, int(out_hw[0]), int(out_hw[1])), dtype=torch.float32, device=x.device)
+    L.check(L.lib().jtsm_resize_nearest_f32(L.ptr(x), Cc, H, W, int(out_hw[0]), int(out_hw[1]), int(bool(flip_source)),
+                                            L.ptr(y), L.stream()), "resize_nearest")
+    return y

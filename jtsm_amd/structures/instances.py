@@ -55,9 +55,14 @@ class Instances:
         return self._fields
 
     def __setattr__(self, name: str, value: Any) -> None:
-        self.set(name, value)
+        if name.startswith("_"):          # the two slots (copy / pickle restore them this way)
+            object.__setattr__(self, name, value)
+        else:
+            self.set(name, value)
 
     def __getattr__(self, name: str) -> Any:
+        if name.startswith("_"):          # a slot not set yet (object under construction by copy / pickle)
+            raise AttributeError(name)
         fields = object.__getattribute__(self, "_fields")
         if name in fields:
             return fields[name]
