@@ -142,7 +142,11 @@ int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32
 /* All FPN levels in ONE launch — what detectron2/modeling/poolers.py:193-250 does level by level around
  * wsl/layers/moi_pool.py:10-33.  inputs[l] / grad_inputs[l]: (B,H[l],W[l],C) NHWC maps (host arrays of device
  * pointers, nlevels <= 8); roi_level[n] in [0,nlevels) picks roi n's map; output / argmax as above (NHWC).
- * The backward zero-fills every grad_inputs[l] and accumulates with float atomics. */
+ * Backward: with `scales` (the forward's level scales), a workspace
+ * (jtsm_moi_pool_backward_levels_workspace_bytes) and C a multiple of 256, every gradient map is produced by a
+ * gather — one workgroup per 8x8-cell tile sums, in roi / bin order, the gradients of the bins whose argmax fell
+ * into it (LDS accumulation, no atomics, bitwise reproducible, every cell written once); otherwise (scales or workspace NULL)
+ * each grad_inputs[l] is zero-filled and accumulated with float atomics. */
 size_t jtsm_moi_pool_levels_workspace_bytes(int B, const int* H, const int* W, int nlevels, int M, int L);
 int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, const int* W,
                                      const float* scales, int nlevels, const float* rois,
@@ -150,10 +154,12 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
                                      const int32_t* superpixels, float* output, int32_t* argmax,
                                      void* workspace, int B, int C, int M, int L, int Hs, int Ws,
                                      int pooled_h, int pooled_w, void* stream);
+size_t jtsm_moi_pool_backward_levels_workspace_bytes(int nlevels, int B, int M);
 int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                       const int32_t* argmax, float* const* grad_inputs, const int* H,
-                                      const int* W, int nlevels, int B, int C, int M, int pooled_h,
-                                      int pooled_w, void* stream);
+                                      const int* W, const float* scales, int nlevels, int B, int C, int M,
+                                      int pooled_h, int pooled_w, void* workspace, size_t workspace_bytes,
+                                      void* stream);
 
 /* mois (M,H,W) int32 exactly as MoIForward (MOIPool_cuda.cu:138-215) would write it;
  * test/diagnostic entry, same workspace contract as the forward. */

@@ -35,7 +35,8 @@ def lib():
         for name in ("jtsm_mil_workspace_bytes", "jtsm_oicr_workspace_bytes", "jtsm_conv_workspace_bytes",
                      "jtsm_group_norm_workspace_bytes", "jtsm_semseg_ce_workspace_bytes",
                      "jtsm_conv_bf16x3_wgrad_workspace_bytes", "jtsm_moi_pool_levels_workspace_bytes",
-                     "jtsm_paint_sem_seg_workspace_bytes", "jtsm_mask_bce_workspace_bytes"):
+                     "jtsm_paint_sem_seg_workspace_bytes", "jtsm_mask_bce_workspace_bytes",
+                     "jtsm_moi_pool_backward_levels_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_size_t
     return _lib

@@ -235,6 +235,140 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_levels(
   }
 }
 
+// Gather form of the backward: a workgroup owns an 8 x 8-cell tile of one level's gradient map (x 256 channels, 64 KB
+// of LDS), finds the (roi, bin) pairs whose bin range touches the tile from the roi geometry alone, and adds their
+// gradients into LDS — thread c owns channel c, so there are no atomics, the order is the roi / bin order (bitwise
+// reproducible), and every cell of the map is written exactly once (no zero fill, no read-modify-write in L2; the
+// scatter form above spends its time in L2 atomic line operations).
+constexpr int kTile = 8;
+struct MoiTiles {
+  int first[kMaxLevels + 1];   // first workgroup of each level
+  int tiles_x[kMaxLevels], tiles_y[kMaxLevels];
+};
+
+// ordered compaction of a per-thread flag over the 256 threads of the workgroup: returns this thread's slot (if
+// flagged) and the total; two barriers.
+__device__ __forceinline__ int compact256(bool flag, int* __restrict__ wave_count, int& total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  __syncthreads();                       // previous readers of wave_count are done
+  if (lane == 0) wave_count[wv] = __popcll(bal);
+  __syncthreads();
+  int off = 0;
+  total = 0;
+  for (int w = 0; w < 4; ++w) { if (w < wv) off += wave_count[w]; total += wave_count[w]; }
+  return off + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+constexpr int kPairCap = 1024;
+
+// rois of one (level, image), in index order: lists[(l * B + b) * M ...], counts[l * B + b].  One workgroup each.
+__global__ __launch_bounds__(256) void moi_roi_lists_kernel(const float* __restrict__ rois,
+                                                            const int* __restrict__ roi_level, int M, int B,
+                                                            int* __restrict__ lists, int* __restrict__ counts) {
+  __shared__ int wave_count[4];
+  const int l = blockIdx.x / B, b = blockIdx.x % B;
+  int* __restrict__ mine = lists + (size_t)blockIdx.x * M;
+  int filled = 0;
+  for (int base = 0; base < M; base += 256) {
+    const int n = base + threadIdx.x;
+    const bool hit = n < M && roi_level[n] == l && (int)rois[(size_t)n * 5] == b;
+    int cnt;
+    const int slot = compact256(hit, wave_count, cnt);
+    if (hit) mine[filled + slot] = n;
+    filled += cnt;
+  }
+  if (threadIdx.x == 0) counts[blockIdx.x] = filled;
+}
+
+__global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
+    const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
+    const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
+    const int* __restrict__ counts, int nlevels) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 cells][256 channels]
+  __shared__ int roi_list[256];
+  __shared__ int pair_list[kPairCap];   // (roi * nbins + bin) rows whose bin range touches the tile, in order
+  __shared__ int wave_count[4];
+  const int t = threadIdx.x;
+  int l = 0;
+  while (l + 1 < nlevels && (int)blockIdx.x >= tl.first[l + 1]) ++l;
+  const int H = lv.H[l], W = lv.W[l];
+  int rel = blockIdx.x - tl.first[l];
+  const int tx = rel % tl.tiles_x[l]; rel /= tl.tiles_x[l];
+  const int ty = rel % tl.tiles_y[l];
+  const int b = rel / tl.tiles_y[l];
+  const int x0 = tx * kTile, y0 = ty * kTile, x1 = min(x0 + kTile, W) - 1, y1 = min(y0 + kTile, H) - 1;
+  const int c = blockIdx.y * 256 + t;
+  const float scale = lv.scale[l];
+  const int nbins = PH * PW;
+  for (int i = t; i < kTile * kTile * 64; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  int np = 0;   // uniform
+
+  constexpr int kDepth = 16;
+  auto drain = [&]() {   // add the listed rows' gradients into the tile: kDepth rows' loads in flight per thread
+    __syncthreads();
+    for (int j = 0; j < np; j += kDepth) {
+      int a[kDepth];
+      float g[kDepth];
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        const size_t row = (size_t)pair_list[min(j + u, np - 1)];
+        a[u] = j + u < np ? argmax[row * C + c] : -1;
+        g[u] = j + u < np ? grad[row * C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        if (a[u] < 0) continue;
+        const int ay = a[u] / W, ax = a[u] - ay * W;
+        if (ay >= y0 && ay <= y1 && ax >= x0 && ax <= x1) acc[((ay - y0) * kTile + (ax - x0)) * 256 + t] += g[u];
+      }
+    }
+    np = 0;
+  };
+
+  const int* __restrict__ mine = lists + (size_t)(l * B + b) * M;
+  const int nmine = counts[l * B + b];
+  for (int base = 0; base < nmine; base += 256) {
+    // ---- rois of this level / image whose box touches the tile, in index order
+    const int n = base + t < nmine ? mine[base + t] : -1;
+    bool hit = false;
+    if (n >= 0) {
+      const IBox r = round_box(rois + (size_t)n * 5, scale);
+      hit = r.x0 <= x1 && r.x1 >= x0 && r.y0 <= y1 && r.y1 >= y0;
+    }
+    int nroi;
+    const int slot = compact256(hit, wave_count, nroi);
+    if (hit) roi_list[slot] = n;
+    __syncthreads();
+    // ---- their bins whose cell range touches the tile, in (roi, bin) order
+    const int ncombo = nroi * nbins;
+    for (int k0 = 0; k0 < ncombo; k0 += 256) {
+      if (np > kPairCap - 256) drain();
+      const int k = k0 + t;
+      bool bh = false;
+      int row = 0;
+      if (k < ncombo) {
+        const int i = k / nbins, bin = k - i * nbins, m = roi_list[i];
+        const IBox r = round_box(rois + (size_t)m * 5, scale);
+        const BinRange q = bin_range(r, bin / PW, bin % PW, PH, PW, H, W);
+        bh = q.he > q.hs && q.we > q.ws && q.hs <= y1 && q.he > y0 && q.ws <= x1 && q.we > x0;
+        row = m * nbins + bin;
+      }
+      int cnt;
+      const int ps = compact256(bh, wave_count, cnt);
+      if (bh) pair_list[np + ps] = row;
+      np += cnt;
+    }
+    __syncthreads();   // roi_list is rewritten by the next chunk
+  }
+  drain();
+  float* __restrict__ out = lv.gin[l] + (size_t)b * H * W * C;
+  for (int y = y0; y <= y1; ++y)
+    for (int x = x0; x <= x1; ++x)
+      out[((size_t)y * W + x) * C + c] = acc[((y - y0) * kTile + (x - x0)) * 256 + t];
+}
+
 // NCHW (reference layout): one thread per output element; cell test done per thread.
 __global__ __launch_bounds__(256) void moi_pool_fwd_nchw(
     const float* __restrict__ in, const float* __restrict__ rois,
@@ -518,16 +652,51 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
   return JTSM_OK;
 }
 
+size_t jtsm_moi_pool_backward_levels_workspace_bytes(int nlevels, int B, int M) {
+  if (nlevels <= 0 || B <= 0 || M <= 0) return 0;
+  return ((size_t)nlevels * B * ((size_t)M + 1) * sizeof(int) + 15) & ~(size_t)15;
+}
+
 int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                       const int32_t* argmax, float* const* grad_inputs, const int* H, const int* W,
-                                      int nlevels, int B, int C, int M, int pooled_h, int pooled_w, void* stream) {
+                                      const float* scales, int nlevels, int B, int C, int M, int pooled_h, int pooled_w,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
   JTSM_REQUIRE(nlevels > 0 && nlevels <= kMaxLevels && grad_inputs && H && W, "moi_pool levels backward: bad level table");
   JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0 && C % 4 == 0,
                "moi_pool levels backward: bad sizes (C %% 4 must be 0)");
   hipStream_t st = as_stream(stream);
   MoiLevels lv = {};
+  bool all = true;
   for (int l = 0; l < nlevels; ++l) {
     lv.gin[l] = grad_inputs[l]; lv.H[l] = H[l]; lv.W[l] = W[l];
+    lv.scale[l] = scales ? scales[l] : 0.f;
+    all = all && grad_inputs[l] != nullptr;
+  }
+  // gather form: needs the level scales (bin geometry), 256-channel blocks, bins that fit one wavefront
+  const bool tiled = scales && workspace && all && C % 256 == 0 && M > 0 && B > 0;
+  if (tiled) {
+    JTSM_REQUIRE(grad && rois && roi_level && argmax, "moi_pool levels backward: null pointer");
+    const size_t need = jtsm_moi_pool_backward_levels_workspace_bytes(nlevels, B, M);
+    JTSM_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 3) == 0,
+                 "moi_pool levels backward: workspace of %zu bytes needed", need);
+    int* lists = reinterpret_cast<int*>(workspace);
+    int* counts = lists + (size_t)nlevels * B * M;
+    hipLaunchKernelGGL(moi_roi_lists_kernel, dim3(nlevels * B), dim3(256), 0, st, rois, roi_level, M, B, lists, counts);
+    MoiTiles tl = {};
+    int blocks = 0;
+    for (int l = 0; l < nlevels; ++l) {
+      tl.first[l] = blocks;
+      tl.tiles_x[l] = ceil_div(W[l], kTile);
+      tl.tiles_y[l] = ceil_div(H[l], kTile);
+      blocks += B * tl.tiles_x[l] * tl.tiles_y[l];
+    }
+    tl.first[nlevels] = blocks;
+    hipLaunchKernelGGL(moi_pool_bwd_tiled, dim3(blocks, C / 256), dim3(256), kTile * kTile * 256 * sizeof(float), st, lv, tl,
+                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels);
+    JTSM_CHECK_LAUNCH("moi_pool backward levels (tiled)");
+    return JTSM_OK;
+  }
+  for (int l = 0; l < nlevels; ++l) {
     if (!grad_inputs[l]) continue;   // a level whose gradient is not wanted
     JTSM_CHECK_HIP(hipMemsetAsync(grad_inputs[l], 0, (size_t)B * H[l] * W[l] * C * sizeof(float), st));
   }

@@ -115,7 +115,7 @@ class _MOILevels(Function):
             L.ptr(arg), L.ptr(ws), B, Cc, M, Lw, superpixels.shape[1], superpixels.shape[2], res, res, L.stream()),
             "moi_pool_forward_levels")
         ctx.save_for_backward(rois, roi_level, arg)
-        ctx.cfg = (res, [tuple(f.shape) for f in feats])
+        ctx.cfg = (res, [tuple(f.shape) for f in feats], [float(x) for x in scales])
         ctx.mark_non_differentiable(arg)
         return out, arg
 
@@ -123,7 +123,7 @@ class _MOILevels(Function):
     @once_differentiable
     def backward(ctx, g, _ga=None):
         rois, roi_level, arg = ctx.saved_tensors
-        res, shapes = ctx.cfg
+        res, shapes, scales = ctx.cfg
         g = g.contiguous(memory_format=CL)
         nl = len(shapes)
         B, Cc = shapes[0][0], shapes[0][1]
@@ -131,9 +131,13 @@ class _MOILevels(Function):
         Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
         Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
         ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads])
-        L.check(L.lib().jtsm_moi_pool_backward_levels_f32(
-            L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, nl, B, Cc, rois.shape[0], res, res,
-            L.stream()), "moi_pool_backward_levels")
+        sc = (C.c_float * nl)(*scales)
+        lib = L.lib()
+        ws = torch.empty(max(lib.jtsm_moi_pool_backward_levels_workspace_bytes(nl, B, rois.shape[0]), 16),
+                         dtype=torch.uint8, device=g.device)
+        L.check(lib.jtsm_moi_pool_backward_levels_f32(
+            L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
+            L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "moi_pool_backward_levels")
         grads = [gi if ctx.needs_input_grad[6 + lvl] else None for lvl, gi in enumerate(grads)]
         return (None, None, None, None, None, None, *grads)
 

@@ -287,3 +287,74 @@ def test_fpn_level_assignment_and_multilevel_pooling_match_oracle(cuda):
     assert np.array_equal(y.detach().cpu().numpy(), y0.detach().numpy())
     for a, b in zip(xs, fr):
         assert np.allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_multilevel_moi_pool_backward_gather_matches_oracle_and_scatter(cuda):
+    """The gather form of the multi-level MOIPool backward (one workgroup per 8x8-cell tile, LDS accumulation in
+    roi / bin order; 256-channel maps) against (1) the oracle's per-level scatter, (2) the library's own atomic
+    scatter form (scales == NULL) on the same inputs, and (3) itself run twice — it must be bitwise reproducible."""
+    import ctypes as C
+
+    from jtsm_amd import _lib as L
+    from jtsm_amd.modeling.poolers import ROIPooler
+    from jtsm_amd.structures import Boxes
+    from oracle import model as OM
+
+    rng = np.random.default_rng(41)
+    B, Cc, size, sp = 2, 256, 256, 8
+    M = 300
+    r = _fpn_like_rois(rng, M, B, size)
+    boxes = [torch.from_numpy(r[r[:, 0] == b][:, 1:]) for b in range(B)]
+    grid = size // sp
+    ids = (torch.arange(size)[:, None] // sp) * grid + (torch.arange(size)[None, :] // sp)
+    superpixels = ids.to(torch.int32)[None].repeat(B, 1, 1)
+    cy = torch.arange(grid) * sp + sp / 2.0
+    oh = []
+    for bx in boxes:
+        iny = (cy[None, :] >= bx[:, 1:2]) & (cy[None, :] <= bx[:, 3:4])
+        inx = (cy[None, :] >= bx[:, 0:1]) & (cy[None, :] <= bx[:, 2:3])
+        oh.append((iny[:, :, None] & inx[:, None, :]).reshape(len(bx), -1).to(torch.int32))
+    feats = [rng.standard_normal((B, Cc, (size // 4) >> i, (size // 4) >> i)).astype(np.float32) for i in range(4)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+
+    def run():
+        pooler = ROIPooler(7, scales, 0, "MOIPool")
+        xs = [dev(f, cuda, True).requires_grad_() for f in feats]
+        y, arg = pooler(xs, [Boxes(b.to(cuda)) for b in boxes], oh_labels_list=[o.to(cuda) for o in oh],
+                        superpixels=superpixels.to(cuda))
+        return xs, y, arg
+
+    xs, y, arg = run()
+    g = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    gd = dev(g, cuda, True)
+    y.backward(gd)
+    # (1) oracle
+    fr = [torch.from_numpy(f).requires_grad_() for f in feats]
+    y0, a0 = OM.moi_pool_levels(fr, boxes, oh, superpixels)
+    y0.backward(torch.from_numpy(g))
+    assert np.array_equal(y.detach().cpu().numpy(), y0.detach().numpy())
+    assert np.array_equal(arg.cpu().numpy(), a0.numpy())
+    for a, b in zip(xs, fr):
+        assert np.allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-5, atol=1e-5)
+    assert sum(float(a.grad.abs().sum()) for a in xs) > 0
+    # (2) the atomic scatter form of the same library entry
+    from jtsm_amd.modeling.poolers import assign_boxes_to_levels, convert_boxes_to_pooler_format
+    bl = [Boxes(b.to(cuda)) for b in boxes]
+    rois = convert_boxes_to_pooler_format(bl)
+    lv = assign_boxes_to_levels(bl, 2, 5, 224, 4).to(torch.int32)
+    nl = 4
+    grads = [torch.full_like(a.grad, float("nan")) for a in xs]
+    Hs = (C.c_int * nl)(*[a.shape[2] for a in xs])
+    Ws = (C.c_int * nl)(*[a.shape[3] for a in xs])
+    ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads])
+    gcl, acl = gd.contiguous(memory_format=torch.channels_last), arg.contiguous(memory_format=torch.channels_last)
+    L.check(L.lib().jtsm_moi_pool_backward_levels_f32(L.ptr(gcl), L.ptr(rois), L.ptr(lv), L.ptr(acl), ptrs, Hs, Ws, None,
+                                                      nl, B, Cc, rois.shape[0], 7, 7, None, C.c_size_t(0), L.stream()),
+            "scatter form")
+    for a, s in zip(xs, grads):
+        assert torch.allclose(a.grad, s, rtol=1e-5, atol=1e-5)
+    # (3) bitwise reproducible
+    xs2, y2, _ = run()
+    y2.backward(gd)
+    for a, b in zip(xs, xs2):
+        assert torch.equal(a.grad, b.grad)
