@@ -504,10 +504,15 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
                                                 28, 0, True))[:, 0] >= 0.5
     ar = torch.arange(fg_rois.shape[0])
     logits = mask_head_layers(p, "roi_heads.mask_head.", mfeat)
-    losses["loss_mask"] = F.binary_cross_entropy_with_logits(logits[ar, fg_cls], gt28.to(torch.float32))
+    def mask_loss(z, target):   # mask_rcnn_loss: an empty foreground set contributes an exact zero (mask_head.py:47-48)
+        if z.shape[0] == 0:
+            return z.sum() * 0
+        return F.binary_cross_entropy_with_logits(z[ar, fg_cls], target.to(torch.float32))
+
+    losses["loss_mask"] = mask_loss(logits, gt28)
     tgt2 = logits.detach()[ar, fg_cls] > 0.0      # sigmoid > 0.5 of the first head's own prediction
     logits2 = mask_head_layers(p, "roi_heads.mask_refinery_0.", mfeat)
-    losses["loss_mask_r0"] = F.binary_cross_entropy_with_logits(logits2[ar, fg_cls], tgt2.to(torch.float32))
+    losses["loss_mask_r0"] = mask_loss(logits2, tgt2)
 
     # ---- semantic branch
     sl = semseg_head(p, feats)

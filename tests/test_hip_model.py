@@ -173,3 +173,42 @@ def test_ragged_batch_losses_and_labels(cuda):
         assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
     assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
+
+
+def test_r101_rectangular_losses_match(cuda):
+    """BASELINE configs[4] geometry at reduced size: R101-FPN on 1:2 (Cityscapes-shaped) images — every loss against
+    the oracle (the arithmetic of that config's 'fp16 MFMA path' is served here by the split-bf16 contractions, whose
+    error is below fp16's)."""
+    params = OM.init_params(seed=7, depth=101, random_bn=True, input_gain=1.0 / 64)
+    with torch.no_grad():   # 33 random-init residual blocks double the variance each: damp every block's last norm
+        for k in params:
+            if k.endswith("conv3.norm.weight"):
+                params[k] *= 0.3
+    batch = OM.synthetic_batch(99, B=1, size=256, R=96, sp_block=8)
+    # crop to 128 x 256 (H x W): boxes / labels / superpixels follow
+    H, W = 128, 256
+    batch["images"] = [im[:, :H, :W].contiguous() for im in batch["images"]]
+    batch["sem_seg"] = batch["sem_seg"][:, :H, :W].contiguous()
+    batch["superpixels"] = batch["superpixels"][:, :H, :W].contiguous()
+    bx = batch["boxes"][0].clone()
+    bx[:, 1] *= 0.5
+    bx[:, 3] *= 0.5                                       # the same boxes squeezed into the top half
+    batch["boxes"][0] = bx
+    grid = 256 // 8
+    cy = torch.arange(grid) * 8 + 4.0
+    iny = (cy[None, :] >= bx[:, 1:2]) & (cy[None, :] <= bx[:, 3:4])
+    inx = (cy[None, :] >= bx[:, 0:1]) & (cy[None, :] <= bx[:, 2:3])
+    batch["oh_labels"][0] = (iny[:, :, None] & inx[:, None, :]).reshape(len(bx), -1).to(torch.int32)
+    losses0 = OM.forward_losses(params, batch, depth=101)
+    model = build_model(jtsm_cfg("cuda", depth=101))
+    model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    losses = model(to_batched_inputs(batch))
+    assert set(losses) == set(losses0)
+    for k in sorted(losses0):
+        a, b = float(losses[k].detach()), float(losses0[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
+    assert float(losses0["loss_mask"]) > 0                # the case has foreground rois
+    sum(losses.values()).backward()
+    assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())

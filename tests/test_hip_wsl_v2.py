@@ -104,3 +104,28 @@ def test_dc5_composite_training_step(cuda):
             assert p.grad is None, n
         elif p.requires_grad:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+def test_dc5_inference_contract(cuda):
+    """The shipped configuration in eval mode: single-level MOIPool on the dilated res5 map (2048 channels: eight
+    channel blocks in the pooling kernels), 20 classes, the parameter-free two-class semantic head -> detections, masks
+    and a panoptic map whose only stuff segment is class 1."""
+    torch.manual_seed(0)
+    cfg = dc5_cfg("cuda")
+    cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 1e-5
+    cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.3
+    cfg.MODEL.PANOPTIC_FPN.COMBINE.INSTANCES_CONFIDENCE_THRESH = 0.9     # keep most of the map for the stuff class
+    model = build_model(cfg)
+    with torch.no_grad():
+        model.backbone.stem.conv1.weight.mul_(1.0 / 64)
+    model.eval()
+    inputs = synthetic_inputs(99, batch=2, size=256, proposals=120, sp_block=8, device=cuda, num_things=20, num_stuff=2,
+                              n_stuff=1)
+    out = model(inputs)
+    assert len(out) == 2
+    for o in out:
+        inst, sem, (pan, info) = o["instances"], o["sem_seg"], o["panoptic_seg"]
+        assert sem.shape == (2, 256, 256) and bool((sem[1] > sem[0]).all())
+        assert len(inst) <= 100 and inst.pred_masks.shape[1:] == (256, 256) and int(inst.pred_classes.max()) < 20
+        stuff = [s for s in info if not s["isthing"]]
+        assert [s["category_id"] for s in stuff] == [1] and int((pan == stuff[0]["id"]).sum()) == stuff[0]["area"]
