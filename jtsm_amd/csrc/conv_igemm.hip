@@ -1249,11 +1249,14 @@ static int x3_wgrad_splits(const Params& p) {
   const int t = big ? 256 : 128;
   const int ntiles = ceil_div(p.N, t) * ceil_div(p.M, t);
   const int ktiles = ceil_div(p.K, XBK);
-  // Pixel-axis split (measured on MI355X, scratch/wgrad_sweep.py): about one workgroup per CU with >= 16 stages
-  // each; only when that would leave > 64 stages per workgroup (large maps) go to three workgroups per CU.
-  int splits = ceil_div(256, ntiles);
+  // Pixel-axis split (measured on MI355X, scratch/wsplit.py): the kernels are bound by memory latency x bytes in
+  // flight, so two workgroups per CU (512) beat one as long as each keeps >= 8 stages; 256 x 256 tiles hold one
+  // workgroup per CU.
+  int splits = ceil_div(big ? 256 : 512, ntiles);
   if (!big && ceil_div(ktiles, splits) > 64) splits = ceil_div(768, ntiles);
-  if (splits > ceil_div(ktiles, 16)) splits = ceil_div(ktiles, 16);
+  const int min_stages = big ? 16 : 8;
+  if (splits > ceil_div(ktiles, min_stages)) splits = ceil_div(ktiles, min_stages);
+  if (splits > 64) splits = 64;   // slab traffic: the finishing pass reads splits x dW
   if (splits < 1) splits = 1;
   const int kps = ceil_div(ktiles, splits);
   return kps > 0 ? ceil_div(ktiles, kps) : 1;
