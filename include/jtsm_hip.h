@@ -557,13 +557,14 @@ int jtsm_argmax_channels_f32(const float* x, int C, long HW, int64_t* out, void*
  * uint8, order (N) int32 = instance indices by descending score, scores / classes (N), sem (H, W) int64 in [0, S),
  * S <= 256.  panoptic (H, W) int32 <- segment ids; seg_table (N + S, 5) int32 rows {id, isthing, category_id,
  * instance_id or -1, area (stuff: unpainted area; things: newly painted pixels)}, seg_score (N + S),
- * *num_segments (device). */
+ * *num_segments (device).  max_visits: number of leading instances (in `order`) to walk — pass the count of scores
+ * >= the confidence threshold when it is known, or -1 for all N (the walk itself stops at the threshold too). */
 size_t jtsm_panoptic_combine_workspace_bytes(int N, int S);
 int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const float* scores, const int64_t* classes,
                           int N, int H, int W, const int64_t* sem, int S, double overlap_threshold,
                           int stuff_area_limit, float instances_confidence_threshold, int32_t* panoptic,
-                          int32_t* seg_table, float* seg_score, int32_t* num_segments, void* workspace,
-                          size_t workspace_bytes, void* stream);
+                          int32_t* seg_table, float* seg_score, int32_t* num_segments, int max_visits,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* Model input boundary: GeneralizedMCNNWSL.preprocess_image
  * (projects/WSL/wsl/modeling/meta_arch/mcnn.py:303-318) + ImageList.from_tensors

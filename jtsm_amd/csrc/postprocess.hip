@@ -912,8 +912,8 @@ size_t jtsm_panoptic_combine_workspace_bytes(int N, int S) {
 int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const float* scores, const int64_t* classes,
                           int N, int H, int W, const int64_t* sem, int S, double overlap_threshold,
                           int stuff_area_limit, float instances_confidence_threshold, int32_t* panoptic,
-                          int32_t* seg_table, float* seg_score, int32_t* num_segments, void* workspace,
-                          size_t workspace_bytes, void* stream) {
+                          int32_t* seg_table, float* seg_score, int32_t* num_segments, int max_visits,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   JTSM_REQUIRE(N >= 0 && H >= 1 && W >= 1 && S >= 1 && S <= kMaxSem, "panoptic_combine: bad sizes (S <= %d)", kMaxSem);
   JTSM_REQUIRE(sem && panoptic && seg_table && seg_score && num_segments, "panoptic_combine: null pointer");
   JTSM_REQUIRE(N == 0 || (masks && order && scores && classes), "panoptic_combine: null instance arrays");
@@ -934,7 +934,10 @@ int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const floa
     hipLaunchKernelGGL(pan_extent_init_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, extent, N, H);
     hipLaunchKernelGGL(pan_extent_kernel, dim3(ceil_div((long)N * H, 4)), dim3(256), 0, st, masks, N, H, W, extent);
   }
-  for (int v = 0; v < N; ++v) {
+  // the walk stops at the first score below the confidence threshold: a caller that knows how many instances
+  // clear it passes that count and saves the launches of the rest (they would all return at once)
+  const int visits = (max_visits >= 0 && max_visits < N) ? max_visits : N;
+  for (int v = 0; v < visits; ++v) {
     hipLaunchKernelGGL(pan_count_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, v, H, W,
                        instances_confidence_threshold, panoptic, extent, counters);
     hipLaunchKernelGGL(pan_paint_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, classes, v, H, W,
@@ -943,7 +946,7 @@ int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const floa
   }
   JTSM_CHECK_LAUNCH("panoptic instances");
   hipLaunchKernelGGL(pan_stuff_hist_kernel, dim3(blocks), dim3(256), 0, st, sem, panoptic, HW, S, hist);
-  hipLaunchKernelGGL(pan_stuff_assign_kernel, dim3(1), dim3(1), 0, st, hist, S, stuff_area_limit, N, next_id, label_id,
+  hipLaunchKernelGGL(pan_stuff_assign_kernel, dim3(1), dim3(1), 0, st, hist, S, stuff_area_limit, visits, next_id, label_id,
                      seg_table, seg_score, num_segments);
   hipLaunchKernelGGL(pan_stuff_paint_kernel, dim3(blocks), dim3(256), 0, st, sem, HW, S, label_id, panoptic);
   JTSM_CHECK_LAUNCH("panoptic stuff");

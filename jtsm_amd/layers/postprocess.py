@@ -178,13 +178,17 @@ def panoptic_combine(masks, scores, classes, sem, num_sem_classes, overlap_thres
         scores = scores.to(torch.float32).contiguous()
         classes = classes.to(torch.int64).contiguous()
         order = torch.sort(scores, descending=True, stable=True).indices.to(torch.int32)
+        # instances above the confidence threshold: the walk is two launches per visited instance, so knowing the
+        # count up front (one small read; this function ends with a read anyway) saves the rest
+        visits = int((scores >= float(instances_confidence_threshold)).sum().item())
     lib = L.lib()
     ws = _ws(_sizet(lib.jtsm_panoptic_combine_workspace_bytes, N, S), dev)
     L.check(lib.jtsm_panoptic_combine(L.ptr(masks) if N else None, L.ptr(order), L.ptr(scores) if N else None,
                                       L.ptr(classes) if N else None, N, H, W, L.ptr(sem), S,
                                       C.c_double(float(overlap_threshold)), int(stuff_area_limit),
                                       L.f32(instances_confidence_threshold), L.ptr(pan), L.ptr(table), L.ptr(tscore),
-                                      L.ptr(nseg), L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "panoptic_combine")
+                                      L.ptr(nseg), visits if N else -1, L.ptr(ws), C.c_size_t(ws.numel()), L.stream()),
+            "panoptic_combine")
     n = int(nseg.item())
     return pan, table[:n], tscore[:n]
 
