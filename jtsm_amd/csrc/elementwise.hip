@@ -131,9 +131,25 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd(const float* __restrict__ 
 }
 
 // out = lateral + nearest_upsample_x2(top)      (FPN top-down path, fpn.py:133-136)
+typedef __bf16 ew_bf16x4 __attribute__((ext_vector_type(4)));
+// bf16 hi / lo planes of four values (what jtsm_split_bf16_f32 makes of them), for a bf16x3 consumer
+__device__ __forceinline__ void ew_planes4(unsigned short* hi, unsigned short* lo, long i4, const float4& v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  ew_bf16x4 h, l;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const __bf16 hh = (__bf16)x[e];
+    h[e] = hh;
+    l[e] = (__bf16)(x[e] - (float)hh);
+  }
+  reinterpret_cast<ew_bf16x4*>(hi)[i4] = h;
+  reinterpret_cast<ew_bf16x4*>(lo)[i4] = l;
+}
+
 __global__ __launch_bounds__(256) void upsample2_add_fwd(const float4* __restrict__ top,
                                                          const float4* __restrict__ lat,
-                                                         float4* __restrict__ out, int N, int H,
+                                                         float4* __restrict__ out, unsigned short* __restrict__ out_hi,
+                                                         unsigned short* __restrict__ out_lo, int N, int H,
                                                          int W, int C4) {
   const long total = (long)N * H * W * C4;
   const int Ht = H / 2, Wt = W / 2;
@@ -143,7 +159,9 @@ __global__ __launch_bounds__(256) void upsample2_add_fwd(const float4* __restric
     const int w = (int)(t % W); t /= W;
     const int h = (int)(t % H);
     const int n = (int)(t / H);
-    out[i] = f4add(lat[i], top[((long)(n * Ht + h / 2) * Wt + w / 2) * C4 + c]);
+    const float4 v = f4add(lat[i], top[((long)(n * Ht + h / 2) * Wt + w / 2) * C4 + c]);
+    out[i] = v;
+    if (out_hi) ew_planes4(out_hi, out_lo, i, v);
   }
 }
 // d_top[n,h,w] = sum of the 2x2 block of g
@@ -368,15 +386,16 @@ int jtsm_maxpool3x3s2_backward_f32(const float* x, const float* gy, float* gx, i
   return JTSM_OK;
 }
 
-int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, int N, int H, int W, int C,
-                           void* stream) {
+int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                           int N, int H, int W, int C, void* stream) {
   JTSM_REQUIRE(N >= 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && H % 2 == 0 && W % 2 == 0,
                "upsample2_add: need even H, W and C %% 4 == 0");
   const long total = (long)N * H * W * (C / 4);
   if (total == 0) return JTSM_OK;
   JTSM_REQUIRE(top && lateral && out, "upsample2_add: null pointer");
+  JTSM_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), "upsample2_add: give both planes or neither");
   hipLaunchKernelGGL(upsample2_add_fwd, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
-                     (const float4*)top, (const float4*)lateral, (float4*)out, N, H, W, C / 4);
+                     (const float4*)top, (const float4*)lateral, (float4*)out, out_hi, out_lo, N, H, W, C / 4);
   JTSM_CHECK_LAUNCH("upsample2_add");
   return JTSM_OK;
 }

@@ -465,8 +465,10 @@ class _ConvFused(Function):
     (FrozenBN statistics or a conv bias treated by the caller), residual gets dy * relu'."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True):
+    def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True,
+                emit_dx_planes=False):
         y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
+        ctx.emit_dx_planes = emit_dx_planes   # the input's gradient is the dy of another contraction (FPN laterals)
         ctx.cfg = (stride, pad, dil, relu, bias_needs_grad, tuple(x.shape), tuple(w.shape))
         ctx.has_res = residual is not None
         ctx.save_for_backward(x, w, scale, y if relu else None)
@@ -492,7 +494,7 @@ class _ConvFused(Function):
             # fold the FrozenBN scale into the weight rows once (a few MB) so the data-gradient GEMM takes
             # the direct-to-LDS path, which cannot rescale operands on the fly
             if MATH == "bf16x3":   # (ineligible shapes fall through to the fp32 kernel's own kscale path)
-                dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale)
+                dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale, emit_planes=ctx.emit_dx_planes)
             else:
                 w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
                 dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
@@ -506,11 +508,11 @@ class _ConvFused(Function):
             dw = dw.as_strided(w.shape, w.stride())
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = g
-        return dx, dw, None, db, dres, None, None, None, None, None, None
+        return dx, dw, None, db, dres, None, None, None, None, None, None, None
 
 
 def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False,
-                 bias_needs_grad=False, emit_planes=True):
+                 bias_needs_grad=False, emit_planes=True, emit_dx_planes=False):
     """Autograd-aware fused convolution.  An output-channel count that is not a multiple of 4 (54 sem-seg
     classes, the 1870-wide fused predictor) is zero-padded up for the kernels' 16-byte rows and the
     padding is sliced off the result (its gradient is zero by construction)."""
@@ -524,9 +526,10 @@ def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, di
             bias = torch.cat([bias, bias.new_zeros(extra)])
         if residual is not None:
             residual = torch.nn.functional.pad(residual, (0, 0, 0, 0, 0, extra))
-        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, False)
+        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, False, False)
         return y[:, :o]
-    return _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes)
+    return _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes,
+                            emit_dx_planes)
 
 
 def linear_fused(x, w, bias=None, relu=False, bias_needs_grad=True):
@@ -570,6 +573,6 @@ def linear_fused_split(x, weights, biases, relu=False):
         bs.append(biases[0].new_zeros(pad))
     w = torch.cat(ws).view(total + pad, k, 1, 1)
     b = torch.cat(bs)
-    y = _ConvFused.apply(x.view(r, k, 1, 1), w, None, b, None, 1, 0, 1, relu, True, False).view(r, total + pad)
+    y = _ConvFused.apply(x.view(r, k, 1, 1), w, None, b, None, 1, 0, 1, relu, True, False, False).view(r, total + pad)
     outs = _ColumnSplit.apply(y, *(sizes + ([pad] if pad else [])))
     return list(outs[:len(sizes)])

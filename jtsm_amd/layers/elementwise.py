@@ -121,8 +121,15 @@ class _Upsample2Add(torch.autograd.Function):
         if top.shape != (n, c, h // 2, w // 2) or h % 2 or w % 2:
             raise RuntimeError("upsample2_add: lateral %s is not 2x top %s" % (tuple(lateral.shape), tuple(top.shape)))
         out = torch.empty_like(lateral)
-        L.check(L.lib().jtsm_upsample2_add_f32(L.ptr(top), L.ptr(lateral), L.ptr(out), n, h, w, c, L.stream()),
+        from . import conv
+        buf = hi = lo = None
+        if conv.MATH == "bf16x3" and c % 8 == 0 and out.numel() > 0:   # the merged map feeds a 3x3 output conv
+            buf = conv._planes_buf(out.numel(), out.device)
+            hi, lo = conv._hl(buf)
+        L.check(L.lib().jtsm_upsample2_add_f32(L.ptr(top), L.ptr(lateral), L.ptr(out), hi, lo, n, h, w, c, L.stream()),
                 "upsample2_add")
+        if buf is not None:
+            conv.planes_put(out, buf)
         return out
 
     @staticmethod

@@ -68,7 +68,7 @@ class Conv2d(nn.Conv2d):
         else:
             w = self.weight
         y = conv2d_fused(x, w, scale, bias, residual, self.stride[0], self.padding[0], self.dilation[0], relu,
-                         bias_grad)
+                         bias_grad, emit_dx_planes=getattr(self, "emit_dx_planes", False))
         if isinstance(self.norm, nn.GroupNorm) and self.norm.affine and y.is_cuda and y.dtype == torch.float32:
             # GroupNorm (+ the following ReLU) as one channels-last pass (jtsm_amd/csrc/semseg_ops.hip)
             from .elementwise import group_norm_relu

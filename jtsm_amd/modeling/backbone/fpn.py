@@ -48,6 +48,9 @@ class FPN(Backbone):
             stage = int(math.log2(strides[idx]))
             self.add_module("fpn_lateral{}".format(stage), lateral_conv)
             self.add_module("fpn_output{}".format(stage), output_conv)
+            # the output conv's input gradient is (through the top-down add) the lateral conv's dy: let the
+            # data-gradient epilogue write its bf16 planes for that contraction
+            output_conv.emit_dx_planes = True
             lateral_convs.append(lateral_conv)
             output_convs.append(output_conv)
         # top-down order: coarsest level first
