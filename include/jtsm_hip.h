@@ -311,6 +311,11 @@ int jtsm_maxpool2x2_backward_f32(const float* x, const float* gy, float* gx, int
 /* out(N,H,W,C) = lateral(N,H,W,C) + top(N,H/2,W/2,C) repeated 2x2. */
 int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, uint16_t* out_hi, uint16_t* out_lo,
                            int N, int H, int W, int C, void* stream);   /* out_hi / out_lo (optional): bf16 planes of out */
+/* out = inputs[0] + inputs[1] (+ ...), n <= 4 dense tensors of `numel` floats summed in list order (HOST array of
+ * device pointers), optional bf16 planes of the sum: the level sum of SemSegFPNHead.layers
+ * (detectron2/modeling/meta_arch/semantic_seg.py:178-186) in one pass. */
+int jtsm_sum_tensors_f32(const float* const* inputs, int n, long numel, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                         void* stream);
 /* out(N,Ht,Wt,C) = sum over the 2x2 blocks of g(N,2Ht,2Wt,C): backward of the x2 upsample. */
 int jtsm_sum2x2_f32(const float* g, float* out, int N, int Ht, int Wt, int C, void* stream);
 /* scatter=0: dst(N,Ho,Wo,C) = src(N,H,W,C)[:, ::2, ::2]; scatter=1: dst(N,H,W,C) zero-filled, then

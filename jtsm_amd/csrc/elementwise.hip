@@ -164,6 +164,19 @@ __global__ __launch_bounds__(256) void upsample2_add_fwd(const float4* __restric
     if (out_hi) ew_planes4(out_hi, out_lo, i, v);
   }
 }
+// out = x0 + x1 (+ x2 (+ x3)), summed in that order (the accumulation order of `x = x + y` loops), optional bf16
+// planes of the sum: the level sum of SemSegFPNHead.layers (semantic_seg.py:178-186) in one pass.
+struct SumPtrs { const float4* p[4]; };
+__global__ __launch_bounds__(256) void sum_tensors_kernel(SumPtrs in, int n, long total4, float4* __restrict__ out,
+                                                          unsigned short* __restrict__ hi, unsigned short* __restrict__ lo) {
+#pragma clang fp contract(off)
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    float4 v = in.p[0][i];
+    for (int k = 1; k < n; ++k) v = f4add(v, in.p[k][i]);
+    out[i] = v;
+    if (hi) ew_planes4(hi, lo, i, v);
+  }
+}
 // d_top[n,h,w] = sum of the 2x2 block of g
 __global__ __launch_bounds__(256) void sum2x2_kernel(const float4* __restrict__ g,
                                                      float4* __restrict__ out, int N, int Ht, int Wt,
@@ -397,6 +410,23 @@ int jtsm_upsample2_add_f32(const float* top, const float* lateral, float* out, u
   hipLaunchKernelGGL(upsample2_add_fwd, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                      (const float4*)top, (const float4*)lateral, (float4*)out, out_hi, out_lo, N, H, W, C / 4);
   JTSM_CHECK_LAUNCH("upsample2_add");
+  return JTSM_OK;
+}
+
+int jtsm_sum_tensors_f32(const float* const* inputs, int n, long numel, float* out, uint16_t* out_hi, uint16_t* out_lo,
+                         void* stream) {
+  JTSM_REQUIRE(n >= 1 && n <= 4 && numel >= 0 && numel % 4 == 0, "sum_tensors: 1..4 inputs, numel %% 4 == 0");
+  if (numel == 0) return JTSM_OK;
+  JTSM_REQUIRE(inputs && out, "sum_tensors: null pointer");
+  JTSM_REQUIRE((out_hi == nullptr) == (out_lo == nullptr), "sum_tensors: give both planes or neither");
+  SumPtrs sp = {};
+  for (int k = 0; k < n; ++k) {
+    JTSM_REQUIRE(inputs[k] && ((uintptr_t)inputs[k] & 15) == 0, "sum_tensors: input %d null or not 16-byte aligned", k);
+    sp.p[k] = reinterpret_cast<const float4*>(inputs[k]);
+  }
+  hipLaunchKernelGGL(sum_tensors_kernel, dim3(grid_for(numel / 4)), dim3(256), 0, as_stream(stream), sp, n, numel / 4,
+                     (float4*)out, out_hi, out_lo);
+  JTSM_CHECK_LAUNCH("sum_tensors");
   return JTSM_OK;
 }
 

@@ -143,6 +143,45 @@ class _Upsample2Add(torch.autograd.Function):
         return gt, (g if ctx.needs_input_grad[1] else None)
 
 
+class _SumTensors(torch.autograd.Function):
+    """x0 + x1 + ... (list order) in one pass, with the bf16 planes of the sum; every input's gradient is the
+    incoming gradient itself."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        from . import conv
+        xs = [_cl4(x) for x in xs]
+        out = torch.empty_like(xs[0])
+        n = out.numel()
+        buf = hi = lo = None
+        if conv.MATH == "bf16x3" and out.shape[1] % 8 == 0 and n > 0:
+            buf = conv._planes_buf(n, out.device)
+            hi, lo = conv._hl(buf)
+        ptrs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+        L.check(L.lib().jtsm_sum_tensors_f32(ptrs, len(xs), C.c_long(n), L.ptr(out), hi, lo, L.stream()), "sum_tensors")
+        if buf is not None:
+            conv.planes_put(out, buf)
+        ctx.n = len(xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g,) * ctx.n
+
+
+def sum_tensors(xs):
+    """Sum of 1..4 same-shape channels_last maps (channels % 4 == 0), accumulated in list order."""
+    xs = list(xs)
+    if len(xs) == 1:
+        return xs[0]
+    if len(xs) > 4 or any(x.shape != xs[0].shape for x in xs) or xs[0].shape[1] % 4 or not xs[0].is_cuda:
+        out = xs[0]
+        for x in xs[1:]:
+            out = out + x
+        return out
+    return _SumTensors.apply(*xs)
+
+
 def upsample2_add(top, lateral):
     """lateral + F.interpolate(top, scale_factor=2, mode="nearest")."""
     return _Upsample2Add.apply(top, lateral)

@@ -78,11 +78,9 @@ class SemSegFPNHead(nn.Module):
         return _upsample_logits(x, self.common_stride), {}
 
     def layers(self, features):
-        x = None
-        for i, f in enumerate(self.in_features):
-            y = self.scale_heads[i](features[f])
-            x = y if x is None else x + y
-        return self.predictor(x)
+        from ...layers.elementwise import sum_tensors
+        # `x = x + y` over the levels, in level order, as one pass that also writes the predictor's operand planes
+        return self.predictor(sum_tensors([self.scale_heads[i](features[f]) for i, f in enumerate(self.in_features)]))
 
     def losses(self, predictions, targets):
         from ...layers.elementwise import semseg_cross_entropy
