@@ -94,3 +94,27 @@ def test_conv_planning_host_logic_handles_empty_and_odd_shapes():
     bad = ConvShape(1, 8, 8, 3, 8, 1, 1, 1, 0, 1)  # in_c not a multiple of 4
     assert lib.jtsm_conv_plan(C.byref(bad), 0, 0, None, None, None, None) != 0
     assert b"in_c" in lib.jtsm_last_error()
+
+
+def test_integration_doc_maps_every_declared_symbol():
+    """INTEGRATION.md's symbol <-> reference-interface table names every entry point include/jtsm_hip.h declares
+    (brace lists and trailing-* families expanded)."""
+    import re
+
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    have = set()
+    for m in re.findall(r"jtsm_[a-z0-9_{},*]+", integ):
+        parts = [m]
+        while any("{" in p for p in parts):
+            nxt = []
+            for p in parts:
+                mm = re.search(r"\{([^{}]*)\}", p)
+                if not mm:
+                    nxt.append(p)
+                    continue
+                nxt += [p[:mm.start()] + alt + p[mm.end():] for alt in mm.group(1).split(",")]
+            parts = nxt
+        have.update(parts)
+    missing = [n for n in _declared()
+               if n not in have and not any("*" in w and re.fullmatch(w.replace("*", ".*"), n) for w in have)]
+    assert not missing, missing
