@@ -246,20 +246,6 @@ struct MoiTiles {
   int tiles_x[kMaxLevels], tiles_y[kMaxLevels];
 };
 
-// ordered compaction of a per-thread flag over the 256 threads of the workgroup: returns this thread's slot (if
-// flagged) and the total; two barriers.
-__device__ __forceinline__ int compact256(bool flag, int* __restrict__ wave_count, int& total) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const unsigned long long bal = __ballot(flag);
-  __syncthreads();                       // previous readers of wave_count are done
-  if (lane == 0) wave_count[wv] = __popcll(bal);
-  __syncthreads();
-  int off = 0;
-  total = 0;
-  for (int w = 0; w < 4; ++w) { if (w < wv) off += wave_count[w]; total += wave_count[w]; }
-  return off + __popcll(bal & ((1ull << lane) - 1ull));
-}
-
 constexpr int kPairCap = 1024;
 
 // rois of one (level, image), in index order: lists[(l * B + b) * M ...], counts[l * B + b].  One workgroup each.
