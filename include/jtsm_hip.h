@@ -145,7 +145,8 @@ int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32
  * Backward: with `scales` (the forward's level scales), a workspace
  * (jtsm_moi_pool_backward_levels_workspace_bytes) and C a multiple of 256, every gradient map is produced by a
  * gather — one workgroup per 8x8-cell tile sums, in roi / bin order, the gradients of the bins whose argmax fell
- * into it (LDS accumulation, no atomics, bitwise reproducible, every cell written once); otherwise (scales or workspace NULL)
+ * into it (LDS accumulation, no atomics, bitwise reproducible, every cell written once) — unless a census of the
+ * roi boxes estimates more than 4000 (roi, bin) pairs on one tile (proposals piled on one spot), in which case, and otherwise (scales or workspace NULL)
  * each grad_inputs[l] is zero-filled and accumulated with float atomics. */
 size_t jtsm_moi_pool_levels_workspace_bytes(int B, const int* H, const int* W, int nlevels, int M, int L);
 int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, const int* W,
@@ -154,7 +155,7 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
                                      const int32_t* superpixels, float* output, int32_t* argmax,
                                      void* workspace, int B, int C, int M, int L, int Hs, int Ws,
                                      int pooled_h, int pooled_w, void* stream);
-size_t jtsm_moi_pool_backward_levels_workspace_bytes(int nlevels, int B, int M);
+size_t jtsm_moi_pool_backward_levels_workspace_bytes(const int* H, const int* W, int nlevels, int B, int M);
 int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                       const int32_t* argmax, float* const* grad_inputs, const int* H,
                                       const int* W, const float* scales, int nlevels, int B, int C, int M,

@@ -19,6 +19,7 @@
 // bin's cells one by one (coalesced word row + wave ballot), and for every surviving cell
 // gather their own channels (VEC floats per lane, 1 KiB per 256-channel row).  Scan order is
 // h outer / w inner with a strict '>' so ties and argmax are bit-identical to the reference.
+#include <algorithm>
 #include <cfloat>
 
 #include "common.h"
@@ -216,22 +217,24 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_levels(
 // grad_input[level(n)][b, argmax, c] += grad[n, bin, c]: a wavefront per (roi, bin).
 __global__ __launch_bounds__(256) void moi_pool_bwd_levels(
     const MoiLevels lv, const float* __restrict__ grad, const float* __restrict__ rois,
-    const int* __restrict__ argmax, int C, int M, int nbins, const int* __restrict__ roi_level, int nlevels) {
+    const int* __restrict__ argmax, int C, int M, int nbins, const int* __restrict__ roi_level, int nlevels,
+    const int* __restrict__ census_max, int census_limit) {
+  if (census_max && *census_max <= census_limit) return;   // the gather form took this call
   const int lane = threadIdx.x & 63;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wave >= (long)M * nbins) return;
-  const int n = (int)(wave / nbins);
-  const int l = roi_level[n];
-  if ((unsigned)l >= (unsigned)nlevels) return;
-  const int b = (int)rois[(size_t)n * 5];
-  float* __restrict__ g = lv.gin[l] + (size_t)b * lv.H[l] * lv.W[l] * C;
-  const float* __restrict__ src = grad + (size_t)wave * C;
-  const int* __restrict__ arg = argmax + (size_t)wave * C;
-  // one channel per lane: neighbouring channels mostly share their winning cell, so a wave-instruction's 64
-  // atomics land in a few contiguous 256-byte runs (the shape the L2 atomic units take at full rate)
-  for (int c = lane; c < C; c += 64) {
-    const int a = arg[c];
-    if (a != -1) atomicAdd(g + (size_t)a * C + c, src[c]);
+  for (long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wave < (long)M * nbins; wave += (long)gridDim.x * 4) {
+    const int n = (int)(wave / nbins);
+    const int l = roi_level[n];
+    if ((unsigned)l >= (unsigned)nlevels) continue;
+    const int b = (int)rois[(size_t)n * 5];
+    float* __restrict__ g = lv.gin[l] + (size_t)b * lv.H[l] * lv.W[l] * C;
+    const float* __restrict__ src = grad + (size_t)wave * C;
+    const int* __restrict__ arg = argmax + (size_t)wave * C;
+    // one channel per lane: neighbouring channels mostly share their winning cell, so a wave-instruction's 64
+    // atomics land in a few contiguous 256-byte runs (the shape the L2 atomic units take at full rate)
+    for (int c = lane; c < C; c += 64) {
+      const int a = arg[c];
+      if (a != -1) atomicAdd(g + (size_t)a * C + c, src[c]);
+    }
   }
 }
 
@@ -267,10 +270,51 @@ __global__ __launch_bounds__(256) void moi_roi_lists_kernel(const float* __restr
   if (threadIdx.x == 0) counts[blockIdx.x] = filled;
 }
 
+// How many (roi, bin) pairs each tile will have to walk (estimated from the box geometry): the gather handles a tile
+// in ONE workgroup, so a tile under very many overlapping rois (proposals piled on one object) would take longer than
+// the whole scatter form.  The census lets the call fall back: above kCensusLimit pairs on one tile the gather only
+// clears the maps and the float-atomic scatter (whose cost does not depend on where the rois are) does the work.
+constexpr int kCensusLimit = 4000;   // ~0.1-0.15 us per pair for the gather; the scatter form takes ~1 ms in all
+
+__global__ __launch_bounds__(256) void moi_tile_census_kernel(const MoiLevels lv, const MoiTiles tl,
+                                                              const float* __restrict__ rois,
+                                                              const int* __restrict__ roi_level, int M, int nlevels,
+                                                              int PH, int PW, int* __restrict__ census) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= M) return;
+  const int l = roi_level[n];
+  if ((unsigned)l >= (unsigned)nlevels) return;
+  const IBox r = round_box(rois + (size_t)n * 5, lv.scale[l]);
+  const int H = lv.H[l], W = lv.W[l];
+  const int xa = max(r.x0, 0), xz = min(r.x1, W - 1), ya = max(r.y0, 0), yz = min(r.y1, H - 1);
+  if (xa > xz || ya > yz) return;
+  const float bw = (float)max(r.x1 - r.x0 + 1, 1) / (float)PW, bh = (float)max(r.y1 - r.y0 + 1, 1) / (float)PH;
+  for (int ty = ya / kTile; ty <= yz / kTile; ++ty) {
+    const int oy = min(yz, ty * kTile + kTile - 1) - max(ya, ty * kTile) + 1;      // overlapped rows
+    const int by = min(PH, (int)((float)oy / bh) + 2);                            // bins touching them (upper bound)
+    for (int tx = xa / kTile; tx <= xz / kTile; ++tx) {
+      const int ox = min(xz, tx * kTile + kTile - 1) - max(xa, tx * kTile) + 1;
+      const int bx = min(PW, (int)((float)ox / bw) + 2);
+      atomicAdd(&census[tl.first[l] + (r.b * tl.tiles_y[l] + ty) * tl.tiles_x[l] + tx], by * bx);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void moi_census_max_kernel(const int* __restrict__ census, int total,
+                                                             int* __restrict__ out) {
+  __shared__ int part[4];
+  int m = 0;
+  for (int i = threadIdx.x; i < total; i += 256) m = max(m, census[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
 __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
     const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
-    const int* __restrict__ counts, int nlevels) {
+    const int* __restrict__ counts, int nlevels, const int* __restrict__ census_max) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 cells][256 channels]
   __shared__ int roi_list[256];
@@ -288,6 +332,12 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   const int c = blockIdx.y * 256 + t;
   const float scale = lv.scale[l];
   const int nbins = PH * PW;
+  if (*census_max > kCensusLimit) {   // too many rois on one tile somewhere: clear the map for the scatter form
+    float* __restrict__ z = lv.gin[l] + (size_t)b * H * W * C;
+    for (int y = y0; y <= y1; ++y)
+      for (int x = x0; x <= x1; ++x) z[((size_t)y * W + x) * C + c] = 0.f;
+    return;
+  }
   for (int i = t; i < kTile * kTile * 64; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int np = 0;   // uniform
 
@@ -638,9 +688,17 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
   return JTSM_OK;
 }
 
-size_t jtsm_moi_pool_backward_levels_workspace_bytes(int nlevels, int B, int M) {
-  if (nlevels <= 0 || B <= 0 || M <= 0) return 0;
-  return ((size_t)nlevels * B * ((size_t)M + 1) * sizeof(int) + 15) & ~(size_t)15;
+static long census_tiles(const int* H, const int* W, int nlevels, int B) {
+  long n = 0;
+  for (int l = 0; l < nlevels; ++l) n += (long)B * ceil_div(W[l], kTile) * ceil_div(H[l], kTile);
+  return n;
+}
+
+size_t jtsm_moi_pool_backward_levels_workspace_bytes(const int* H, const int* W, int nlevels, int B, int M) {
+  if (nlevels <= 0 || nlevels > kMaxLevels || B <= 0 || M <= 0 || !H || !W) return 0;
+  // per-(level, image) roi lists + counts, then the tile census + its maximum
+  return (((size_t)nlevels * B * ((size_t)M + 1) + (size_t)census_tiles(H, W, nlevels, B) + 4) * sizeof(int) + 15) &
+         ~(size_t)15;
 }
 
 int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
@@ -662,11 +720,14 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
   const bool tiled = scales && workspace && all && C % 256 == 0 && M > 0 && B > 0;
   if (tiled) {
     JTSM_REQUIRE(grad && rois && roi_level && argmax, "moi_pool levels backward: null pointer");
-    const size_t need = jtsm_moi_pool_backward_levels_workspace_bytes(nlevels, B, M);
+    const size_t need = jtsm_moi_pool_backward_levels_workspace_bytes(H, W, nlevels, B, M);
     JTSM_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 3) == 0,
                  "moi_pool levels backward: workspace of %zu bytes needed", need);
     int* lists = reinterpret_cast<int*>(workspace);
     int* counts = lists + (size_t)nlevels * B * M;
+    int* census = counts + (size_t)nlevels * B;
+    const int ntile = (int)census_tiles(H, W, nlevels, B);
+    int* census_max = census + ntile;
     hipLaunchKernelGGL(moi_roi_lists_kernel, dim3(nlevels * B), dim3(256), 0, st, rois, roi_level, M, B, lists, counts);
     MoiTiles tl = {};
     int blocks = 0;
@@ -677,8 +738,16 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
       blocks += B * tl.tiles_x[l] * tl.tiles_y[l];
     }
     tl.first[nlevels] = blocks;
+    JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
+    hipLaunchKernelGGL(moi_tile_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, lv, tl, rois, roi_level, M, nlevels,
+                       pooled_h, pooled_w, census);
+    hipLaunchKernelGGL(moi_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census_max);
     hipLaunchKernelGGL(moi_pool_bwd_tiled, dim3(blocks, C / 256), dim3(256), kTile * kTile * 256 * sizeof(float), st, lv, tl,
-                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels);
+                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, census_max);
+    // (returns at once unless the census sent the gather home)
+    hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(std::min(ceil_div((long)M * pooled_h * pooled_w, 4), 8192)), dim3(256), 0,
+                       st, lv, grad, rois, argmax, C, M, pooled_h * pooled_w, roi_level, nlevels, census_max,
+                       kCensusLimit);
     JTSM_CHECK_LAUNCH("moi_pool backward levels (tiled)");
     return JTSM_OK;
   }
@@ -691,8 +760,8 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
   for (int l = 0; l < nlevels; ++l)
     JTSM_REQUIRE(grad_inputs[l], "moi_pool levels backward: every level needs a gradient buffer");
   const int nbins = pooled_h * pooled_w;
-  hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(ceil_div((long)M * nbins, 4)), dim3(256), 0, st, lv, grad, rois, argmax,
-                     C, M, nbins, roi_level, nlevels);
+  hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(std::min(ceil_div((long)M * nbins, 4), 8192)), dim3(256), 0, st, lv, grad,
+                     rois, argmax, C, M, nbins, roi_level, nlevels, (const int*)nullptr, 0);
   JTSM_CHECK_LAUNCH("moi_pool backward levels");
   return JTSM_OK;
 }

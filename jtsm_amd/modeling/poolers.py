@@ -133,7 +133,7 @@ class _MOILevels(Function):
         ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads])
         sc = (C.c_float * nl)(*scales)
         lib = L.lib()
-        ws = torch.empty(max(lib.jtsm_moi_pool_backward_levels_workspace_bytes(nl, B, rois.shape[0]), 16),
+        ws = torch.empty(max(lib.jtsm_moi_pool_backward_levels_workspace_bytes(Hs, Ws, nl, B, rois.shape[0]), 16),
                          dtype=torch.uint8, device=g.device)
         L.check(lib.jtsm_moi_pool_backward_levels_f32(
             L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,

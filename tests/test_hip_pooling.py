@@ -358,3 +358,37 @@ def test_multilevel_moi_pool_backward_gather_matches_oracle_and_scatter(cuda):
     y2.backward(gd)
     for a, b in zip(xs, xs2):
         assert torch.equal(a.grad, b.grad)
+
+
+def test_multilevel_moi_pool_backward_falls_back_when_rois_pile_up(cuda):
+    """More than 4000 (roi, bin) pairs on one 8x8-cell tile (1300 small rois on one spot): the gather only clears the maps and the float-atomic scatter does
+    the work (csrc/moi_pool.hip: census).  Same gradients as the oracle either way."""
+    from jtsm_amd.modeling.poolers import ROIPooler
+    from jtsm_amd.structures import Boxes
+    from oracle import model as OM
+
+    rng = np.random.default_rng(43)
+    B, Cc, size, sp = 1, 256, 128, 8
+    M = 1300
+    x0 = rng.uniform(40, 44, M).astype(np.float32)
+    y0 = rng.uniform(40, 44, M).astype(np.float32)
+    wh = rng.uniform(17, 30, (M, 2)).astype(np.float32)
+    boxes = [torch.from_numpy(np.stack([x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], 1))]
+    grid = size // sp
+    ids = (torch.arange(size)[:, None] // sp) * grid + (torch.arange(size)[None, :] // sp)
+    superpixels = ids.to(torch.int32)[None]
+    oh = [torch.ones(M, grid * grid, dtype=torch.int32)]
+    feats = [rng.standard_normal((B, Cc, (size // 4) >> i, (size // 4) >> i)).astype(np.float32) for i in range(4)]
+    pooler = ROIPooler(7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 0, "MOIPool")
+    xs = [dev(f, cuda, True).requires_grad_() for f in feats]
+    y, arg = pooler(xs, [Boxes(boxes[0].to(cuda))], oh_labels_list=[oh[0].to(cuda)], superpixels=superpixels.to(cuda))
+    g = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(dev(g, cuda, True))
+    fr = [torch.from_numpy(f).requires_grad_() for f in feats]
+    y0_, a0 = OM.moi_pool_levels(fr, boxes, oh, superpixels)
+    y0_.backward(torch.from_numpy(g))
+    assert np.array_equal(arg.cpu().numpy(), a0.numpy())
+    for a, b in zip(xs, fr):
+        ref = b.grad.numpy()
+        assert np.allclose(a.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
+    assert float(xs[0].grad.abs().sum()) > 0
