@@ -793,7 +793,7 @@ __global__ __launch_bounds__(256, NBUF == 1 ? 4 : 2) void igemm_dma_kernel(const
 // Which kernel?  The direct-to-LDS kernel (64-80 KiB LDS, 2 workgroups per CU, deep prefetch) wins when a
 // workgroup sweeps many K tiles; short sweeps (split-K slices, 1x1 convolutions with few channels) are
 // dominated by prologue/epilogue latency and do better with the register-staged kernel's 3 workgroups
-// per CU.  Measured on MI355X (scratch/bench_conv.py): crossover around 24 K tiles per workgroup.
+// per CU.  Measured on MI355X (tools/sweeps/bench_conv.py): crossover around 24 K tiles per workgroup.
 constexpr int kDmaMinKTiles = 24;
 constexpr int kWgradTargetBlocks = 1024;  // WGRAD pixel-axis split: workgroups aimed at (atomic traffic grows with it)
 constexpr bool kShortSweepDma = true;   // short sweeps: single-buffered DMA kernel instead of the register-staged one
@@ -1224,7 +1224,7 @@ static bool x3_wgrad_big(const Params& p) {
   if (p.M < 256 || p.N < 256) return false;
   constexpr long min_work = 2000;
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
-  return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, scratch/wgrad_sweep.py)
+  return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, tools/sweeps/wgrad_sweep.py)
 }
 
 // The LDS-halo weight gradient: 3x3, stride 1, undilated, 32-channel input blocks, output rows of whole 32-pixel
@@ -1249,7 +1249,7 @@ static int x3_wgrad_splits(const Params& p) {
   const int t = big ? 256 : 128;
   const int ntiles = ceil_div(p.N, t) * ceil_div(p.M, t);
   const int ktiles = ceil_div(p.K, XBK);
-  // Pixel-axis split (measured on MI355X, scratch/wsplit.py): the kernels are bound by memory latency x bytes in
+  // Pixel-axis split (measured on MI355X, tools/sweeps/wsplit.py): the kernels are bound by memory latency x bytes in
   // flight, so two workgroups per CU (512) beat one as long as each keeps >= 8 stages; 256 x 256 tiles hold one
   // workgroup per CU.
   int splits = ceil_div(big ? 256 : 512, ntiles);

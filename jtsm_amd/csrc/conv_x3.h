@@ -940,7 +940,7 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
   const int ntiles = ceil_div(p.N, BN) * ceil_div(p.M, BM);
   const int ktiles = ceil_div(p.K, XBK);
-  // aim at one full round of resident workgroups (measured: scratch/x3_sweep.py)
+  // aim at one full round of resident workgroups (measured: tools/sweeps/x3_sweep.py)
   int splits = plan_splits(ntiles, ktiles, round_blocks);
   if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
   if (splits > 1) {
@@ -971,7 +971,7 @@ inline int x3_tile_choice(const Params& p) {
   // 256x256 pays once its (fewer, larger) workgroups still fill the chip and K is deep enough to amortise them
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
   const int ktiles = ceil_div(p.K, XBK);
-  constexpr long min_work = 9216;   // tiles x stages (measured crossover, scratch/x3_sweep.py + layer timings)
+  constexpr long min_work = 9216;   // tiles x stages (measured crossover, tools/sweeps/x3_sweep.py + layer timings)
   if (p.N >= 192 && t256 * ktiles >= min_work && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
   return 0;
 }
@@ -990,7 +990,7 @@ inline bool x3_halo_ok(int role, const Params& p) {
   const int c = role == FWD ? s.Cin : s.Cout;
   const int OH = role == FWD ? s.Ho : s.H, OW = role == FWD ? s.Wo : s.W;
   // maps below 32 x 32 waste too much of the 8 x 16 patches; layers large enough for 256 x 256 tiles stay there
-  // (measured equal or better, scratch/x3_sweep.py)
+  // (measured equal or better, tools/sweeps/x3_sweep.py)
   return !p.scatter && s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && c % XBK == 0 && p.N > 64 &&
          OH >= 32 && OW >= 32;
 }
