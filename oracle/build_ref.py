@@ -21,6 +21,7 @@ def build(verbose=False):
     srcs = [
         os.path.join(csrc, "ROIAlign", "ROIAlign_cpu.cpp"),
         os.path.join(csrc, "ROIAlignRotated", "ROIAlignRotated_cpu.cpp"),
+        os.path.join(csrc, "nms_rotated", "nms_rotated_cpu.cpp"),   # the reference's greedy NMS loop (angle 0 = plain boxes)
     ]
     if not all(os.path.isfile(s) for s in srcs):
         return None

@@ -11,6 +11,11 @@ Sources of truth
   * kat_reference_tests.npz: the known-answer tables the reference's tests hold
     (tests/layers/test_roi_align.py:22-45, tests/layers/test_roi_align_rotated.py:30-71,
     gradient ROI set :107-125).
+  * nms_ref.npz: keep lists of the REFERENCE's own greedy NMS loop (detectron2/layers/csrc/nms_rotated/
+    nms_rotated_cpu.cpp — "modified from torchvision's nms_cpu_kernel", its comment says — compiled by
+    oracle/build_ref.py) on axis-aligned boxes passed as (cx, cy, w, h, 0).  Its IoU comes from polygon clipping and
+    its test is `>=`, so every case is generated with all pairwise IoUs at least 1e-3 away from the threshold: there
+    the keep list depends only on the greedy visiting order and the suppress rule, which is what it pins.
   * moi_pool_oracle.npz: MOIPool has no runnable reference -> vectors come from
     our restatement (oracle/c/pool_ops.inc); "parity unpinned", they pin regressions only.
 """
@@ -126,6 +131,32 @@ def main():
         cases[name] = dict(x=x, rois=r, oh=oh, sp=sp, y=y, argmax=a, g=g, gx=gx,
                            meta=np.array([1.0 / stride, PH, PW], np.float64))
     np.savez_compressed(os.path.join(HERE, "moi_pool_oracle.npz"),
+                        **{"%s__%s" % (k, f): v for k, d in cases.items() for f, v in d.items()})
+    # ---- greedy NMS: the reference's own loop on angle-0 boxes -------------------------------------
+    cases = {}
+    for name, (n, size, thr) in {"n200_t03": (200, 120.0, 0.3), "n400_t05": (400, 200.0, 0.5),
+                                 "n300_t07": (300, 150.0, 0.7), "n64_t05": (64, 40.0, 0.5)}.items():
+        for attempt in range(200):
+            xy = rng.uniform(0, size * 0.8, (n, 2))
+            wh = rng.uniform(2.0, size * 0.3, (n, 2))
+            b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+            sc = rng.permutation(n).astype(np.float32) / n          # distinct scores: no ordering ambiguity
+            bd = b.astype(np.float64)
+            iw = np.clip(np.minimum(bd[:, None, 2], bd[None, :, 2]) - np.maximum(bd[:, None, 0], bd[None, :, 0]), 0, None)
+            ih = np.clip(np.minimum(bd[:, None, 3], bd[None, :, 3]) - np.maximum(bd[:, None, 1], bd[None, :, 1]), 0, None)
+            inter = iw * ih
+            area = (bd[:, 2] - bd[:, 0]) * (bd[:, 3] - bd[:, 1])
+            iou = inter / (area[:, None] + area[None, :] - inter)
+            np.fill_diagonal(iou, 0.0)
+            if np.abs(iou - thr).min() > 1e-3:
+                break
+        else:
+            raise RuntimeError("no NMS case away from the threshold found")
+        rb = np.stack([(b[:, 0] + b[:, 2]) / 2, (b[:, 1] + b[:, 3]) / 2, b[:, 2] - b[:, 0], b[:, 3] - b[:, 1],
+                       np.zeros(n, np.float32)], 1).astype(np.float32)
+        keep = ref.nms_rotated(T(rb), T(sc), float(thr)).numpy()
+        cases[name] = dict(boxes=b, scores=sc, keep=keep.astype(np.int64), thr=np.array([thr], np.float64))
+    np.savez_compressed(os.path.join(HERE, "nms_ref.npz"),
                         **{"%s__%s" % (k, f): v for k, d in cases.items() for f, v in d.items()})
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

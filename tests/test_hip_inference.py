@@ -44,6 +44,17 @@ def test_batched_nms_matches_oracle(cuda, n, classes, thr):
     assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
 
 
+def test_batched_nms_matches_reference_fixture(cuda):
+    """tests/golden/nms_ref.npz: keep lists of the reference's own compiled greedy NMS loop (see
+    tests/test_oracle_inference.py) — the HIP path directly against the reference run."""
+    from conftest import load_cases
+
+    for name, c in load_cases("nms_ref.npz").items():
+        b, sc = torch.from_numpy(c["boxes"]).cuda(), torch.from_numpy(c["scores"]).cuda()
+        got = batched_nms(b, sc, torch.zeros(len(b), dtype=torch.int64, device="cuda"), float(c["thr"][0]))
+        assert got.cpu().tolist() == c["keep"].tolist(), name
+
+
 def test_batched_nms_equal_scores_and_duplicates(cuda):
     g = torch.Generator().manual_seed(5)
     boxes = _random_boxes(300, 100, g)

@@ -102,3 +102,20 @@ def test_predict_K_is_mean_of_heads():
     assert boxes.shape == (6, 12)
     zero = OI.predict_K(zs, [torch.zeros(6, 12)] * 2, prop)[1]
     assert torch.allclose(zero, prop.repeat(1, 3), atol=1e-4)
+
+
+def test_nms_matches_the_reference_greedy_loop():
+    """tests/golden/nms_ref.npz: keep lists produced by the REFERENCE's own compiled greedy NMS
+    (detectron2/layers/csrc/nms_rotated/nms_rotated_cpu.cpp, "modified from torchvision's nms_cpu_kernel") on
+    axis-aligned boxes, every pairwise IoU at least 1e-3 away from the threshold — pins the oracle's visiting order
+    and suppress rule to the reference run (generator: tests/golden/make_golden.py)."""
+    from conftest import load_cases
+
+    cases = load_cases("nms_ref.npz")
+    assert len(cases) == 4
+    for name, c in cases.items():
+        keep = OI.nms(torch.from_numpy(c["boxes"]), torch.from_numpy(c["scores"]), float(c["thr"][0]))
+        assert keep.tolist() == c["keep"].tolist(), name
+        one_class = OI.batched_nms(torch.from_numpy(c["boxes"]), torch.from_numpy(c["scores"]),
+                                   torch.zeros(len(c["boxes"]), dtype=torch.int64), float(c["thr"][0]))
+        assert one_class.tolist() == c["keep"].tolist(), name
