@@ -17,10 +17,15 @@ What each function follows (paths relative to the reference tree):
   combine_semantic_and_instance_outputs        detectron2/modeling/meta_arch/panoptic_fpn.py:133-218
   forward_inference           projects/WSL/wsl/modeling/meta_arch/mcnn.py:236-365; roi_heads_jtsm.py:553-561,738-752
 
-Parity pins: the reference's own tests for this row need torchvision / pycocotools / COCO files
-(tests/layers/test_nms.py, test_mask_ops.py) and hold no golden vectors: **parity unpinned** for NMS ordering under
-equal scores (resolved here and in the product as "lower index first"; the reference's sort is unstable there).
-grid_sample / interpolate / softmax are the literal torch operators the reference calls.
+Parity pins: the greedy NMS loop is pinned to a REFERENCE RUN — tests/golden/nms_ref.npz holds keep lists of the
+reference's own compiled detectron2/layers/csrc/nms_rotated/nms_rotated_cpu.cpp ("modified from torchvision's
+nms_cpu_kernel") on angle-0 boxes whose pairwise IoUs all stay >= 1e-3 away from the threshold (generator:
+tests/golden/make_golden.py through oracle/build_ref.py).  The reference's Python tests for this row need
+torchvision / pycocotools / COCO files (tests/layers/test_nms.py, test_mask_ops.py) and hold no golden vectors:
+**parity unpinned** for the ordering under equal scores (resolved here and in the product as "lower index first"; the
+reference's sort is unstable there), for the coordinate-offset arithmetic of torchvision's batched_nms (restated from
+its published source) and for the panoptic merge (hand-worked example).  grid_sample / interpolate / softmax are the
+literal torch operators the reference calls.
 """
 import numpy as np
 import torch
