@@ -19,6 +19,8 @@
 // Backward: same decomposition, scatter with float atomics (global_atomic_add_f32 /
 // _f64); in NHWC each wave instruction adds 256 contiguous bytes, the shape the memory-side
 // atomic units run at full rate on (MI355X_MICROARCH.md "Global float atomics").
+#include <type_traits>
+
 #include "common.h"
 #include "roi_geometry.h"
 
@@ -126,8 +128,10 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
                                                       T* __restrict__ gin, int C, int H, int W,
                                                       int M, T scale, int PH, int PW, int sr,
                                                       int aligned,
-                                                      const int* __restrict__ roi_level, int level) {
+                                                      const int* __restrict__ roi_level, int level,
+                                                      const int* __restrict__ census_max, int census_limit) {
 #pragma clang fp contract(off)
+  if (census_max && *census_max <= census_limit) return;   // the gather form (align_bwd_tiled) took this call
   const int lane = threadIdx.x & 63;
   const int nbins = PH * PW;
   const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -177,6 +181,205 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
         }
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------- NHWC backward as a gather
+// A workgroup owns an 8 x 8-cell tile of the gradient map x 64 channels, lists — from the roi geometry alone, in
+// (roi, bin) order — the bins whose bilinear taps can reach the tile, and adds their contributions in LDS.  The bin's
+// samples form a gh x gw grid and a sample's four weights are (hy | ly) x (hx | lx), so the sum over the grid
+// factorises into eight row weights times eight column weights of the tile (make_tap's clamping and out-of-range
+// rules, roi_geometry.h, are per axis too).  The four wavefronts take the listed bins round-robin, each into its OWN
+// 64-cell x 64-channel accumulator (lane = channel), and the four are summed in a fixed order at the end: no
+// atomics, reproducible bit for bit, every map cell written exactly once (no zero fill).  2-5x faster than the scatter
+// form above on spread-out rois; a tile under a pile of rois is walked by one workgroup, so a census of the boxes
+// (estimated bins per tile) sends such calls to the scatter form instead (as csrc/moi_pool.hip does).
+constexpr int kTile = 8, kPairCap = 1024;
+constexpr int kCensusLimit = 2000;   // bins on one tile: ~0.1 us each for the gather's four wavefronts
+
+__global__ __launch_bounds__(256) void align_census_kernel(const float* __restrict__ rois, int M, float scale, int PH,
+                                                           int PW, int sr, int aligned, int H, int W,
+                                                           const int* __restrict__ roi_level, int level, int tiles_x,
+                                                           int tiles_y, int* __restrict__ census) {
+#pragma clang fp contract(off)
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= M || (roi_level && roi_level[n] != level)) return;
+  const RoiGeom<float> g = geom_box<float>(rois + (size_t)n * 5, scale, PH, PW, sr, aligned != 0);
+  if (g.gh <= 0 || g.gw <= 0) return;
+  const int xa = max((int)floorf(g.x0), 0), xz = min((int)floorf(g.x0 + (float)PW * g.bw) + 1, W - 1);
+  const int ya = max((int)floorf(g.y0), 0), yz = min((int)floorf(g.y0 + (float)PH * g.bh) + 1, H - 1);
+  if (xa > xz || ya > yz) return;
+  for (int ty = ya / kTile; ty <= yz / kTile; ++ty) {
+    const int oy = min(yz, ty * kTile + kTile - 1) - max(ya, ty * kTile) + 1;
+    const int by = min(PH, (int)((float)oy / fmaxf(g.bh, 1e-6f)) + 2);
+    for (int tx = xa / kTile; tx <= xz / kTile; ++tx) {
+      const int ox = min(xz, tx * kTile + kTile - 1) - max(xa, tx * kTile) + 1;
+      const int bx = min(PW, (int)((float)ox / fmaxf(g.bw, 1e-6f)) + 2);
+      atomicAdd(&census[(g.b * tiles_y + ty) * tiles_x + tx], by * bx);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void align_census_max_kernel(const int* __restrict__ census, int total,
+                                                               int* __restrict__ out) {
+  __shared__ int part[4];
+  int m = 0;
+  for (int i = threadIdx.x; i < total; i += 256) m = max(m, census[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = max(max(part[0], part[1]), max(part[2], part[3]));
+}
+
+__global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__ grad, const float* __restrict__ rois,
+                                                       float* __restrict__ gin, int C, int H, int W, int M, float scale,
+                                                       int PH, int PW, int sr, int aligned,
+                                                       const int* __restrict__ roi_level, int level, int tiles_x,
+                                                       int tiles_y, const int* __restrict__ census_max) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [4 wavefronts][64 cells][64 channels]
+  __shared__ int roi_list[256];
+  __shared__ float roi_row[256][5];     // the listed rois' rows: the walk must not wait on global memory
+  __shared__ int pair_list[kPairCap];   // slot in roi_list * nbins + bin
+  __shared__ int wave_count[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  int rel = blockIdx.x;
+  const int tx = rel % tiles_x; rel /= tiles_x;
+  const int ty = rel % tiles_y;
+  const int b = rel / tiles_y;
+  const int x0 = tx * kTile, y0 = ty * kTile, x1 = min(x0 + kTile, W) - 1, y1 = min(y0 + kTile, H) - 1;
+  const int c = blockIdx.y * 64 + lane;
+  const int nbins = PH * PW;
+  float* __restrict__ out = gin + (size_t)b * H * W * C;
+  if (*census_max > kCensusLimit) {   // piled-up rois somewhere: clear the map, the scatter form does the work
+    for (int cell = wv; cell < kTile * kTile; cell += 4) {
+      const int y = y0 + cell / kTile, x = x0 + cell % kTile;
+      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
+    }
+    return;
+  }
+  float* __restrict__ mine = acc + wv * (kTile * kTile * 64);
+  int np = 0;            // uniform
+  bool dirty = false;    // uniform: the accumulators are cleared when a first bin arrives (most tiles see none)
+
+  // cells a sample coordinate range [lo, hi] can touch: floor(lo) .. floor(hi) + 1, after the clamp to the map
+  auto reach = [](float lo, float hi, int n, int& a, int& z) {
+    a = max((int)floorf(lo), 0);
+    z = min((int)floorf(hi) + 1, n - 1);
+  };
+
+  constexpr int kDepth = 8;
+  auto drain = [&]() {
+    if (np == 0) return;
+    if (!dirty) {
+      for (int i = t; i < kTile * kTile * 64; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dirty = true;
+    }
+    __syncthreads();
+    for (int j0 = wv; j0 < np; j0 += 4 * kDepth) {   // wavefront wv: listed bins wv, wv + 4, ...
+      float gos[kDepth];                             // kDepth gradients in flight before any is used
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        gos[u] = 0.f;
+        if (j0 + 4 * u < np) {
+          const int e = pair_list[j0 + 4 * u], i = e / nbins;
+          gos[u] = grad[((size_t)roi_list[i] * nbins + (e - i * nbins)) * C + c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kDepth; ++u) {
+        if (j0 + 4 * u >= np) break;
+        const int e = pair_list[j0 + 4 * u];
+        const int i = e / nbins, bin = e - i * nbins;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const RoiGeom<float> g = geom_box<float>(roi_row[i], scale, PH, PW, sr, aligned != 0);
+        float wy[kTile], wx[kTile];
+#pragma unroll
+        for (int r = 0; r < kTile; ++r) wy[r] = wx[r] = 0.f;
+        for (int iy = 0; iy < g.gh; ++iy) {
+          float y = g.y0 + (float)ph * g.bh + (float)((float)iy + .5f) * g.bh / (float)g.gh;
+          if (y < -1.0f || y > (float)H) continue;
+          if (y <= 0.f) y = 0.f;
+          int yl = (int)y, yh;
+          if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
+          const float ly = y - (float)yl, hy = 1.f - ly;
+#pragma unroll
+          for (int r = 0; r < kTile; ++r) wy[r] += (yl == y0 + r ? hy : 0.f) + (yh == y0 + r ? ly : 0.f);
+        }
+        for (int ix = 0; ix < g.gw; ++ix) {
+          float x = g.x0 + (float)pw * g.bw + (float)((float)ix + .5f) * g.bw / (float)g.gw;
+          if (x < -1.0f || x > (float)W) continue;
+          if (x <= 0.f) x = 0.f;
+          int xl = (int)x, xh;
+          if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
+          const float lx = x - (float)xl, hx = 1.f - lx;
+#pragma unroll
+          for (int r = 0; r < kTile; ++r) wx[r] += (xl == x0 + r ? hx : 0.f) + (xh == x0 + r ? lx : 0.f);
+        }
+        const float gs = gos[u] / (float)(g.gh * g.gw);
+#pragma unroll
+        for (int r = 0; r < kTile; ++r) {
+          if (wy[r] == 0.f) continue;
+          const float gr = gs * wy[r];
+#pragma unroll
+          for (int q = 0; q < kTile; ++q)
+            if (wx[q] != 0.f) mine[(r * kTile + q) * 64 + lane] += gr * wx[q];
+        }
+      }
+    }
+    np = 0;
+  };
+
+  for (int base = 0; base < M; base += 256) {
+    const int n = base + t;
+    bool hit = false;
+    if (n < M && (!roi_level || roi_level[n] == level)) {
+      const RoiGeom<float> g = geom_box<float>(rois + (size_t)n * 5, scale, PH, PW, sr, aligned != 0);
+      if (g.b == b && g.gh > 0 && g.gw > 0) {
+        int ya, yz, xa, xz;
+        reach(g.y0, g.y0 + (float)PH * g.bh, H, ya, yz);
+        reach(g.x0, g.x0 + (float)PW * g.bw, W, xa, xz);
+        hit = ya <= y1 && yz >= y0 && xa <= x1 && xz >= x0;
+      }
+    }
+    int nroi;
+    const int slot = compact256(hit, wave_count, nroi);
+    if (hit) {
+      roi_list[slot] = n;
+#pragma unroll
+      for (int q = 0; q < 5; ++q) roi_row[slot][q] = rois[(size_t)n * 5 + q];
+    }
+    __syncthreads();
+    const int ncombo = nroi * nbins;
+    for (int k0 = 0; k0 < ncombo; k0 += 256) {
+      if (np > kPairCap - 256) drain();
+      const int k = k0 + t;
+      bool bh = false;
+      if (k < ncombo) {
+        const int i = k / nbins, bin = k - i * nbins;
+        const int ph = bin / PW, pw = bin - ph * PW;
+        const RoiGeom<float> g = geom_box<float>(roi_row[i], scale, PH, PW, sr, aligned != 0);
+        int ya, yz, xa, xz;
+        reach(g.y0 + (float)ph * g.bh, g.y0 + (float)(ph + 1) * g.bh, H, ya, yz);
+        reach(g.x0 + (float)pw * g.bw, g.x0 + (float)(pw + 1) * g.bw, W, xa, xz);
+        bh = ya <= y1 && yz >= y0 && xa <= x1 && xz >= x0;
+      }
+      int cnt;
+      const int ps = compact256(bh, wave_count, cnt);
+      if (bh) pair_list[np + ps] = k;   // slot * nbins + bin
+      np += cnt;
+    }
+    drain();                            // before the next chunk overwrites roi_list / roi_row
+    __syncthreads();
+  }
+  __syncthreads();
+  // sum the four wavefronts' accumulators in a fixed order; wavefront wv writes cells wv, wv + 4, ...
+  constexpr int SLAB = kTile * kTile * 64;
+  for (int cell = wv; cell < kTile * kTile; cell += 4) {
+    const int y = y0 + cell / kTile, x = x0 + cell % kTile;
+    if (y > y1 || x > x1) continue;
+    const int o = cell * 64 + lane;
+    out[((size_t)y * W + x) * C + c] = dirty ? ((acc[o] + acc[SLAB + o]) + acc[2 * SLAB + o]) + acc[3 * SLAB + o] : 0.f;
   }
 }
 
@@ -311,6 +514,35 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
   const size_t in_elems = (size_t)B * C * H * W;
   if (in_elems == 0) return JTSM_OK;
   JTSM_REQUIRE(gin, "roi_align backward: null grad_input");
+  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && M > 0 && grad && rois &&
+      (long)M * PH * PW < (1L << 30)) {
+    // gather form with the census guard: both forms are launched, the device-side census lets one of them return
+    const int tiles_x = ceil_div(W, kTile), tiles_y = ceil_div(H, kTile), ntile = B * tiles_x * tiles_y;
+    int* census = nullptr;
+    JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), (size_t)(ntile + 1) * sizeof(int), st));
+    JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
+    const float* g32 = reinterpret_cast<const float*>(grad);
+    const float* r32 = reinterpret_cast<const float*>(rois);
+    hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, r32, M, (float)scale, PH, PW, sr,
+                       aligned, H, W, roi_level, level, tiles_x, tiles_y, census);
+    hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
+    hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 4 * kTile * kTile * 64 * sizeof(float), st, g32,
+                       r32, reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
+                       tiles_x, tiles_y, census + ntile);
+    constexpr int V = WideVec<float>::value;
+    const int blocks = ceil_div((long)M * PH * PW, 4);
+    if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
+      hipLaunchKernelGGL((align_bwd_nhwc<float, V, false>), dim3(blocks), dim3(256), 0, st, g32, r32,
+                         reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
+                         census + ntile, kCensusLimit);
+    else
+      hipLaunchKernelGGL((align_bwd_nhwc<float, 1, false>), dim3(blocks), dim3(256), 0, st, g32, r32,
+                         reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
+                         census + ntile, kCensusLimit);
+    JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
+    JTSM_CHECK_HIP(hipFreeAsync(census, st));
+    return JTSM_OK;
+  }
   JTSM_CHECK_HIP(hipMemsetAsync(gin, 0, in_elems * sizeof(T), st));
   if ((long)M * C * PH * PW == 0) return JTSM_OK;  // empty gradient: zeros (ROIAlign_cuda.cu:402-405)
   JTSM_REQUIRE(grad && rois, "roi_align backward: null pointer");
@@ -320,10 +552,10 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
     constexpr int V = WideVec<T>::value;
     if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(T))) == 0)
       hipLaunchKernelGGL((align_bwd_nhwc<T, V, ROT>), dim3(blocks), dim3(256), 0, st, grad, rois,
-                         gin, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level);
+                         gin, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level, (const int*)nullptr, 0);
     else
       hipLaunchKernelGGL((align_bwd_nhwc<T, 1, ROT>), dim3(blocks), dim3(256), 0, st, grad, rois,
-                         gin, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level);
+                         gin, C, H, W, M, scale, PH, PW, sr, aligned, roi_level, level, (const int*)nullptr, 0);
   } else {
     JTSM_REQUIRE(!roi_level, "roi_align: per-level filtering needs the NHWC layout");
     const long total = (long)M * C * PH * PW;

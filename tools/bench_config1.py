@@ -93,14 +93,24 @@ def main():
 
         t_fb = timed(bwd, args.steps, args.warmup)
         out_bytes = M * C * res * res * 4
-        # sampled bytes: every bin reads ceil(roi/res)^2 samples x 4 taps x C x 4 B (upper bound of the reads)
-        sampled = 0
-        for bx in boxes:
+        # unique feature bytes: cells of each level under at least one of ITS rois (box grown by one cell for the
+        # bilinear neighbours), x C x 4 — §8d's min(unique, sampled) is this for every case here
+        from jtsm_amd.modeling.poolers import assign_boxes_to_levels
+        lv = assign_boxes_to_levels(boxes, 2, 5, 224, 4).cpu()
+        unique_cells, off = 0, 0
+        for bi, bx in enumerate(boxes):
             b = bx.tensor.cpu()
-            gw = torch.ceil((b[:, 2] - b[:, 0]) / res).clamp(min=1)     # in image pixels; the level scale cancels in
-            gh = torch.ceil((b[:, 3] - b[:, 1]) / res).clamp(min=1)     # the count only roughly — upper bound
-            sampled += int((res * res * gw * gh).sum().item()) * 4 * C * 4
-        fb = out_bytes + min(feat_bytes, sampled)
+            for l, f in enumerate(levels):
+                Hl, Wl = f.shape[2], f.shape[3]
+                sc = Hl / float(S)
+                cover = torch.zeros(Hl, Wl, dtype=torch.bool)
+                for r in b[lv[off:off + len(b)] == l]:
+                    x0, y0 = max(int(r[0] * sc) - 1, 0), max(int(r[1] * sc) - 1, 0)
+                    x1, y1 = min(int(r[2] * sc) + 2, Wl), min(int(r[3] * sc) + 2, Hl)
+                    cover[y0:y1, x0:x1] = True
+                unique_cells += int(cover.sum())
+            off += len(b)
+        fb = out_bytes + unique_cells * C * 4
         bb = out_bytes + feat_bytes
         ops["roi_align_%dx%d" % (res, res)] = {
             "forward_us": round(t_f * 1e6, 1), "forward_GB_per_s": round(fb / t_f / 1e9, 1),
