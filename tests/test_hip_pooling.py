@@ -392,3 +392,32 @@ def test_multilevel_moi_pool_backward_falls_back_when_rois_pile_up(cuda):
         ref = b.grad.numpy()
         assert np.allclose(a.grad.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max())))
     assert float(xs[0].grad.abs().sum()) > 0
+
+
+def test_roi_align_backward_gather_reproducible_and_fallback(cuda):
+    """NHWC float32 backward with a 64-multiple channel count runs as a tiled gather (csrc/roi_align.hip:
+    align_bwd_tiled): bitwise reproducible, equal to the oracle within rounding; with a pile of rois on one tile the
+    census sends the call to the float-atomic scatter — same gradients either way."""
+    rng = np.random.default_rng(7)
+    B, Cc, H, W = 2, 64, 64, 64
+    x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
+    # (1) spread-out rois, legacy and aligned sampling, fixed and adaptive grids
+    r = _fpn_like_rois(rng, 96, B, 512)
+    for aligned, sr in ((True, 0), (False, 0), (True, 2)):
+        g = rng.standard_normal((96, Cc, 7, 7)).astype(np.float32)
+        _, gx = run_align(x, r, 0.125, 7, 7, sr, aligned, cuda, True, g=g)
+        _, gx2 = run_align(x, r, 0.125, 7, 7, sr, aligned, cuda, True, g=g)
+        assert np.array_equal(gx, gx2)
+        gx0 = P.roi_align_backward(g, r, 0.125, 7, 7, B, Cc, H, W, sr, aligned)
+        assert np.allclose(gx, gx0, rtol=1e-4, atol=1e-4), np.abs(gx - gx0).max()
+    # (2) 600 small rois on one spot: > 2000 estimated bins on a tile -> scatter form
+    M = 600
+    x0 = rng.uniform(200, 204, M).astype(np.float32)
+    y0 = rng.uniform(100, 104, M).astype(np.float32)
+    wh = rng.uniform(20, 40, (M, 2)).astype(np.float32)
+    r2 = np.stack([np.zeros(M, np.float32), x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], 1)
+    g = rng.standard_normal((M, Cc, 7, 7)).astype(np.float32)
+    _, gx = run_align(x, r2, 0.125, 7, 7, 0, True, cuda, True, g=g)
+    gx0 = P.roi_align_backward(g, r2, 0.125, 7, 7, B, Cc, H, W, 0, True)
+    assert np.allclose(gx, gx0, rtol=1e-4, atol=1e-3 * max(1.0, float(np.abs(gx0).max()) / 10)), np.abs(gx - gx0).max()
+    assert float(np.abs(gx[1]).max()) == 0.0            # nothing lands in the other image
