@@ -1230,9 +1230,8 @@ static bool x3_wgrad_big(const Params& p) {
 // The LDS-halo weight gradient: 3x3, stride 1, undilated, 32-channel input blocks, output rows of whole 32-pixel
 // segments, and enough pixels to feed the split.
 static bool x3_wgrad_halo(const Params& p) {
-  static const bool on = !(getenv("JTSM_X3_WGRAD_HALO") && atoi(getenv("JTSM_X3_WGRAD_HALO")) == 0);
   const ConvShape& s = p.s;
-  return on && s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && s.Cin % 32 == 0 && s.Wo % 32 == 0 &&
+  return s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && s.Cin % 32 == 0 && s.Wo % 32 == 0 &&
          s.Cout % 8 == 0 && p.K >= 2048;
 }
 
