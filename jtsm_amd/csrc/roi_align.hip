@@ -514,8 +514,10 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
   const size_t in_elems = (size_t)B * C * H * W;
   if (in_elems == 0) return JTSM_OK;
   JTSM_REQUIRE(gin, "roi_align backward: null grad_input");
-  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && M > 0 && grad && rois &&
-      (long)M * PH * PW < (1L << 30)) {
+  // (a handful of rois — the mask branch's foreground set — is cheaper as memset + scatter than as one workgroup per
+  // tile of the whole map: the gather starts at 8192 bins)
+  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && grad && rois &&
+      (long)M * PH * PW >= 8192 && (long)M * PH * PW < (1L << 30)) {
     // gather form with the census guard: both forms are launched, the device-side census lets one of them return
     const int tiles_x = ceil_div(W, kTile), tiles_y = ceil_div(H, kTile), ntile = B * tiles_x * tiles_y;
     int* census = nullptr;

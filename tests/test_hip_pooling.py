@@ -401,10 +401,10 @@ def test_roi_align_backward_gather_reproducible_and_fallback(cuda):
     rng = np.random.default_rng(7)
     B, Cc, H, W = 2, 64, 64, 64
     x = rng.standard_normal((B, Cc, H, W)).astype(np.float32)
-    # (1) spread-out rois, legacy and aligned sampling, fixed and adaptive grids
-    r = _fpn_like_rois(rng, 96, B, 512)
+    # (1) spread-out rois (>= 8192 bins: the gather's threshold), legacy and aligned sampling, fixed and adaptive grids
+    r = _fpn_like_rois(rng, 192, B, 512)
     for aligned, sr in ((True, 0), (False, 0), (True, 2)):
-        g = rng.standard_normal((96, Cc, 7, 7)).astype(np.float32)
+        g = rng.standard_normal((192, Cc, 7, 7)).astype(np.float32)
         _, gx = run_align(x, r, 0.125, 7, 7, sr, aligned, cuda, True, g=g)
         _, gx2 = run_align(x, r, 0.125, 7, 7, sr, aligned, cuda, True, g=g)
         assert np.array_equal(gx, gx2)

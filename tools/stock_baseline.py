@@ -27,7 +27,7 @@ CL = torch.channels_last
 
 
 def conv2d_stock(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False,
-                 bias_needs_grad=False):
+                 bias_needs_grad=False, emit_planes=True, emit_dx_planes=False):
     y = F.conv2d(x, w, None, stride, pad, dil)
     if scale is not None:
         y = y * scale.view(1, -1, 1, 1)
@@ -85,6 +85,7 @@ def patch_to_stock():
     resnet.max_pool_3x3_s2 = lambda x: F.max_pool2d(x, 3, 2, 1)
     fpn.upsample2_add = lambda top, lat: lat + F.interpolate(top, scale_factor=2.0, mode="nearest")
     fpn.subsample2 = lambda x: F.max_pool2d(x, 1, 2, 0)
+    ew.sum_tensors = lambda xs: sum(xs[1:], xs[0])
     ew.group_norm_relu = lambda x, g, b, groups, eps=1e-5, relu=True: (
         F.relu(F.group_norm(x, groups, g, b, eps)) if relu else F.group_norm(x, groups, g, b, eps))
     ew.upsample_bilinear2x = lambda x: F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
