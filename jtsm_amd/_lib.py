@@ -53,8 +53,20 @@ def ptr(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_device_index = None
+
+
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of this process's device as a void*.  Called once per library launch (~950 per
+    training step), so it goes through torch's raw accessor (one C call) rather than building a Stream object; one
+    process drives one GPU (bench.py, DDP), whose index is looked up once."""
+    global _device_index
+    if _raw_stream is None:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _device_index is None:
+        _device_index = torch.cuda.current_device()
+    return C.c_void_p(_raw_stream(_device_index))
 
 
 def require_gpu(*tensors):
