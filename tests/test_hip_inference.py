@@ -145,6 +145,29 @@ def test_fast_rcnn_inference_matches_oracle(cuda, R, K, agnostic, thresh, topk):
     assert all_scores.shape == (1, R, K + 1) and all_boxes.shape == (1, R, kb * 4)
 
 
+def test_fast_rcnn_inference_full_size_consistent_with_batched_nms(cuda):
+    """R = 4000 proposals x K = 80 classes (the shipped PRECOMPUTED_PROPOSAL_TOPK_TEST and NUM_CLASSES) with the
+    shipped thresholds (score > 1e-5, NMS 0.3): 320000 candidates, too many for the Python oracle.  The one-call
+    detection routine must agree with the same selection assembled from its parts: threshold + clip on the host side
+    of the API, batched_nms (checked against the oracle and by properties above), top-100."""
+    g = torch.Generator().manual_seed(21)
+    R, K = 4000, 80
+    boxes = (_random_boxes(R * K, 1333, g).view(R, K * 4) - 20.0).cuda()
+    scores = torch.softmax(torch.randn(R, K + 1, generator=g) * 1.5, dim=1).cuda()
+    inst, rows, _, _ = fast_rcnn_inference_single_image(boxes, scores, (800, 1333), 1e-5, 0.3, 100)
+    assert len(inst) == 100
+    sc = scores[:, :-1]
+    b = boxes.view(R, K, 4).clone()
+    b[..., 0].clamp_(0, 1333); b[..., 1].clamp_(0, 800); b[..., 2].clamp_(0, 1333); b[..., 3].clamp_(0, 800)
+    mask = sc > 1e-5
+    idx = mask.nonzero()
+    assert len(idx) >= 40000                                  # the plain per-class branch of nms.py
+    keep = batched_nms(b[mask], sc[mask], idx[:, 1], 0.3)[:100]
+    assert torch.equal(inst.pred_boxes.tensor, b[mask][keep]) and torch.equal(inst.scores, sc[mask][keep])
+    assert torch.equal(inst.pred_classes, idx[keep, 1]) and torch.equal(rows, idx[keep, 0])
+    assert torch.equal(inst.scores, torch.sort(inst.scores, descending=True).values)
+
+
 def test_fast_rcnn_inference_empty(cuda):
     inst, rows, _, _ = fast_rcnn_inference_single_image(torch.zeros(0, 8).cuda(), torch.zeros(0, 3).cuda(), (10, 10),
                                                         0.05, 0.5, 100)
