@@ -276,6 +276,33 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
                                        const float* row_scale, int zero_dw, void* workspace,
                                        size_t workspace_bytes, void* stream);
 
+/* fp16 contractions (BASELINE.json configs[4]: "fp16 MFMA path" — fp16 operands, fp32 accumulate, fp32 results and
+ * losses; the reference reaches fp16 through torch autocast, detectron2/engine/train_loop.py AMPTrainer).  Same
+ * shapes, epilogue, workspace, eligibility and split-K rules as the bf16x3 entry points, but every operand is ONE
+ * plane of IEEE binary16 bit patterns (uint16_t, 16-byte aligned) and a product is one v_mfma_f32_32x32x16_f16.
+ *   jtsm_split_f16_f32              h[i] <- fp16(src[i] * 2^shift), same layout
+ *   jtsm_split_f16_transposed_f32   as jtsm_split_bf16_transposed_f32, one plane
+ *   jtsm_split_bf16_multi_f32       with a record's `lo` word 0 writes that record's fp16 plane into `hi`
+ * Gradient planes carry a power-of-two factor 2^grad_shift (exact; keeps small gradients out of fp16's subnormal
+ * range — the per-contraction equivalent of loss scaling): the caller splits dy with shift = grad_shift, the kernels
+ * multiply the accumulator by 2^-grad_shift before the epilogue (dx, dw come out unscaled, fp32) and write the dx
+ * plane (dx_h, nullable) with the factor applied again.  y_h (nullable) is the plain fp16 plane of y. */
+int jtsm_split_f16_f32(const float* src, uint16_t* h, long n, int shift, void* stream);
+int jtsm_split_f16_transposed_f32(const float* w, const float* row_scale, uint16_t* h, int out_c, int taps, int in_c,
+                                  void* stream);
+int jtsm_conv2d_forward_f16(const uint16_t* x_h, const uint16_t* w_h, float* y, uint16_t* y_h,
+                            const jtsm_conv_shape* s, const float* scale, const float* bias,
+                            const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                            void* stream);
+int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                  const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask,
+                                  int grad_shift, void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_conv2d_backward_weight_f16(const uint16_t* dy_h, const uint16_t* x_h, float* dw, const jtsm_conv_shape* s,
+                                    const float* row_scale, int zero_dw, int grad_shift, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+/* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */
+int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
+                                 void* stream);
 
 /* ---------------------------------------------------------------------------
  * Bandwidth-bound helpers (no reference source: torch elementwise ops behind

@@ -70,7 +70,10 @@ struct Params {
   int scatter, sc_Ho, sc_Wo, sc_H, sc_W, sc_stride;
   int wide;   // epilogue through LDS with 16-byte accesses (set by the launcher when alignment allows)
   unsigned short* out_hi;   // optional: bf16 hi / lo planes of the finished output, for a bf16x3 consumer
-  unsigned short* out_lo;
+  unsigned short* out_lo;   // (null with out_hi set: ONE IEEE fp16 plane, for an f16 consumer)
+  // fp16 path: gradient planes are stored times 2^k so that small gradients stay above fp16's subnormal range.
+  int in_shift;             // the accumulator is multiplied by 2^-in_shift first (an operand plane carried 2^in_shift)
+  int out_shift;            // emitted planes are multiplied by 2^out_shift
   ConvShape s;
   Epilogue e;
 };
@@ -78,6 +81,9 @@ struct Params {
 constexpr int BK = 32;
 constexpr int PAD_T = 1;  // transposed-store tiles: stride BM+1
 constexpr int PAD_D = 4;  // direct-store tiles:     stride BM+4
+
+// 2^k as a float (|k| < 127), exact
+__device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
 
 __device__ __forceinline__ float4 ldg4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
@@ -231,6 +237,7 @@ __device__ __forceinline__ void store_tile(const Params& p, f32x16 (&acc)[TM][TN
           p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v;
           continue;
         }
+        v *= pow2i(-p.in_shift);
         size_t o = (size_t)m * p.ldc + n;
         if (ROLE == DGRAD && p.scatter) {
           const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
@@ -252,10 +259,21 @@ __device__ __forceinline__ void store_tile(const Params& p, f32x16 (&acc)[TM][TN
   }
 }
 
-// hi/lo bf16 planes of four finished outputs (what jtsm_split_bf16_f32 would produce from them).
-__device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short* lo, size_t o, const float4& v) {
+// hi/lo bf16 planes of four finished outputs (what jtsm_split_bf16_f32 would produce from them); with lo == null,
+// one fp16 plane of v * 2^shift (what jtsm_split_f16_f32 would produce).
+__device__ __forceinline__ void emit_planes4(unsigned short* hi, unsigned short* lo, size_t o, const float4& v,
+                                             int shift = 0) {
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
   const float x[4] = {v.x, v.y, v.z, v.w};
+  if (!lo) {
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    const float sc = pow2i(shift);
+    f16x4_t h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = (_Float16)(x[e] * sc);
+    *reinterpret_cast<f16x4_t*>(hi + o) = h;
+    return;
+  }
   bf16x4_t h, l;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -331,6 +349,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
         const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
         o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
       }
+      if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
       if (ROLE == WGRAD) {
         if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
       } else if (e.scale) {
@@ -351,7 +370,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
         v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
       }
       *reinterpret_cast<float4*>(p.C + o) = v;
-      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v);
+      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
     }
   }
 }
@@ -817,6 +836,7 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
   const int nv = p.N / VEC;
   const long total = (long)p.M * nv;
   const Epilogue& e = p.e;
+  const float alpha = pow2i(-p.in_shift);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int n = (int)(i % nv) * VEC;
     const long m = i / nv;
@@ -841,7 +861,7 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float x = v[j] * (e.scale ? e.scale[scale_by_row ? m : n + j] : 1.f) + (e.bias ? e.bias[n + j] : 0.f);
+      float x = v[j] * alpha * (e.scale ? e.scale[scale_by_row ? m : n + j] : 1.f) + (e.bias ? e.bias[n + j] : 0.f);
       if (e.residual) x += e.residual[o + j];
       if (e.relu) x = fmaxf(x, 0.f);
       if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
@@ -850,7 +870,7 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
     if (VEC == 4) {
       const float4 out = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
       *reinterpret_cast<float4*>(p.C + o) = out;
-      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out);
+      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out, p.out_shift);
     } else {
       p.C[o] = v[0];
     }
@@ -1143,11 +1163,15 @@ int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role) {
   return x3_eligible(role, c) ? 1 : 0;
 }
 
-int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
-                               const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,
-                               const jtsm_conv_shape* s, const float* scale, const float* bias,
-                               const float* residual, int relu, void* workspace, size_t workspace_bytes,
-                               void* stream) {
+}  // extern "C"
+
+// NP = 2: split-bf16 planes (hi, lo).  NP = 1: one fp16 plane (the *_lo arguments are null).
+template <int NP>
+static int x3_forward(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
+                      const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,
+                      const jtsm_conv_shape* s, const float* scale, const float* bias,
+                      const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                      void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1159,14 +1183,14 @@ int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const
   p.N = p.s.Cout;
   p.K = p.s.KH * p.s.KW * p.s.Cin;
   if (p.M == 0) return JTSM_OK;
-  JTSM_REQUIRE(x_hi && x_lo && w_hi && w_lo && y, "conv forward bf16x3: null pointer");
+  JTSM_REQUIRE(x_hi && w_hi && y && (NP == 1 || (x_lo && w_lo)), "conv forward bf16x3 / f16: null pointer");
   JTSM_REQUIRE(aligned16(x_hi) && aligned16(x_lo) && aligned16(w_hi) && aligned16(w_lo),
-               "conv forward bf16x3: planes must be 16-byte aligned");
+               "conv forward bf16x3 / f16: planes must be 16-byte aligned");
   X3Planes q = {reinterpret_cast<const __bf16*>(x_hi), reinterpret_cast<const __bf16*>(x_lo),
                 reinterpret_cast<const __bf16*>(w_hi), reinterpret_cast<const __bf16*>(w_lo)};
   p.C = y; p.ldc = p.N;
   p.e.scale = scale; p.e.bias = bias; p.e.residual = residual; p.e.relu = relu;
-  JTSM_REQUIRE((y_hi == nullptr) == (y_lo == nullptr), "conv forward bf16x3: give both output planes or neither");
+  JTSM_REQUIRE(NP == 1 || (y_hi == nullptr) == (y_lo == nullptr), "conv forward bf16x3: give both output planes or neither");
   if (y_hi) {
     JTSM_REQUIRE(p.N % 4 == 0 && aligned16(y) && aligned16(y_hi) && aligned16(y_lo) &&
                  (!scale || aligned16(scale)) && (!bias || aligned16(bias)) && (!residual || aligned16(residual)),
@@ -1175,13 +1199,14 @@ int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const
   }
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
-  return launch_split_x3<FWD>(p, q, workspace, workspace_bytes, st);
+  return launch_split_x3<FWD, NP>(p, q, workspace, workspace_bytes, st);
 }
 
-int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
-                                     const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
-                                     const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+template <int NP>
+static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                            const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                            const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask, int grad_shift,
+                            void* workspace, size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1193,14 +1218,16 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
   p.N = p.s.Cin;
   p.K = p.s.KH * p.s.KW * p.s.Cout;
   if (p.M == 0) return JTSM_OK;
-  JTSM_REQUIRE(dy_hi && dy_lo && wt_hi && wt_lo && dx, "conv backward-data bf16x3: null pointer");
+  JTSM_REQUIRE(dy_hi && wt_hi && dx && (NP == 1 || (dy_lo && wt_lo)), "conv backward-data bf16x3 / f16: null pointer");
+  JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv backward-data f16: grad_shift must be in 0..24");
+  p.in_shift = grad_shift; p.out_shift = grad_shift;   // dy planes carry 2^shift; so do the dx planes written here
   JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(wt_hi) && aligned16(wt_lo),
                "conv backward-data bf16x3: planes must be 16-byte aligned");
   X3Planes q = {reinterpret_cast<const __bf16*>(dy_hi), reinterpret_cast<const __bf16*>(dy_lo),
                 reinterpret_cast<const __bf16*>(wt_hi), reinterpret_cast<const __bf16*>(wt_lo)};
   p.C = dx; p.ldc = p.N;
   p.e.residual = accumulate; p.e.mask = relu_mask;
-  JTSM_REQUIRE((dx_hi == nullptr) == (dx_lo == nullptr), "conv backward-data bf16x3: give both output planes or neither");
+  JTSM_REQUIRE(NP == 1 || (dx_hi == nullptr) == (dx_lo == nullptr), "conv backward-data bf16x3: give both output planes or neither");
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
   const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask;
@@ -1216,7 +1243,7 @@ int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_l
     p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;
     p.M = p.s.Bn * p.s.Ho * p.s.Wo;
   }
-  return launch_split_x3<DGRAD>(p, q, workspace, workspace_bytes, st);
+  return launch_split_x3<DGRAD, NP>(p, q, workspace, workspace_bytes, st);
 }
 
 // 256x256 tiles for the weight gradients whose output is large enough to fill the chip with them.
@@ -1261,7 +1288,7 @@ static int x3_wgrad_splits(const Params& p) {
   return kps > 0 ? ceil_div(ktiles, kps) : 1;
 }
 
-size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s) {
+extern "C" size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s) {
   if (!s || check_shape(s)) return 0;
   Params p = {};
   p.s = to_shape(s);
@@ -1272,10 +1299,11 @@ size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s) {
   return splits > 1 ? (size_t)splits * p.M * p.N * sizeof(float) : 0;
 }
 
-int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
-                                       const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
-                                       const float* row_scale, int zero_dw, void* workspace,
-                                       size_t workspace_bytes, void* stream) {
+template <int NP>
+static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
+                              const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
+                              const float* row_scale, int zero_dw, int grad_shift, void* workspace,
+                              size_t workspace_bytes, void* stream) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1292,7 +1320,9 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
     if (zero_dw) JTSM_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)p.M * p.N * sizeof(float), st));
     return JTSM_OK;
   }
-  JTSM_REQUIRE(dy_hi && dy_lo && x_hi && x_lo, "conv backward-weight bf16x3: null pointer");
+  JTSM_REQUIRE(dy_hi && x_hi && (NP == 1 || (dy_lo && x_lo)), "conv backward-weight bf16x3 / f16: null pointer");
+  JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv backward-weight f16: grad_shift must be in 0..24");
+  p.in_shift = grad_shift;
   JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(x_hi) && aligned16(x_lo),
                "conv backward-weight bf16x3: planes must be 16-byte aligned");
   X3Planes q = {reinterpret_cast<const __bf16*>(dy_hi), reinterpret_cast<const __bf16*>(dy_lo),
@@ -1313,12 +1343,85 @@ int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy
   p.wide = 1;   // N = taps * in_c is a multiple of 8, dw / slab 16-byte aligned
   if (x3_wgrad_halo(p)) {
     const int halo_tiles = ceil_div(p.M, 128) * (p.s.Cin / 32);
-    hipLaunchKernelGGL(igemm_x3_wgrad_halo_kernel, dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
-  } else if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
-  else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
+    hipLaunchKernelGGL(igemm_x3_wgrad_halo_kernel<NP>, dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
+  } else if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2, NP>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
+  else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2, NP>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
   record_mid(st);
   if (splits > 1) return finish_split(p, splits, st, 1);
+  return JTSM_OK;
+}
+
+extern "C" {
+
+int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
+                               const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,
+                               const jtsm_conv_shape* s, const float* scale, const float* bias,
+                               const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+  return x3_forward<2>(x_hi, x_lo, w_hi, w_lo, y, y_hi, y_lo, s, scale, bias, residual, relu, workspace,
+                       workspace_bytes, stream);
+}
+
+int jtsm_conv2d_backward_data_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                     const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                     const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  return x3_backward_data<2>(dy_hi, dy_lo, wt_hi, wt_lo, dx, dx_hi, dx_lo, s, accumulate, relu_mask, 0, workspace,
+                             workspace_bytes, stream);
+}
+
+int jtsm_conv2d_backward_weight_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
+                                       const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
+                                       const float* row_scale, int zero_dw, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+  return x3_backward_weight<2>(dy_hi, dy_lo, x_hi, x_lo, dw, s, row_scale, zero_dw, 0, workspace, workspace_bytes,
+                               stream);
+}
+
+/* ---- fp16 path (BASELINE configs[4]): ONE IEEE fp16 plane per operand, fp32 accumulate, fp32 results ---- */
+int jtsm_conv2d_forward_f16(const uint16_t* x_h, const uint16_t* w_h, float* y, uint16_t* y_h,
+                            const jtsm_conv_shape* s, const float* scale, const float* bias,
+                            const float* residual, int relu, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  return x3_forward<1>(x_h, nullptr, w_h, nullptr, y, y_h, nullptr, s, scale, bias, residual, relu, workspace,
+                       workspace_bytes, stream);
+}
+
+int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                  const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask,
+                                  int grad_shift, void* workspace, size_t workspace_bytes, void* stream) {
+  return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, relu_mask, grad_shift,
+                             workspace, workspace_bytes, stream);
+}
+
+int jtsm_conv2d_backward_weight_f16(const uint16_t* dy_h, const uint16_t* x_h, float* dw, const jtsm_conv_shape* s,
+                                    const float* row_scale, int zero_dw, int grad_shift, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  return x3_backward_weight<1>(dy_h, nullptr, x_h, nullptr, dw, s, row_scale, zero_dw, grad_shift, workspace,
+                               workspace_bytes, stream);
+}
+
+int jtsm_split_f16_f32(const float* src, uint16_t* h, long n, int shift, void* stream) {
+  JTSM_REQUIRE(n >= 0 && shift >= 0 && shift <= 24, "split_f16: bad size / shift");
+  if (n == 0) return JTSM_OK;
+  JTSM_REQUIRE(src && h && aligned16(src) && aligned16(h), "split_f16: pointers must be non-null and 16-byte aligned");
+  const long n8 = n >> 3;
+  const int blocks = (int)(n8 / 256 + 1 < 8192 ? n8 / 256 + 1 : 8192);
+  hipLaunchKernelGGL(split_f16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src,
+                     reinterpret_cast<_Float16*>(h), n, shift);
+  JTSM_CHECK_LAUNCH("split_f16");
+  return JTSM_OK;
+}
+
+int jtsm_split_f16_transposed_f32(const float* w, const float* row_scale, uint16_t* h, int out_c, int taps, int in_c,
+                                  void* stream) {
+  JTSM_REQUIRE(out_c >= 0 && taps > 0 && in_c >= 0 && taps <= 65535, "split_f16_transposed: bad sizes");
+  if (out_c == 0 || in_c == 0) return JTSM_OK;
+  JTSM_REQUIRE(w && h, "split_f16_transposed: null pointer");
+  hipLaunchKernelGGL(split_bf16_transposed_kernel, dim3(ceil_div(in_c, 32), ceil_div(out_c, 32), taps), dim3(256), 0,
+                     as_stream(stream), w, row_scale, reinterpret_cast<__bf16*>(h), (__bf16*)nullptr, out_c, taps, in_c);
+  JTSM_CHECK_LAUNCH("split_f16_transposed");
   return JTSM_OK;
 }
 

@@ -20,6 +20,27 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XBK = 32;   // k per stage (and the unit of split-K bookkeeping)
 
+// NP = planes per operand.  2: split-bf16 (hi + lo, three bf16 products per fp32 product).  1: ONE IEEE fp16 plane
+// (BASELINE configs[4]: fp16 operands, fp32 accumulate) — a single v_mfma_f32_32x32x16_f16 per sixteen k, half the
+// operand bytes; the kernels are otherwise the same, X3Planes' lo pointers are unused.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int NP>
+__device__ __forceinline__ void x3_mma(f32x16& acc, const bf16x8& ah, const bf16x8& al, const bf16x8& bh,
+                                       const bf16x8& bl) {
+  if (NP == 2) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  } else {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
+  }
+}
+constexpr int x3_max(int a, int b) { return a > b ? a : b; }
+// epilogue bands through an LDS window of `kbytes` (the K-loop buffers) for a BM x BN fp32 tile
+constexpr int x3_passes(int kbytes, int BM, int BN, int TM) {
+  return kbytes >= BM * BN * 4 ? 1 : (kbytes >= BM * BN * 2 ? 2 : (((BM / 4) % (32 * TM) == 0 && kbytes >= BM * BN) ? 4 : 2));
+}
+
 struct X3Planes {
   const __bf16* A_hi; const __bf16* A_lo;
   const __bf16* B_hi; const __bf16* B_lo;
@@ -34,17 +55,19 @@ __device__ __forceinline__ void dma16b(const void* g, void* lds_uniform_base) {
 // BM x BN = 32*WM*TM x 32*WN*TN outputs.  The loop is bound by how many operand bytes a CU can keep in
 // flight from L2 (measured: the same kernel without its MFMAs takes 67-90 % of the full time, and LDS limits
 // the bytes in flight), so the large layers use 256x256 (half the operand bytes per FLOP of 128x128).
-template <int ROLE, int WM, int WN, int TM, int TN, int NBUF>
+template <int ROLE, int WM, int WN, int TM, int TN, int NBUF, int NP = 2>
 __global__ __launch_bounds__(64 * WM * WN, (NBUF == 1 && WM * WN == 4) ? 4 : (WM * WN == 4 ? 2 : 2))
 void igemm_x3_kernel(const Params p, const X3Planes q) {
   static_assert(ROLE == FWD || ROLE == DGRAD, "bf16x3: forward and data-gradient roles");
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   constexpr int A_PL = BM * 64, B_PL = BN * 64;          // bytes per plane per stage (64-byte rows)
-  constexpr int STAGE = 2 * A_PL + 2 * B_PL;
+  constexpr int STAGE = NP * (A_PL + B_PL);
   static_assert(BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "16-row loads must divide evenly among the wavefronts");
   constexpr int A_INS = BM / 16 / NW, B_INS = BN / 16 / NW;   // loads per wavefront per plane per stage
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
+  constexpr int PASSES = x3_passes(NBUF * STAGE, BM, BN, TM);
+  constexpr int LDSB = x3_max(NBUF * STAGE, BM * BN * 4 / PASSES);
+  __shared__ __attribute__((aligned(16))) char lds[LDSB];
 
   const ConvShape& s = p.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,11 +135,11 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
 
   // One direct-to-LDS load ("piece") of the next stage: pieces 0 .. 2*A_INS-1 are the A rows (hi, lo
   // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups.
-  constexpr int PIECES = 2 * A_INS + 2 * B_INS;
+  constexpr int PIECES = NP * (A_INS + B_INS);
   auto issue_piece = [&](int idx, int k0, int buf) {
     char* St = lds + buf * STAGE;
-    if (idx < 2 * A_INS) {
-      const int j = idx >> 1, lo = idx & 1;
+    if (idx < NP * A_INS) {
+      const int j = idx / NP, lo = idx % NP;
       bool ok;
       int off;
       if (linear) {
@@ -135,10 +158,10 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
       const __bf16* src = q.A_hi + off + (lo ? lo_delta_a : 0);
       dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + lo * A_PL + (wave * A_INS + j) * 1024);
     } else {
-      const int j = (idx - 2 * A_INS) >> 1, lo = (idx - 2 * A_INS) & 1;
+      const int j = (idx - NP * A_INS) / NP, lo = (idx - NP * A_INS) % NP;
       const bool ok = b_off[j] >= 0 && (k0 + b_chunk[j]) < kend;
       const __bf16* src = q.B_hi + (b_off[j] + k0 + b_chunk[j]) + (lo ? lo_delta_b : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + 2 * A_PL + lo * B_PL + (wave * B_INS + j) * 1024);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + NP * A_PL + lo * B_PL + (wave * B_INS + j) * 1024);
     }
   };
   auto advance_tap = [&]() {   // next stage: same tap or the next one (stages never straddle taps)
@@ -172,7 +195,7 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int br = (wn * TN + t) * 32 + li;
-    bb_off[t] = 2 * A_PL + br * 64;
+    bb_off[t] = NP * A_PL + br * 64;
     b_swz[t] = (br >> 2) & 3;
   }
 
@@ -197,21 +220,19 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
       for (int u = 0; u < TM; ++u) {
         const int ao = a_off[u] + ((c ^ a_swz[u]) << 4);
         ah[u] = *reinterpret_cast<const bf16x8*>(St + ao);
-        al[u] = *reinterpret_cast<const bf16x8*>(St + A_PL + ao);
+        al[u] = NP == 2 ? *reinterpret_cast<const bf16x8*>(St + A_PL + ao) : ah[u];
       }
 #pragma unroll
       for (int u = 0; u < TN; ++u) {
         const int bo = bb_off[u] + ((c ^ b_swz[u]) << 4);
         bh[u] = *reinterpret_cast<const bf16x8*>(St + bo);
-        bl[u] = *reinterpret_cast<const bf16x8*>(St + B_PL + bo);
+        bl[u] = NP == 2 ? *reinterpret_cast<const bf16x8*>(St + B_PL + bo) : bh[u];
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          x3_mma<NP>(acc[i][j], ah[i], al[i], bh[j], bl[j]);
           if (NBUF == 2) {
             const int slot = (st * TM + i) * TN + j;
             if (more) {
@@ -225,8 +246,6 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
     }
     if (more) advance_tap();
   }
-  constexpr int LDSB = NBUF * STAGE;
-  constexpr int PASSES = LDSB >= BM * BN * 4 ? 1 : (LDSB >= BM * BN * 2 ? 2 : 4);
   static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
   if (p.wide)
     store_tile_wide<ROLE, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
@@ -243,7 +262,7 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
 // K order: channel block outer, taps inner (any order sums to the same product; split-K cuts channel blocks).
 // Two shapes: 8 x 16 pixels x 128 channels (4 wavefronts, 80 KiB, two workgroups per CU) and 16 x 16 pixels x 256
 // channels (8 wavefronts, 148 KiB) for the layers that fill the chip with 256-wide tiles.
-template <int ROLE, int TH, int WM, int WN, int TN, int HP16 /* 16-row groups of the halo image */>
+template <int ROLE, int TH, int WM, int WN, int TN, int HP16 /* 16-row groups of the halo image */, int NP = 2>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Params p, const X3Planes q) {
   static_assert(ROLE == FWD || ROLE == DGRAD, "halo kernel: forward and data-gradient roles");
   constexpr int TW = 16, TM = 2, NW = WM * WN, NT = 64 * NW;
@@ -251,10 +270,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
   static_assert(BM == 32 * WM * TM, "patch rows = wavefront rows");
   constexpr int A_PL = HP16 * 1024;          // bytes per plane of one halo buffer
   constexpr int B_PL = BN * 64;              // bytes per plane of one weight stage
-  constexpr int A_BUF = 2 * A_PL, B_BUF = 2 * B_PL;
+  constexpr int A_BUF = NP * A_PL, B_BUF = NP * B_PL;
   constexpr int A_J = (HP16 + NW - 1) / NW;  // halo loads per wavefront per plane
   constexpr int B_J = BN / 16 / NW;          // weight loads per wavefront per plane
-  __shared__ __attribute__((aligned(16))) char lds[2 * A_BUF + 2 * B_BUF];
+  constexpr int PASSES = x3_passes(2 * A_BUF + 2 * B_BUF, BM, BN, TM);
+  constexpr int LDSB = x3_max(2 * A_BUF + 2 * B_BUF, BM * BN * 4 / PASSES);
+  __shared__ __attribute__((aligned(16))) char lds[LDSB];
   char* const Abase = lds;
   char* const Bbase = lds + 2 * A_BUF;
 
@@ -316,16 +337,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
   }
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
 
-  constexpr int A_PIECES = 2 * A_J, B_PIECES = 2 * B_J;
+  constexpr int A_PIECES = NP * A_J, B_PIECES = NP * B_J;
   auto issue_a_piece = [&](int idx, int cb, int buf) {
-    const int j = idx >> 1, lo = idx & 1;
+    const int j = idx / NP, lo = idx % NP;
     const int T = wave + NW * j;
     if (T >= HP16) return;   // wave-uniform
     const __bf16* src = q.A_hi + (a_base[j] + cb * XBK) + (lo ? lo_delta_a : 0);
     dma16b(a_ok[j] ? (const void*)src : (const void*)g_zero_page, Abase + buf * A_BUF + lo * A_PL + T * 1024);
   };
   auto issue_b_piece = [&](int idx, int cb, int tap, int buf) {
-    const int j = idx >> 1, lo = idx & 1;
+    const int j = idx / NP, lo = idx % NP;
     const __bf16* src = q.B_hi + (b_off[j] + tap * Cdim + cb * XBK + b_chunk[j]) + (lo ? lo_delta_b : 0);
     dma16b(b_off[j] >= 0 ? (const void*)src : (const void*)g_zero_page,
            Bbase + buf * B_BUF + lo * B_PL + (wave * B_J + j) * 1024);
@@ -387,21 +408,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
       for (int u = 0; u < TM; ++u) {
         const int ao = a_row[u] + ((c ^ a_swz[u]) << 4);
         ah[u] = *reinterpret_cast<const bf16x8*>(Ab + ao);
-        al[u] = *reinterpret_cast<const bf16x8*>(Ab + A_PL + ao);
+        al[u] = NP == 2 ? *reinterpret_cast<const bf16x8*>(Ab + A_PL + ao) : ah[u];
       }
 #pragma unroll
       for (int u = 0; u < TN; ++u) {
         const int bo = bb_off[u] + ((c ^ b_swz[u]) << 4);
         bh[u] = *reinterpret_cast<const bf16x8*>(Bb + bo);
-        bl[u] = *reinterpret_cast<const bf16x8*>(Bb + B_PL + bo);
+        bl[u] = NP == 2 ? *reinterpret_cast<const bf16x8*>(Bb + B_PL + bo) : bh[u];
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          x3_mma<NP>(acc[i][j], ah[i], al[i], bh[j], bl[j]);
           // MFMA groups 0 .. B_PIECES-1 are each followed by one weight load of the next stage, the remaining
           // groups by the next channel block's halo loads (when the next stage starts one)
           constexpr int SLOTS = 2 * TM * TN, A_SLOTS = SLOTS - B_PIECES, A_PER = (A_PIECES + A_SLOTS - 1) / A_SLOTS;
@@ -423,9 +442,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
     if (++kw == s.KW) { kw = 0; if (++kh == s.KH) kh = 0; }
   }
   const PatchRows rows = {b, oy0, ox0, OH, OW, TW};
-  constexpr int LDSB = 2 * A_BUF + 2 * B_BUF;
-  constexpr int PASSES = LDSB >= BM * BN * 4 ? 1 : 2;
-  static_assert(LDSB >= BM * BN * 4 / PASSES, "epilogue band does not fit");
+  static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit");
   if (p.wide)
     store_tile_wide<ROLE, BM, BN, PASSES, TM, TN, NT, PatchRows>(p, acc, 0, n0, wm, wn, lane, tid,
                                                                  reinterpret_cast<float*>(lds), &rows);
@@ -445,7 +462,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
           float v = acc[i][j][r];
           if (gridDim.y > 1) { p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v; continue; }
           const size_t o = (size_t)m * p.ldc + n;
-          v = v * (e.scale ? e.scale[n] : 1.f) + (e.bias ? e.bias[n] : 0.f);
+          v = v * pow2i(-p.in_shift) * (e.scale ? e.scale[n] : 1.f) + (e.bias ? e.bias[n] : 0.f);
           if (e.residual) v += e.residual[o];
           if (e.relu) v = fmaxf(v, 0.f);
           if (e.mask) v = e.mask[o] > 0.f ? v : 0.f;
@@ -472,16 +489,18 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* lo_rows, const char* hi_ro
 
 // WM x WN wavefronts of TM x TN MFMA tiles, as in igemm_x3_kernel; operands wider than 128 channels are kept
 // as several 128-channel images (each with the swizzle above).
-template <int WM, int WN, int TM, int TN, int NBUF>
+template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const Params p, const X3Planes q) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(BM % 128 == 0 && BN % 128 == 0 && 8 % NW == 0, "128-channel images; 8 row groups shared by the wavefronts");
   constexpr int ASUB = BM / 128, BSUB = BN / 128;
   constexpr int PL = XBK * 256;                 // bytes per image per plane per stage: 32 pixel rows x 128 channels
-  constexpr int STAGE = 2 * (ASUB + BSUB) * PL; // [dY image 0 hi, lo, image 1 hi, lo ...][X images likewise]
+  constexpr int STAGE = NP * (ASUB + BSUB) * PL; // [dY image 0 hi, lo, image 1 hi, lo ...][X images likewise]
   constexpr int INS = 8 / NW;                   // 4-row load groups per wavefront per image
-  __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE];
+  constexpr int PASSES = x3_passes(NBUF * STAGE, BM, BN, TM);
+  constexpr int LDSB = x3_max(NBUF * STAGE, BM * BN * 4 / PASSES);
+  __shared__ __attribute__((aligned(16))) char lds[LDSB];
 
   const ConvShape& s = p.s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -534,25 +553,25 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
 
   // piece idx -> (row group j, operand, image u, plane): INS * 2 * (ASUB + BSUB) pieces per wavefront per stage
-  constexpr int PPJ = 2 * (ASUB + BSUB);
+  constexpr int PPJ = NP * (ASUB + BSUB);
   constexpr int PIECES = INS * PPJ;
   auto issue_piece = [&](int idx, int k0, int buf) {
     char* St = lds + buf * STAGE;
     const int j = idx / PPJ, w = idx % PPJ;
     const int dst = (wave * INS + j) * 1024;
-    if (w < 2 * ASUB) {
-      const int u = w >> 1, lo = w & 1;
+    if (w < NP * ASUB) {
+      const int u = w / NP, lo = w % NP;
       const int k = k0 + row_k[j];
       const bool ok = a_ok[j][u] && k < kend;
       const __bf16* src = q.A_hi + ((long)k * s.Cout + a_col[j][u]) + (lo ? lo_delta_a : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (u * 2 + lo) * PL + dst);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (u * NP + lo) * PL + dst);
     } else {
-      const int u = (w - 2 * ASUB) >> 1, lo = (w - 2 * ASUB) & 1;
+      const int u = (w - NP * ASUB) / NP, lo = (w - NP * ASUB) % NP;
       const PixState& px = bpix[j];
       const int ih = px.oh * s.stride - s.pad + b_kh[j][u] * s.dil, iw = px.ow * s.stride - s.pad + b_kw[j][u] * s.dil;
       const bool ok = b_ok[j][u] && px.k < kend && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
       const __bf16* src = q.B_hi + (((long)(px.b * s.H + ih) * s.W + iw) * s.Cin + b_ci[j][u]) + (lo ? lo_delta_b : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (2 * ASUB + u * 2 + lo) * PL + dst);
+      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (NP * ASUB + u * NP + lo) * PL + dst);
     }
   };
   auto advance_pix = [&]() {
@@ -585,13 +604,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
     for (int t = 0; t < TM; ++t) {
       const int cb = (wm * TM + t) * 32;          // first channel of this tile inside the BM tile
       const int ch = (cb % 128) / 8 + 2 * g + (pl >> 1);
-      a_rd[t][r2] = (cb / 128) * 2 * PL + 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
+      a_rd[t][r2] = (cb / 128) * NP * PL + 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
     }
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
       const int cb = (wn * TN + t) * 32;
       const int ch = (cb % 128) / 8 + 2 * g + (pl >> 1);
-      b_rd[t][r2] = (2 * ASUB + (cb / 128) * 2) * PL + 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
+      b_rd[t][r2] = NP * (ASUB + cb / 128) * PL + 256 * row + 16 * (ch ^ swz) + 8 * (pl & 1);
     }
   }
 
@@ -615,20 +634,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
 #pragma unroll
       for (int u = 0; u < TM; ++u) {
         ah[u] = lds_tr8(Ss + a_rd[u][0], Ss + a_rd[u][1]);
-        al[u] = lds_tr8(Ss + PL + a_rd[u][0], Ss + PL + a_rd[u][1]);
+        al[u] = NP == 2 ? lds_tr8(Ss + PL + a_rd[u][0], Ss + PL + a_rd[u][1]) : ah[u];
       }
 #pragma unroll
       for (int u = 0; u < TN; ++u) {
         bh[u] = lds_tr8(Ss + b_rd[u][0], Ss + b_rd[u][1]);
-        bl[u] = lds_tr8(Ss + PL + b_rd[u][0], Ss + PL + b_rd[u][1]);
+        bl[u] = NP == 2 ? lds_tr8(Ss + PL + b_rd[u][0], Ss + PL + b_rd[u][1]) : bh[u];
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          x3_mma<NP>(acc[i][j], ah[i], al[i], bh[j], bl[j]);
           if (NBUF == 2) {
             const int slot = (st * TM + i) * TN + j;
             if (more) {
@@ -642,8 +659,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
     }
     if (more) advance_pix();
   }
-  constexpr int LDSB = NBUF * STAGE;
-  constexpr int PASSES = LDSB >= BM * BN * 4 ? 1 : (LDSB >= BM * BN * 2 ? 2 : 4);
   static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
   if (p.wide)
     store_tile_wide<WGRAD, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
@@ -661,11 +676,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
 // never wrap); everything else keeps the generic kernel.
 // Halo image: [102 pixel rows][64 B] per plane, UNswizzled — a transposed read of 4 consecutive pixel rows x 32
 // channels is one contiguous 256-byte run (all 64 banks) wherever it starts.
+template <int NP = 2>
 __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Params p, const X3Planes q) {
   constexpr int SEG = 32, HPW = SEG + 2, HP = 3 * HPW;          // 102 halo pixels
   constexpr int A_PL = SEG * 256;                                 // dY stage plane: 32 px x 128 co
   constexpr int B_G = (HP + 15) / 16, B_PL = B_G * 1024;          // halo plane: 7 groups of 16 pixel rows
-  constexpr int STAGE = 2 * A_PL + 2 * B_PL;                      // 30 KiB
+  constexpr int STAGE = NP * (A_PL + B_PL);                       // 30 KiB (two planes)
   constexpr int TAPS = 9;
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
@@ -718,7 +734,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       const long aoff = (long)(k0 + a_rowk[j]) * s.Cout + a_col[j];
       const int dst = (wave * 2 + j) * 1024;
       dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff) : (const void*)g_zero_page, St + dst);
-      dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff + lo_delta_a) : (const void*)g_zero_page, St + A_PL + dst);
+      if (NP == 2) dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff + lo_delta_a) : (const void*)g_zero_page, St + A_PL + dst);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -727,8 +743,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       const int y = sy * s.stride + b_ry[j], x = sx * s.stride + b_rx[j];
       const bool ok = b_in[j] && (unsigned)y < (unsigned)s.H && (unsigned)x < (unsigned)s.W;
       const long boff = ((long)(sb * s.H + y) * s.W + x) * s.Cin + b_c[j];
-      dma16b(ok ? (const void*)(q.B_hi + boff) : (const void*)g_zero_page, St + 2 * A_PL + T * 1024);
-      dma16b(ok ? (const void*)(q.B_hi + boff + lo_delta_b) : (const void*)g_zero_page, St + 2 * A_PL + B_PL + T * 1024);
+      dma16b(ok ? (const void*)(q.B_hi + boff) : (const void*)g_zero_page, St + NP * A_PL + T * 1024);
+      if (NP == 2) dma16b(ok ? (const void*)(q.B_hi + boff + lo_delta_b) : (const void*)g_zero_page, St + NP * A_PL + B_PL + T * 1024);
     }
     sx += SEG;   // next segment (the output width is a multiple of 32)
     if (sx >= s.Wo) { sx = 0; if (++sy == s.Ho) { sy = 0; ++sb; } }
@@ -758,21 +774,19 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
     __syncthreads();
     if (st + 1 < nstage) issue(kbeg + (st + 1) * SEG, (st + 1) & 1);
     const char* St = lds + (st & 1) * STAGE;
-    const char* Bh = St + 2 * A_PL;
+    const char* Bh = St + NP * A_PL;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const char* As = St + ks * 16 * 256;
       const bf16x8 ah = lds_tr8(As + a_rd[0], As + a_rd[1]);
-      const bf16x8 al = lds_tr8(As + A_PL + a_rd[0], As + A_PL + a_rd[1]);
+      const bf16x8 al = NP == 2 ? lds_tr8(As + A_PL + a_rd[0], As + A_PL + a_rd[1]) : ah;
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int kh = t / 3, kw = t % 3;
         const char* Bs = Bh + ((kh * HPW + kw + 16 * ks) * 64) + b_rd;
         const bf16x8 bh = lds_tr8(Bs, Bs + 4 * 64);
-        const bf16x8 bl = lds_tr8(Bs + B_PL, Bs + B_PL + 4 * 64);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t], 0, 0, 0);
+        const bf16x8 bl = NP == 2 ? lds_tr8(Bs + B_PL, Bs + B_PL + 4 * 64) : bh;
+        x3_mma<NP>(acc[t], ah, al, bh, bl);
       }
     }
   }
@@ -790,6 +804,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       float v = acc[t][r];
       if (gridDim.y > 1) { p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v; continue; }
       const size_t o = (size_t)m * p.ldc + n;
+      v *= pow2i(-p.in_shift);
       if (e.scale) v *= e.scale[m];
       if (e.residual) v += e.residual[o];
       p.C[o] = v;
@@ -826,6 +841,26 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
+// fp16 path: ONE plane h[i] = fp16(src[i] * 2^shift) (shift: the gradient-plane exponent offset, 0 for activations
+// and weights).
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ h, long n,
+                                                        int shift) {
+  const long n8 = n >> 3;
+  const float sc = pow2i(shift);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)(v[e] * sc);
+    reinterpret_cast<f16x8*>(h)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) {
+    const long i = (n8 << 3) + threadIdx.x;
+    h[i] = (_Float16)(src[i] * sc);
+  }
+}
+
 // W [Cout][taps][Cin] -> planes of W^T [Cin][taps][Cout] (the K-contiguous B operand of the data gradient).
 // row_scale (optional, [Cout]) multiplies row co first: the FrozenBN scale folded into the data gradient.
 __global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float* __restrict__ w,
@@ -846,7 +881,8 @@ __global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float*
     const int ci = ci0 + r, co = co0 + tx;
     if (ci < Cin && co < Cout) {
       const size_t o = ((size_t)ci * taps + tap) * Cout + co;
-      split1(tile[tx][r], hi[o], lo[o]);
+      if (lo) split1(tile[tx][r], hi[o], lo[o]);
+      else reinterpret_cast<_Float16*>(hi)[o] = (_Float16)tile[tx][r];
     }
   }
 }
@@ -857,7 +893,7 @@ __global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float*
 struct SplitEntry {        // 8 x 8 bytes, built by the host as int64 words
   const float* src;        // weight [Cout][taps][Cin]
   __bf16* hi;
-  __bf16* lo;
+  __bf16* lo;              // null: write ONE fp16 plane into `hi` (the fp16 path)
   const float* row_scale;  // transposed form only (nullable)
   long first_block;        // first workgroup of this entry
   long n;                  // straight: elements.  transposed: Cout
@@ -882,6 +918,13 @@ __global__ __launch_bounds__(256) void split_bf16_multi_kernel(const SplitEntry*
   if (base + 8 <= t.n) {
     const float4 a = *reinterpret_cast<const float4*>(t.src + base), b = *reinterpret_cast<const float4*>(t.src + base + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (!t.lo) {   // fp16 form: one plane
+      f16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (_Float16)v[k];
+      *reinterpret_cast<f16x8*>(t.hi + base) = o;
+      return;
+    }
     bf16x8 h, l;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -892,7 +935,10 @@ __global__ __launch_bounds__(256) void split_bf16_multi_kernel(const SplitEntry*
     *reinterpret_cast<bf16x8*>(t.hi + base) = h;
     *reinterpret_cast<bf16x8*>(t.lo + base) = l;
   } else {
-    for (long i = base; i < t.n; ++i) split1(t.src[i], t.hi[i], t.lo[i]);
+    for (long i = base; i < t.n; ++i) {
+      if (t.lo) split1(t.src[i], t.hi[i], t.lo[i]);
+      else reinterpret_cast<_Float16*>(t.hi)[i] = (_Float16)t.src[i];
+    }
   }
 }
 
@@ -920,7 +966,8 @@ __global__ __launch_bounds__(256) void split_bf16_transposed_multi_kernel(const 
     const int ci = ci0 + rr, co = co0 + tx;
     if (ci < Cin && co < Cout) {
       const size_t o = ((size_t)ci * taps + tap) * Cout + co;
-      split1(tile[tx][rr], t.hi[o], t.lo[o]);
+      if (t.lo) split1(tile[tx][rr], t.hi[o], t.lo[o]);
+      else reinterpret_cast<_Float16*>(t.hi)[o] = (_Float16)tile[tx][rr];
     }
   }
 }
@@ -934,7 +981,7 @@ inline bool x3_eligible(int role, const ConvShape& s) {
 }
 
 // Launch one tile configuration, with its split-K plan.
-template <int ROLE, int WM, int WN, int TM, int TN>
+template <int ROLE, int WM, int WN, int TM, int TN, int NP>
 int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, int round_blocks,
                   hipStream_t st) {
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN, NT = 64 * WM * WN;
@@ -956,9 +1003,9 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
   if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
     // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
     // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
-    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 1>), grid, dim3(NT), 0, st, p, q);
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 1, NP>), grid, dim3(NT), 0, st, p, q);
   else
-    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2>), grid, dim3(NT), 0, st, p, q);
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2, NP>), grid, dim3(NT), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3");
   record_mid(st);
   if (splits > 1) return finish_split(p, splits, st);
@@ -995,7 +1042,7 @@ inline bool x3_halo_ok(int role, const Params& p) {
          OH >= 32 && OW >= 32;
 }
 
-template <int ROLE, bool BIG>
+template <int ROLE, bool BIG, int NP>
 int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
   const ConvShape& s = p.s;
   constexpr int TH = BIG ? 16 : 8, BN = BIG ? 256 : 128;
@@ -1019,23 +1066,23 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
-  if (BIG) hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 16, 4, 2, 4, 21>), grid, dim3(512), 0, st, p, q);
-  else hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 8, 2, 2, 2, 12>), grid, dim3(256), 0, st, p, q);
+  if (BIG) hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 16, 4, 2, 4, 21, NP>), grid, dim3(512), 0, st, p, q);
+  else hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 8, 2, 2, 2, 12, NP>), grid, dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 halo");
   record_mid(st);
   if (splits > 1) return finish_split(p, splits, st);
   return JTSM_OK;
 }
 
-template <int ROLE>
+template <int ROLE, int NP = 2>
 int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
   if (x3_halo_ok(ROLE, p)) {
-    if (x3_tile_choice(p) == 2) return launch_x3_halo<ROLE, true>(p, q, workspace, workspace_bytes, st);
-    return launch_x3_halo<ROLE, false>(p, q, workspace, workspace_bytes, st);
+    if (x3_tile_choice(p) == 2) return launch_x3_halo<ROLE, true, NP>(p, q, workspace, workspace_bytes, st);
+    return launch_x3_halo<ROLE, false, NP>(p, q, workspace, workspace_bytes, st);
   }
   switch (x3_tile_choice(p)) {
-    case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2>(p, q, workspace, workspace_bytes, 512, st);
-    case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4>(p, q, workspace, workspace_bytes, 256, st);
-    default: return launch_x3_cfg<ROLE, 2, 2, 2, 2>(p, q, workspace, workspace_bytes, 512, st);
+    case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2, NP>(p, q, workspace, workspace_bytes, 512, st);
+    case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4, NP>(p, q, workspace, workspace_bytes, 256, st);
+    default: return launch_x3_cfg<ROLE, 2, 2, 2, 2, NP>(p, q, workspace, workspace_bytes, 512, st);
   }
 }

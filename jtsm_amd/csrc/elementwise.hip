@@ -43,6 +43,24 @@ __global__ __launch_bounds__(256) void relu_bwd_split_kernel(const float4* __res
     lo[i] = l;
   }
 }
+// fp16 form: ONE plane of g * 2^shift
+typedef _Float16 ew_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void relu_bwd_split_f16_kernel(const float4* __restrict__ dy, const float4* __restrict__ y,
+                                                                 float4* __restrict__ g, ew_f16x8* __restrict__ h, long n8,
+                                                                 int shift) {
+  const float sc = __int_as_float((127 + shift) << 23);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const float4 a0 = dy[2 * i], a1 = dy[2 * i + 1], b0 = y[2 * i], b1 = y[2 * i + 1];
+    const float v[8] = {b0.x > 0.f ? a0.x : 0.f, b0.y > 0.f ? a0.y : 0.f, b0.z > 0.f ? a0.z : 0.f, b0.w > 0.f ? a0.w : 0.f,
+                        b1.x > 0.f ? a1.x : 0.f, b1.y > 0.f ? a1.y : 0.f, b1.z > 0.f ? a1.z : 0.f, b1.w > 0.f ? a1.w : 0.f};
+    g[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+    g[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    ew_f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (_Float16)(v[e] * sc);
+    h[i] = o;
+  }
+}
 __global__ __launch_bounds__(256) void relu_bwd_tail(const float* __restrict__ dy,
                                                      const float* __restrict__ y,
                                                      float* __restrict__ g, long beg, long n) {
@@ -350,6 +368,22 @@ int jtsm_relu_backward_split_f32(const float* dy, const float* y, float* g, uint
                      (const float4*)y, (float4*)g, reinterpret_cast<ew_bf16x8*>(g_hi), reinterpret_cast<ew_bf16x8*>(g_lo),
                      n8);
   JTSM_CHECK_LAUNCH("relu_backward_split");
+  return JTSM_OK;
+}
+
+int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
+                                 void* stream) {
+  JTSM_REQUIRE(n >= 0 && n % 8 == 0, "relu_backward_split_f16: n must be a non-negative multiple of 8");
+  JTSM_REQUIRE(shift >= 0 && shift <= 24, "relu_backward_split_f16: shift must be in 0..24");
+  if (n == 0) return JTSM_OK;
+  JTSM_REQUIRE(dy && y && g && g_h, "relu_backward_split_f16: null pointer");
+  JTSM_REQUIRE((((uintptr_t)dy | (uintptr_t)y | (uintptr_t)g | (uintptr_t)g_h) & 15) == 0,
+               "relu_backward_split_f16: pointers must be 16-byte aligned");
+  const long n8 = n / 8;
+  const int blocks = (int)((n8 + 255) / 256 < 8192 ? (n8 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(relu_bwd_split_f16_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), (const float4*)dy,
+                     (const float4*)y, (float4*)g, reinterpret_cast<ew_f16x8*>(g_h), n8, shift);
+  JTSM_CHECK_LAUNCH("relu_backward_split_f16");
   return JTSM_OK;
 }
 

@@ -24,36 +24,57 @@ LAUNCH_LOG = None
 
 # Contraction arithmetic: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 (three bf16 MFMA products per fp32
 # product, fp32 accumulate, ~2^-16 relative error per product) for every eligible forward / data-gradient
-# contraction.  See csrc/conv_x3.h.
+# contraction; "f16" = ONE fp16 plane per operand, one fp16 MFMA product, fp32 accumulate and fp32 results
+# (BASELINE configs[4]; ~2^-11 relative error per operand — NOT inside the 1e-4 parity bar, never the headline).
+# See csrc/conv_x3.h.
 MATH = os.environ.get("JTSM_CONV_MATH", "bf16x3")
+_MODES = ("f32", "bf16x3", "f16")
+# fp16 mode: gradient planes are stored times 2^GRAD_SHIFT (exact) so small gradients stay clear of fp16's
+# subnormal range; the kernels undo it in the accumulator (include/jtsm_hip.h, "fp16 contractions")
+GRAD_SHIFT = int(os.environ.get("JTSM_F16_GRAD_SHIFT", "12"))
+
+
+def planes_mode():
+    """True when the contractions read operand planes (bf16 hi/lo pairs or one fp16 plane)."""
+    return MATH != "f32"
 
 
 def set_math(mode):
     global MATH
-    if mode not in ("f32", "bf16x3"):
-        raise ValueError("conv math must be 'f32' or 'bf16x3', got %r" % (mode,))
+    if mode not in _MODES:
+        raise ValueError("conv math must be one of %r, got %r" % (_MODES, mode))
+    if mode != MATH:   # cached planes are in the old mode's format
+        _drop_planes()
     MATH = mode
 
 
 def _planes_buf(n, device):
     n8 = (n + 7) // 8 * 8
+    if MATH == "f16":
+        return torch.empty(n8, dtype=torch.int16, device=device)   # one fp16 plane
     return torch.empty(2 * n8, dtype=torch.int16, device=device)   # hi plane, then lo plane (16-byte aligned)
 
 
 def _hl(buf):
-    """(hi, lo) device pointers of a planes buffer."""
+    """(hi, lo) device pointers of a planes buffer (lo is None for the single fp16 plane)."""
     if buf is None:
         return None, None
     p = buf.data_ptr()
+    if MATH == "f16":
+        return C.c_void_p(p), None
     return C.c_void_p(p), C.c_void_p(p + buf.numel())   # lo starts numel/2 int16 = numel bytes in
 
 
-def _split(t):
+def _split(t, grad=False):
     flat = t.permute(0, 2, 3, 1) if t.dim() == 4 else t
     if not flat.is_contiguous():
         raise RuntimeError("split_bf16: tensor must be channels_last (4-d) or contiguous")
     buf = _planes_buf(t.numel(), t.device)
     hi, lo = _hl(buf)
+    if MATH == "f16":
+        L.check(L.lib().jtsm_split_f16_f32(L.ptr(t), hi, C.c_long(t.numel()), GRAD_SHIFT if grad else 0, L.stream()),
+                "split_f16")
+        return buf
     L.check(L.lib().jtsm_split_bf16_f32(L.ptr(t), hi, lo, C.c_long(t.numel()), L.stream()), "split_bf16")
     return buf
 
@@ -65,13 +86,20 @@ def split_bf16(t):
     return buf[:t.numel()], buf[n8:n8 + t.numel()]
 
 
-def _split_transposed(w, row_scale=None):
+def _split_transposed_into(buf, w, row_scale):
     o, i, kh, kw = w.shape
-    buf = _planes_buf(w.numel(), w.device)
     hi, lo = _hl(buf)
-    L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(row_scale), hi, lo, o, kh * kw, i, L.stream()),
-            "split_bf16_transposed")
+    if MATH == "f16":
+        L.check(L.lib().jtsm_split_f16_transposed_f32(L.ptr(w), L.ptr(row_scale), hi, o, kh * kw, i, L.stream()),
+                "split_f16_transposed")
+    else:
+        L.check(L.lib().jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(row_scale), hi, lo, o, kh * kw, i, L.stream()),
+                "split_bf16_transposed")
     return buf
+
+
+def _split_transposed(w, row_scale=None):
+    return _split_transposed_into(_planes_buf(w.numel(), w.device), w, row_scale)
 
 
 def split_bf16_transposed(w, row_scale=None):
@@ -99,6 +127,15 @@ def planes_clear():
     refresh_weight_planes()
 
 
+def _drop_planes():
+    """Forget every cached plane (activations and weights): the arithmetic mode is changing."""
+    global _planes_bytes
+    _PLANES.clear()
+    _planes_bytes = 0
+    _WPLANES.clear()
+    _WTABLES.clear()
+
+
 def planes_put(t, buf):
     global _planes_bytes
     if _planes_bytes > _PLANES_MAX_BYTES:
@@ -109,12 +146,13 @@ def planes_put(t, buf):
     _planes_bytes += 8 * t.numel()
 
 
-def planes_of(t):
-    """Cached planes buffer of a tensor, splitting it now if nobody has."""
+def planes_of(t, grad=False):
+    """Cached planes buffer of a tensor, splitting it now if nobody has.  grad: the tensor is a gradient (fp16 mode
+    stores those planes times 2^GRAD_SHIFT; whoever registered planes for a gradient applied the same factor)."""
     e = _PLANES.get((t.data_ptr(), t.numel()))
     if e is not None and e[1] == t._version:
         return e[2]
-    buf = _split(t)
+    buf = _split(t, grad)
     planes_put(t, buf)
     return buf
 
@@ -131,8 +169,10 @@ _WTABLES = {}   # (transposed, tuple of entry keys) -> (device table, blocks): r
 
 
 def _cacheable_weight(w):
+    """Planes persist across steps only for real parameters (or views of one): under no_grad every temporary is a
+    leaf too, and caching those (concatenated / zero-padded / reshaped weights) would pin a fresh entry per call."""
     base = w._base if w._base is not None else w
-    return base.is_leaf and (w.dim() != 4 or w.permute(0, 2, 3, 1).is_contiguous())
+    return isinstance(base, torch.nn.Parameter) and (w.dim() != 4 or w.permute(0, 2, 3, 1).is_contiguous())
 
 
 def _weight_planes(w, transposed=False, scale=None):
@@ -154,9 +194,9 @@ def _weight_planes(w, transposed=False, scale=None):
     hi, lo = _hl(e.buf)
     lib = L.lib()
     if transposed:
-        o, i, kh, kw = w.shape
-        L.check(lib.jtsm_split_bf16_transposed_f32(L.ptr(w), L.ptr(scale), hi, lo, o, kh * kw, i, L.stream()),
-                "split_bf16_transposed")
+        _split_transposed_into(e.buf, w, scale)
+    elif MATH == "f16":
+        L.check(lib.jtsm_split_f16_f32(L.ptr(w), hi, C.c_long(w.numel()), 0, L.stream()), "split_f16")
     else:
         L.check(lib.jtsm_split_bf16_f32(L.ptr(w), hi, lo, C.c_long(w.numel()), L.stream()), "split_bf16")
     e.version = w._version
@@ -165,7 +205,7 @@ def _weight_planes(w, transposed=False, scale=None):
 
 def refresh_weight_planes():
     """Re-split every cached weight whose version moved, one launch per form."""
-    if MATH != "bf16x3" or not _WPLANES:
+    if MATH == "f32" or not _WPLANES:
         return
     for transposed in (False, True):
         stale = [(k, e) for k, e in _WPLANES.items() if e.transposed == transposed and e.version != e.w._version]
@@ -177,7 +217,7 @@ def refresh_weight_planes():
             rows, blocks = [], 0
             for _, e in stale:
                 hi = e.buf.data_ptr()
-                lo = hi + e.buf.numel()
+                lo = 0 if MATH == "f16" else hi + e.buf.numel()   # lo == 0: the record's fp16 plane goes to hi
                 if transposed:
                     o, i, kh, kw = e.w.shape
                     nb = ((i + 31) // 32) * ((o + 31) // 32) * kh * kw
@@ -379,15 +419,20 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
     nbytes = pl.ws[0]
     ws = _scratch(nbytes, x.device)
     lib = L.lib()
-    if MATH == "bf16x3" and pl.x3[0]:
+    if MATH != "f32" and pl.x3[0]:
         xh, xl = _hl(planes_of(x))
         wbuf = _weight_planes(w)
         wh, wl = _hl(wbuf)
         ybuf = _planes_buf(y.numel(), y.device) if (emit_planes and s.out_c % 8 == 0) else None
         yh, yl = _hl(ybuf)
-        L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
-            xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-            L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward_bf16x3")
+        if MATH == "f16":
+            L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f16(
+                xh, wh, L.ptr(y), yh, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
+                L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward_f16")
+        else:
+            L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
+                xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
+                L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward_bf16x3")
         if ybuf is not None:
             planes_put(y, ybuf)
         return y
@@ -411,18 +456,24 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     nbytes = pl.ws[1]
     ws = _scratch(nbytes, dy.device)
     lib = L.lib()
-    if MATH == "bf16x3" and pl.x3[1]:
-        gh, gl = _hl(planes_of(dy))
+    if MATH != "f32" and pl.x3[1]:
+        gh, gl = _hl(planes_of(dy, grad=True))
         wbuf = _weight_planes(w, True, kscale)   # the per-row scale rides along in the transposing split
         wh, wl = _hl(wbuf)
         scatter = s.kernel_h == 1 and s.kernel_w == 1 and s.pad == 0 and s.stride > 1 and accumulate is None and \
             relu_mask is None
         dbuf = _planes_buf(dx.numel(), dx.device) if (emit_planes and s.in_c % 8 == 0 and not scatter) else None
         dh, dl = _hl(dbuf)
-        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
-            gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws),
-            C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
-                "conv2d_backward_data_bf16x3")
+        if MATH == "f16":
+            L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_f16(
+                gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), GRAD_SHIFT, L.ptr(ws),
+                C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
+                    "conv2d_backward_data_f16")
+        else:
+            L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
+                gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws),
+                C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
+                    "conv2d_backward_data_bf16x3")
         if dbuf is not None:
             planes_put(dx, dbuf)
         return dx
@@ -439,17 +490,22 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     pl = _plan(x.shape, w_shape, stride, pad, dil)
     s = pl.s
     lib = L.lib()
-    if MATH == "bf16x3" and pl.x3[2]:
-        gh, gl = _hl(planes_of(dy))
+    if MATH != "f32" and pl.x3[2]:
+        gh, gl = _hl(planes_of(dy, grad=True))
         xh, xl = _hl(planes_of(x))
         fresh = out is None
         if fresh:   # deterministic slab kernel: writes every element, nothing to clear
             out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL)
         nbytes = pl.ws[2]
         ws = _scratch(nbytes, x.device)
-        L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
-            gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc), "conv2d_backward_weight_bf16x3")
+        if MATH == "f16":
+            L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_f16(
+                gh, xh, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes),
+                L.stream()), pl.desc), "conv2d_backward_weight_f16")
+        else:
+            L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
+                gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws), C.c_size_t(nbytes),
+                L.stream()), pl.desc), "conv2d_backward_weight_bf16x3")
         return out
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
@@ -481,7 +537,7 @@ class _ConvFused(Function):
 
         x, w, scale, y = ctx.saved_tensors
         stride, pad, dil, relu, bias_needs_grad, xs, ws = ctx.cfg
-        x3 = MATH == "bf16x3" and dy.shape[0] > 0 and dy.shape[1] % 8 == 0 and \
+        x3 = MATH != "f32" and dy.shape[0] > 0 and dy.shape[1] % 8 == 0 and \
             (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         if relu:
             g = relu_backward(dy, y, emit_planes=x3)   # one pass: gate, and the planes both gradients contract
@@ -493,7 +549,7 @@ class _ConvFused(Function):
         if ctx.needs_input_grad[0]:
             # fold the FrozenBN scale into the weight rows once (a few MB) so the data-gradient GEMM takes
             # the direct-to-LDS path, which cannot rescale operands on the fly
-            if MATH == "bf16x3":   # (ineligible shapes fall through to the fp32 kernel's own kscale path)
+            if MATH != "f32":   # (ineligible shapes fall through to the fp32 kernel's own kscale path)
                 dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale, emit_planes=ctx.emit_dx_planes)
             else:
                 w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)

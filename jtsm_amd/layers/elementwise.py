@@ -26,8 +26,12 @@ def relu_backward(dy, y, emit_planes=False):
         from . import conv
         buf = conv._planes_buf(n, y.device)
         hi, lo = conv._hl(buf)
-        L.check(L.lib().jtsm_relu_backward_split_f32(L.ptr(dy), L.ptr(y), L.ptr(g), hi, lo, C.c_long(n),
-                                                     L.stream()), "relu_backward_split")
+        if conv.MATH == "f16":
+            L.check(L.lib().jtsm_relu_backward_split_f16(L.ptr(dy), L.ptr(y), L.ptr(g), hi, C.c_long(n), conv.GRAD_SHIFT,
+                                                         L.stream()), "relu_backward_split_f16")
+        else:
+            L.check(L.lib().jtsm_relu_backward_split_f32(L.ptr(dy), L.ptr(y), L.ptr(g), hi, lo, C.c_long(n),
+                                                         L.stream()), "relu_backward_split")
         conv.planes_put(g, buf)
         return g
     L.check(L.lib().jtsm_relu_backward_f32(L.ptr(dy), L.ptr(y), L.ptr(g), C.c_long(n), L.stream()),

@@ -20,7 +20,7 @@ CL = torch.channels_last
 
 def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=None, emit_planes=False):
     """Data gradient through conv + FrozenBN scale (folded into the weight rows one way or the other)."""
-    if K.MATH == "bf16x3":
+    if K.MATH != "f32":
         return K.conv2d_backward_data(g, w, x_shape, stride, pad, dil, kscale=scale, accumulate=accumulate,
                                       relu_mask=relu_mask, emit_planes=emit_planes)
     w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
@@ -50,7 +50,7 @@ class _BottleneckFn(Function):
         x, y1, y2, y3, w1, s1, w2, s2, w3, s3, ws, ss = ctx.saved_tensors
         stride1, stride2, pad2, dil2, stride_s = ctx.cfg
         need = ctx.needs_input_grad
-        x3 = K.MATH == "bf16x3"
+        x3 = K.MATH != "f32"
         dx = dw1 = dw2 = dw3 = dws = None
         g3 = relu_backward(dy, y3, emit_planes=x3)                       # the block's own output gate
         if need[7]:

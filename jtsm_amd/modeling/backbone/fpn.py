@@ -1,9 +1,14 @@
-"""FPN — surface of detectron2/modeling/backbone/fpn.py:16-160 (FPN), :173-185 (LastLevelMaxPool),
-:209-229 (build_resnet_fpn_backbone).  Lateral / output convolutions are MFMA launches with the
-bias in the epilogue; the top-down `upsample x2 (nearest) + add` is one fused bandwidth kernel."""
+"""Feature pyramid behind the reference's names — API surface of detectron2/modeling/backbone/fpn.py (:16-160 FPN,
+:173-185 LastLevelMaxPool, :209-229 build_resnet_fpn_backbone): same constructor, module names
+(fpn_lateral{L}, fpn_output{L}) and output names (p{L}); the construction is this repo's own.
+
+MI355X mapping: lateral 1x1 and output 3x3 convolutions are MFMA launches with the bias in the epilogue; the
+top-down `nearest x2 + add` is one fused bandwidth kernel that also writes the merged map's operand planes for the
+3x3 that follows.  The pyramid is a list of levels (log2 stride, bottom-up feature, channels); forward walks it from
+the coarsest level down.
+"""
 import math
 
-import torch.nn.functional as F
 from torch import nn
 
 from ...layers.batch_norm import get_norm
@@ -22,81 +27,72 @@ def _xavier(conv):
         nn.init.constant_(conv.bias, 0)
 
 
-def _assert_strides_are_log2_contiguous(strides):
-    for i, stride in enumerate(strides[1:], 1):
-        assert stride == 2 * strides[i - 1], "Strides {} {} are not log2 contiguous".format(stride, strides[i - 1])
-
-
 class FPN(Backbone):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum"):
         super().__init__()
-        assert isinstance(bottom_up, Backbone)
-        assert in_features, in_features
-        input_shapes = bottom_up.output_shape()
-        strides = [input_shapes[f].stride for f in in_features]
-        in_channels_per_feature = [input_shapes[f].channels for f in in_features]
-        _assert_strides_are_log2_contiguous(strides)
-        lateral_convs, output_convs = [], []
-        use_bias = norm == ""
-        for idx, in_channels in enumerate(in_channels_per_feature):
-            lateral_conv = Conv2d(in_channels, out_channels, kernel_size=1, bias=use_bias,
-                                  norm=get_norm(norm, out_channels))
-            output_conv = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=use_bias,
-                                 norm=get_norm(norm, out_channels))
-            _xavier(lateral_conv)
-            _xavier(output_conv)
-            stage = int(math.log2(strides[idx]))
-            self.add_module("fpn_lateral{}".format(stage), lateral_conv)
-            self.add_module("fpn_output{}".format(stage), output_conv)
+        if not isinstance(bottom_up, Backbone):
+            raise TypeError("FPN: bottom_up must be a Backbone")
+        if not in_features:
+            raise ValueError("FPN: in_features is empty")
+        if fuse_type not in ("sum", "avg"):
+            raise ValueError("FPN: fuse_type must be 'sum' or 'avg', got %r" % (fuse_type,))
+        shapes = bottom_up.output_shape()
+        self.levels = []   # finest first: (L = log2 stride, bottom-up feature name)
+        for name in in_features:
+            stride = shapes[name].stride
+            level = int(math.log2(stride))
+            if self.levels and level != self.levels[-1][0] + 1:
+                raise ValueError("FPN: strides of %s must double from one feature to the next" % (list(in_features),))
+            self.levels.append((level, name))
+            bias = norm == ""
+            lateral = Conv2d(shapes[name].channels, out_channels, kernel_size=1, bias=bias,
+                             norm=get_norm(norm, out_channels))
+            output = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=bias,
+                            norm=get_norm(norm, out_channels))
             # the output conv's input gradient is (through the top-down add) the lateral conv's dy: let the
-            # data-gradient epilogue write its bf16 planes for that contraction
-            output_conv.emit_dx_planes = True
-            lateral_convs.append(lateral_conv)
-            output_convs.append(output_conv)
-        # top-down order: coarsest level first
-        self.lateral_convs = lateral_convs[::-1]
-        self.output_convs = output_convs[::-1]
-        self.top_block = top_block
-        self.in_features = in_features
-        self.bottom_up = bottom_up
-        self._out_feature_strides = {"p{}".format(int(math.log2(s))): s for s in strides}
-        if self.top_block is not None:
-            for s in range(stage, stage + self.top_block.num_levels):
-                self._out_feature_strides["p{}".format(s + 1)] = 2 ** (s + 1)
-        self._out_features = list(self._out_feature_strides.keys())
-        self._out_feature_channels = {k: out_channels for k in self._out_features}
-        self._size_divisibility = strides[-1]
-        assert fuse_type in {"avg", "sum"}
+            # data-gradient epilogue write its operand planes for that contraction
+            output.emit_dx_planes = True
+            for conv, kind in ((lateral, "lateral"), (output, "output")):
+                _xavier(conv)
+                self.add_module("fpn_%s%d" % (kind, level), conv)
+        self.bottom_up, self.in_features, self.top_block = bottom_up, in_features, top_block
         self._fuse_type = fuse_type
+        names = ["p%d" % lv for lv, _ in self.levels]
+        strides = {"p%d" % lv: 2 ** lv for lv, _ in self.levels}
+        if top_block is not None:
+            top = self.levels[-1][0]
+            for extra in range(1, top_block.num_levels + 1):
+                names.append("p%d" % (top + extra))
+                strides[names[-1]] = 2 ** (top + extra)
+        self._declare_outputs(names, {n: out_channels for n in names}, strides)
+        self._size_divisibility = 2 ** self.levels[-1][0]
 
     @property
     def size_divisibility(self):
         return self._size_divisibility
 
     def forward(self, x):
-        bottom_up_features = self.bottom_up(x)
-        feats = [bottom_up_features[f] for f in self.in_features[::-1]]
-        results = []
-        prev_features = self.lateral_convs[0](feats[0])
-        results.append(self.output_convs[0](prev_features))
-        for features, lateral_conv, output_conv in zip(feats[1:], self.lateral_convs[1:], self.output_convs[1:]):
-            lateral_features = lateral_conv(features)
-            prev_features = upsample2_add(prev_features, lateral_features)   # nearest x2 + add, one pass
-            if self._fuse_type == "avg":
-                prev_features = prev_features / 2
-            results.insert(0, output_conv(prev_features))
-        if self.top_block is not None:
-            if self.top_block.in_feature in bottom_up_features:
-                top_block_in_feature = bottom_up_features[self.top_block.in_feature]
+        feats = self.bottom_up(x)
+        out, merged = {}, None
+        for level, name in reversed(self.levels):            # coarsest level first
+            lateral = getattr(self, "fpn_lateral%d" % level)(feats[name])
+            if merged is None:
+                merged = lateral
             else:
-                top_block_in_feature = results[self._out_features.index(self.top_block.in_feature)]
-            results.extend(self.top_block(top_block_in_feature))
-        assert len(self._out_features) == len(results)
-        return dict(zip(self._out_features, results))
+                merged = upsample2_add(merged, lateral)      # nearest x2 + add, one pass
+                if self._fuse_type == "avg":
+                    merged = merged / 2
+            out["p%d" % level] = getattr(self, "fpn_output%d" % level)(merged)
+        if self.top_block is not None:
+            src = self.top_block.in_feature
+            extra = self.top_block(feats[src] if src in feats else out[src])
+            for i, t in enumerate(extra, start=1):
+                out["p%d" % (self.levels[-1][0] + i)] = t
+        return {n: out[n] for n in self._out_features}
 
     def output_shape(self):
-        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
-                for name in self._out_features}
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+                for n in self._out_features}
 
 
 class LastLevelMaxPool(nn.Module):
@@ -111,8 +107,19 @@ class LastLevelMaxPool(nn.Module):
         return [subsample2(x)]
 
 
+def fpn_from_cfg(cfg, bottom_up):
+    f = cfg.MODEL.FPN
+    return FPN(bottom_up=bottom_up, in_features=f.IN_FEATURES, out_channels=f.OUT_CHANNELS, norm=f.NORM,
+               top_block=LastLevelMaxPool(), fuse_type=f.FUSE_TYPE)
+
+
 @BACKBONE_REGISTRY.register()
 def build_resnet_fpn_backbone(cfg, input_shape: ShapeSpec):
-    bottom_up = build_resnet_backbone(cfg, input_shape)
-    return FPN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS,
-               norm=cfg.MODEL.FPN.NORM, top_block=LastLevelMaxPool(), fuse_type=cfg.MODEL.FPN.FUSE_TYPE)
+    return fpn_from_cfg(cfg, build_resnet_backbone(cfg, input_shape))
+
+
+@BACKBONE_REGISTRY.register()
+def build_wsl_resnet_v2_fpn_backbone(cfg, input_shape: ShapeSpec):
+    """projects/WSL/wsl/modeling/backbone/resnet_wsl_v2.py:729-750."""
+    from .resnet_wsl_v2 import build_wsl_resnet_v2_backbone
+    return fpn_from_cfg(cfg, build_wsl_resnet_v2_backbone(cfg, input_shape))

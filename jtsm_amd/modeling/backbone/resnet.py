@@ -1,10 +1,12 @@
-"""ResNet bottom-up — surface of detectron2/modeling/backbone/resnet.py:101-211 (BottleneckBlock),
-:331-359 (BasicStem), :362-479 (ResNet), :562-648 (build_resnet_backbone).
+"""ResNet bottom-up behind the reference's names — API surface of detectron2/modeling/backbone/resnet.py
+(:26-98 BasicBlock, :101-211 BottleneckBlock, :331-359 BasicStem, :362-479 ResNet, :562-648 build_resnet_backbone):
+same class names, constructor keywords, module names (stem.conv1, resN.K.convM / shortcut) and therefore the same
+state_dict keys; everything else is this repo's own construction.
 
-MI355X mapping: every conv+FrozenBN(+ReLU) is one implicit-GEMM launch; the block's
-`out += shortcut; relu` rides in conv3's epilogue (residual operand), so a bottleneck is 3 launches
-(4 with a projection shortcut) and writes each activation exactly once.  Activations are
-channels_last throughout.
+MI355X mapping: every conv + FrozenBN (+ ReLU) (+ shortcut add) is ONE implicit-GEMM launch (layers/wrappers.py);
+a whole residual block is one autograd node whenever its norms are frozen (layers/fused_blocks.py), so the ReLU
+gates and the two-path gradient sum ride in data-gradient epilogues.  Activations are channels_last throughout.
+A network is described by a small table (blocks per stage, first stride, dilation) and built by one loop.
 """
 import torch
 import torch.nn.functional as F
@@ -14,10 +16,13 @@ from ...layers.batch_norm import FrozenBatchNorm2d, get_norm
 from ...layers.blocks import CNNBlockBase
 from ...layers.elementwise import max_pool_3x3_s2
 from ...layers.fused_blocks import bottleneck_fused
-from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d
 from .backbone import Backbone
 from .build import BACKBONE_REGISTRY
+
+# blocks in res2..res5 per depth; depths below 50 use the two-conv BasicBlock
+BLOCKS_PER_STAGE = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3), 152: (3, 8, 36, 3)}
+_STAGE_NUMBER = {"res2": 2, "res3": 3, "res4": 4, "res5": 5}
 
 
 def _msra(conv):
@@ -27,36 +32,56 @@ def _msra(conv):
         nn.init.constant_(conv.bias, 0)
 
 
+def conv_norm(cin, cout, k, norm, *, stride=1, dilation=1, relu=False):
+    """Bias-free k x k convolution ('same' padding for its dilation) + norm (+ ReLU), msra-initialised."""
+    conv = Conv2d(cin, cout, kernel_size=k, stride=stride, padding=(k // 2) * dilation, dilation=dilation, bias=False,
+                  norm=get_norm(norm, cout), activation=F.relu if relu else None)
+    _msra(conv)
+    return conv
+
+
+def _all_frozen(convs):
+    return all(isinstance(c.norm, FrozenBatchNorm2d) and c.bias is None for c in convs)
+
+
+class BasicBlock(CNNBlockBase):
+    """Two 3x3 convolutions + (projection) shortcut — ResNet-18/34 (resnet.py:26-98)."""
+
+    def __init__(self, in_channels, out_channels, *, stride=1, norm="BN"):
+        super().__init__(in_channels, out_channels, stride)
+        self.shortcut = None
+        if in_channels != out_channels:
+            self.shortcut = conv_norm(in_channels, out_channels, 1, norm, stride=stride)
+        self.conv1 = conv_norm(in_channels, out_channels, 3, norm, stride=stride, relu=True)
+        self.conv2 = conv_norm(out_channels, out_channels, 3, norm, relu=True)   # ReLU after the shortcut add
+
+    def forward(self, x):
+        skip = x if self.shortcut is None else self.shortcut(x)
+        return self.conv2(self.conv1(x), residual=skip)
+
+
 class BottleneckBlock(CNNBlockBase):
+    """1x1 -> 3x3 -> 1x1 + (projection) shortcut — ResNet-50/101/152 (resnet.py:101-211)."""
+
     def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
                  stride_in_1x1=False, dilation=1):
         super().__init__(in_channels, out_channels, stride)
         if num_groups != 1:
             raise NotImplementedError("jtsm_amd BottleneckBlock: num_groups=1 only")
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        mid = bottleneck_channels
+        self.shortcut = None
         if in_channels != out_channels:
-            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=stride, bias=False,
-                                   norm=get_norm(norm, out_channels))
-        else:
-            self.shortcut = None
-        stride_1x1, stride_3x3 = (stride, 1) if stride_in_1x1 else (1, stride)
-        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=stride_1x1, bias=False,
-                            norm=get_norm(norm, bottleneck_channels), activation=F.relu)
-        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=stride_3x3,
-                            padding=1 * dilation, bias=False, groups=num_groups, dilation=dilation,
-                            norm=get_norm(norm, bottleneck_channels), activation=F.relu)
-        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
-                            norm=get_norm(norm, out_channels), activation=F.relu)
-        for layer in [self.conv1, self.conv2, self.conv3, self.shortcut]:
-            if layer is not None:
-                _msra(layer)
+            self.shortcut = conv_norm(in_channels, out_channels, 1, norm, stride=stride)
+        self.conv1 = conv_norm(in_channels, mid, 1, norm, stride=s1, relu=True)
+        self.conv2 = conv_norm(mid, mid, 3, norm, stride=s3, dilation=dilation, relu=True)
+        self.conv3 = conv_norm(mid, out_channels, 1, norm, relu=True)           # ReLU after the shortcut add
 
-    def _fusable(self, x):
-        convs = [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
-        return (x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and
-                all(isinstance(c.norm, FrozenBatchNorm2d) and c.bias is None for c in convs))
+    def _members(self):
+        return [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
 
     def forward(self, x):
-        if self._fusable(x):
+        if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and _all_frozen(self._members()):
             # one autograd node for the block: ReLU gates and the two-path sum ride in the data-gradient epilogues
             sc = self.shortcut
             return bottleneck_fused(
@@ -64,126 +89,133 @@ class BottleneckBlock(CNNBlockBase):
                 self.conv3.weight, self.conv3.norm.scale_bias(), sc.weight if sc is not None else None,
                 sc.norm.scale_bias() if sc is not None else None, self.conv1.stride[0], self.conv2.stride[0],
                 self.conv2.padding[0], self.conv2.dilation[0], sc.stride[0] if sc is not None else 1)
-        out = self.conv1(x)
-        out = self.conv2(out)
-        shortcut = self.shortcut(x) if self.shortcut is not None else x
-        return self.conv3(out, residual=shortcut)   # relu(bn(conv3(out)) + shortcut)
+        skip = x if self.shortcut is None else self.shortcut(x)
+        return self.conv3(self.conv2(self.conv1(x)), residual=skip)   # relu(bn(conv3(.)) + skip)
 
 
 class BasicStem(CNNBlockBase):
+    """7x7 stride-2 convolution + norm + ReLU, then max-pool 3x3 stride 2: stride 4 (resnet.py:331-359)."""
+
     def __init__(self, in_channels=3, out_channels=64, norm="BN"):
         super().__init__(in_channels, out_channels, 4)
         self.in_channels = in_channels
-        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=7, stride=2, padding=3, bias=False,
-                            norm=get_norm(norm, out_channels), activation=F.relu)
-        _msra(self.conv1)
+        self.conv1 = conv_norm(in_channels, out_channels, 7, norm, stride=2, relu=True)
 
     def forward(self, x):
         return max_pool_3x3_s2(self.conv1(x))
 
 
 class ResNet(Backbone):
+    """stem, then stages `res2`, `res3`, ...; returns the requested subset of {"stem", "res2", ...}."""
+
     def __init__(self, stem, stages, num_classes=None, out_features=None):
         super().__init__()
-        assert num_classes is None, "classification head is outside the JTSM path"
+        if num_classes is not None:
+            raise NotImplementedError("the classification head is outside the JTSM path")
         self.stem = stem
-        current_stride = self.stem.stride
-        self._out_feature_strides = {"stem": current_stride}
-        self._out_feature_channels = {"stem": self.stem.out_channels}
-        self.stage_names, self.stages = [], []
-        for i, blocks in enumerate(stages):
-            assert len(blocks) > 0, len(blocks)
-            name = "res" + str(i + 2)
-            stage = nn.Sequential(*blocks)
-            self.add_module(name, stage)
-            self.stage_names.append(name)
-            self.stages.append(stage)
-            current_stride = int(current_stride * torch.tensor([k.stride for k in blocks]).prod().item())
-            self._out_feature_strides[name] = current_stride
-            self._out_feature_channels[name] = blocks[-1].out_channels
-        self.stage_names = tuple(self.stage_names)
-        if out_features is None:
-            out_features = [name]
-        self._out_features = out_features
-        assert len(self._out_features)
-        children = [x[0] for x in self.named_children()]
-        for f in self._out_features:
-            assert f in children, "Available children: {}".format(", ".join(children))
+        channels, strides = {"stem": stem.out_channels}, {"stem": stem.stride}
+        stride, order = stem.stride, []
+        for number, blocks in enumerate(stages, start=2):
+            blocks = list(blocks)
+            if not blocks:
+                raise ValueError("ResNet: stage res%d has no blocks" % number)
+            name = "res%d" % number
+            self.add_module(name, nn.Sequential(*blocks))
+            for b in blocks:
+                stride *= b.stride
+            channels[name], strides[name] = blocks[-1].out_channels, stride
+            order.append(name)
+        self.stage_names = tuple(order)
+        wanted = list(out_features) if out_features else [order[-1]]
+        unknown = [f for f in wanted if f not in channels]
+        if unknown:
+            raise ValueError("ResNet: unknown out_features %s (have %s)" % (unknown, sorted(channels)))
+        self._declare_outputs(wanted, {f: channels[f] for f in wanted}, {f: strides[f] for f in wanted})
+
+    @property
+    def stages(self):
+        return [getattr(self, n) for n in self.stage_names]
 
     def forward(self, x):
-        assert x.dim() == 4, "ResNet takes an input of shape (N, C, H, W). Got {} instead!".format(x.shape)
-        outputs = {}
+        if x.dim() != 4:
+            raise ValueError("ResNet takes an input of shape (N, C, H, W), got %s" % (tuple(x.shape),))
+        keep = set(self._out_features)
+        out = {}
         x = self.stem(x)
-        if "stem" in self._out_features:
-            outputs["stem"] = x
-        for name, stage in zip(self.stage_names, self.stages):
-            x = stage(x)
-            if name in self._out_features:
-                outputs[name] = x
-        return outputs
+        if "stem" in keep:
+            out["stem"] = x
+        for name in self.stage_names:
+            x = getattr(self, name)(x)
+            if name in keep:
+                out[name] = x
+        return out
 
     def freeze(self, freeze_at=0):
-        """freeze_at=1 freezes the stem, 2 also res2, ... (resnet.py:457-479)."""
+        """freeze_at = 1 freezes the stem, 2 also res2, ... (resnet.py:457-479)."""
         if freeze_at >= 1:
             self.stem.freeze()
-        for idx, stage in enumerate(self.stages, start=2):
-            if freeze_at >= idx:
-                for block in stage.children():
+        for name in self.stage_names:
+            if freeze_at >= _STAGE_NUMBER[name]:
+                for block in getattr(self, name).children():
                     block.freeze()
         return self
 
     @staticmethod
     def make_stage(block_class, num_blocks, first_stride=None, *, in_channels, out_channels, **kwargs):
+        """`num_blocks` blocks of `block_class`; keyword `foo_per_block=[...]` gives block i its own `foo`."""
         if first_stride is not None:
-            assert "stride" not in kwargs and "stride_per_block" not in kwargs
+            if "stride" in kwargs or "stride_per_block" in kwargs:
+                raise ValueError("make_stage: give first_stride or stride(_per_block), not both")
             kwargs["stride_per_block"] = [first_stride] + [1] * (num_blocks - 1)
-        blocks = []
+        suffix = "_per_block"
+        varying = {k[:-len(suffix)]: v for k, v in kwargs.items() if k.endswith(suffix)}
+        shared = {k: v for k, v in kwargs.items() if not k.endswith(suffix)}
+        for k, v in varying.items():
+            if len(v) != num_blocks:
+                raise ValueError("make_stage: %s%s has %d entries for %d blocks" % (k, suffix, len(v), num_blocks))
+        blocks, cin = [], in_channels
         for i in range(num_blocks):
-            curr = {}
-            for k, v in kwargs.items():
-                if k.endswith("_per_block"):
-                    assert len(v) == num_blocks
-                    curr[k[: -len("_per_block")]] = v[i]
-                else:
-                    curr[k] = v
-            blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, **curr))
-            in_channels = out_channels
+            blocks.append(block_class(in_channels=cin, out_channels=out_channels, **shared,
+                                      **{k: v[i] for k, v in varying.items()}))
+            cin = out_channels
         return blocks
+
+
+def resnet_cfg(cfg):
+    """The MODEL.RESNETS keys every ResNet builder reads, validated once."""
+    r = cfg.MODEL.RESNETS
+    if r.DEPTH not in BLOCKS_PER_STAGE:
+        raise ValueError("MODEL.RESNETS.DEPTH must be one of %s, got %r" % (sorted(BLOCKS_PER_STAGE), r.DEPTH))
+    if any(r.DEFORM_ON_PER_STAGE):
+        raise NotImplementedError("deformable conv is outside the JTSM path (SURVEY 2.1)")
+    assert r.RES5_DILATION in {1, 2}, "res5_dilation cannot be {}.".format(r.RES5_DILATION)
+    if r.DEPTH in (18, 34):
+        assert r.RES2_OUT_CHANNELS == 64, "Must set MODEL.RESNETS.RES2_OUT_CHANNELS = 64 for R18/R34"
+        assert r.NUM_GROUPS == 1, "Must set MODEL.RESNETS.NUM_GROUPS = 1 for R18/R34"
+    last = max(_STAGE_NUMBER[f] for f in r.OUT_FEATURES if f != "stem")
+    return r, BLOCKS_PER_STAGE[r.DEPTH][:last - 1]
 
 
 @BACKBONE_REGISTRY.register()
 def build_resnet_backbone(cfg, input_shape):
-    """cfg keys as at resnet.py:562-648 (depth 50/101/152, bottleneck only)."""
-    norm = cfg.MODEL.RESNETS.NORM
-    stem = BasicStem(in_channels=input_shape.channels, out_channels=cfg.MODEL.RESNETS.STEM_OUT_CHANNELS, norm=norm)
-    freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
-    out_features = cfg.MODEL.RESNETS.OUT_FEATURES
-    depth = cfg.MODEL.RESNETS.DEPTH
-    num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
-    width_per_group = cfg.MODEL.RESNETS.WIDTH_PER_GROUP
-    bottleneck_channels = num_groups * width_per_group
-    in_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
-    out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
-    stride_in_1x1 = cfg.MODEL.RESNETS.STRIDE_IN_1X1
-    res5_dilation = cfg.MODEL.RESNETS.RES5_DILATION
-    assert res5_dilation in {1, 2}, "res5_dilation cannot be {}.".format(res5_dilation)
-    if depth not in (50, 101, 152):
-        raise NotImplementedError("jtsm_amd build_resnet_backbone: bottleneck depths 50/101/152")
-    if any(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE):
-        raise NotImplementedError("deformable conv is outside the JTSM path (SURVEY 2.1)")
-    num_blocks_per_stage = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
+    """cfg keys as at resnet.py:562-648.  Stage table: res2 keeps the stem's stride, every later stage halves the
+    map in its first block — except a dilated res5 (DC5), which keeps res4's stride and dilates its 3x3s by 2."""
+    r, counts = resnet_cfg(cfg)
+    basic = r.DEPTH in (18, 34)
+    if basic:
+        assert r.RES5_DILATION == 1, "Must set MODEL.RESNETS.RES5_DILATION = 1 for R18/R34"
+    stem = BasicStem(in_channels=input_shape.channels, out_channels=r.STEM_OUT_CHANNELS, norm=r.NORM)
+    cin, cout, mid = r.STEM_OUT_CHANNELS, r.RES2_OUT_CHANNELS, r.NUM_GROUPS * r.WIDTH_PER_GROUP
     stages = []
-    out_stage_idx = [{"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features if f != "stem"]
-    max_stage_idx = max(out_stage_idx)
-    for idx, stage_idx in enumerate(range(2, max_stage_idx + 1)):
-        dilation = res5_dilation if stage_idx == 5 else 1
-        first_stride = 1 if idx == 0 or (stage_idx == 5 and dilation == 2) else 2
-        blocks = ResNet.make_stage(
-            BottleneckBlock, num_blocks_per_stage[idx], first_stride, in_channels=in_channels,
-            out_channels=out_channels, norm=norm, bottleneck_channels=bottleneck_channels,
-            stride_in_1x1=stride_in_1x1, dilation=dilation, num_groups=num_groups)
-        in_channels = out_channels
-        out_channels *= 2
-        bottleneck_channels *= 2
-        stages.append(blocks)
-    return ResNet(stem, stages, out_features=out_features).freeze(freeze_at)
+    for number, n in enumerate(counts, start=2):
+        dilated = number == 5 and r.RES5_DILATION == 2
+        first_stride = 1 if (number == 2 or dilated) else 2
+        if basic:
+            stage = ResNet.make_stage(BasicBlock, n, first_stride, in_channels=cin, out_channels=cout, norm=r.NORM)
+        else:
+            stage = ResNet.make_stage(BottleneckBlock, n, first_stride, in_channels=cin, out_channels=cout,
+                                      norm=r.NORM, bottleneck_channels=mid, stride_in_1x1=r.STRIDE_IN_1X1,
+                                      dilation=2 if dilated else 1, num_groups=r.NUM_GROUPS)
+        stages.append(stage)
+        cin, cout, mid = cout, cout * 2, mid * 2
+    return ResNet(stem, stages, out_features=r.OUT_FEATURES).freeze(cfg.MODEL.BACKBONE.FREEZE_AT)

@@ -1,6 +1,7 @@
 """ResNet-WS v2 ("WSR") bottom-up — the backbone the shipped JTSM configs name:
-surface of projects/WSL/wsl/modeling/backbone/resnet_wsl_v2.py:122-251 (BottleneckBlock with an optional 2x2
-max-pool in front), :370-429 (three-conv stem), :638-726 (build_wsl_resnet_v2_backbone).
+surface of projects/WSL/wsl/modeling/backbone/resnet_wsl_v2.py:33-119 (BasicBlock, depths 18 / 34) and :122-251
+(BottleneckBlock), both with an optional 2x2 max-pool in front, :370-429 (three-conv stem), :638-726
+(build_wsl_resnet_v2_backbone).
 
 What differs from the Base-RCNN ResNet (backbone/resnet.py):
   * the stem is three 3x3 convolutions (the first with stride 2) + MaxPool2d(2, 2);
@@ -14,67 +15,81 @@ MI355X mapping: identical to resnet.py — every conv+FrozenBN(+ReLU)(+shortcut)
 training step this is a forward-only feature extractor."""
 import torch.nn.functional as F
 
-from ...layers.batch_norm import FrozenBatchNorm2d, get_norm
 from ...layers.blocks import CNNBlockBase
 from ...layers.elementwise import max_pool_2x2
 from ...layers.fused_blocks import bottleneck_fused
-from ...layers.wrappers import Conv2d
 from .build import BACKBONE_REGISTRY
-from .resnet import ResNet, _msra
+from .resnet import ResNet, _all_frozen, conv_norm, resnet_cfg
 
 
-class PooledBottleneckBlock(CNNBlockBase):
-    """1x1 -> 3x3 -> 1x1 (+ projection shortcut), all stride 1; `stride` is spent in a max-pool of the input."""
+class _PooledBlock(CNNBlockBase):
+    """A residual block none of whose convolutions is strided: `stride` is spent in a max-pool of the block INPUT
+    (2x2 stride 2, or — stride 1, dilated stages — pad right/bottom by one and pool 2x2 stride 1)."""
+
+    def __init__(self, in_channels, out_channels, stride, has_pool):
+        super().__init__(in_channels, out_channels, stride)
+        self.has_pool, self.pool_stride = has_pool, stride
+
+    def pooled(self, x):
+        return max_pool_2x2(x, self.pool_stride) if self.has_pool else x
+
+
+class PooledBasicBlock(_PooledBlock):
+    """3x3 -> 3x3 (+ projection shortcut): ResNet-WS 18 / 34 (resnet_wsl_v2.py:33-119).  Two launches (three with a
+    projection): the shortcut add and the final ReLU ride in conv2's epilogue."""
+
+    def __init__(self, in_channels, out_channels, *, stride=1, norm="BN", dilation=1, has_pool=False):
+        super().__init__(in_channels, out_channels, stride, has_pool)
+        self.shortcut = None
+        if in_channels != out_channels:
+            self.shortcut = conv_norm(in_channels, out_channels, 1, norm)
+        self.conv1 = conv_norm(in_channels, out_channels, 3, norm, dilation=dilation, relu=True)
+        self.conv2 = conv_norm(out_channels, out_channels, 3, norm, dilation=dilation, relu=True)
+
+    def forward(self, x):
+        x = self.pooled(x)
+        skip = x if self.shortcut is None else self.shortcut(x)
+        return self.conv2(self.conv1(x), residual=skip)
+
+
+class PooledBottleneckBlock(_PooledBlock):
+    """1x1 -> 3x3 -> 1x1 (+ projection shortcut), all stride 1 (resnet_wsl_v2.py:122-251)."""
 
     def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
                  stride_in_1x1=False, dilation=1, has_pool=False):
-        super().__init__(in_channels, out_channels, stride)
+        super().__init__(in_channels, out_channels, stride, has_pool)
         if num_groups != 1:
             raise NotImplementedError("jtsm_amd PooledBottleneckBlock: num_groups=1 only")
-        self.has_pool, self.pool_stride = has_pool, stride
+        mid = bottleneck_channels
+        self.shortcut = None
         if in_channels != out_channels:
-            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False,
-                                   norm=get_norm(norm, out_channels))
-        else:
-            self.shortcut = None
-        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, bias=False,
-                            norm=get_norm(norm, bottleneck_channels), activation=F.relu)
-        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, padding=dilation, bias=False,
-                            dilation=dilation, norm=get_norm(norm, bottleneck_channels), activation=F.relu)
-        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
-                            norm=get_norm(norm, out_channels), activation=F.relu)
-        for layer in (self.conv1, self.conv2, self.conv3, self.shortcut):
-            if layer is not None:
-                _msra(layer)
+            self.shortcut = conv_norm(in_channels, out_channels, 1, norm)
+        self.conv1 = conv_norm(in_channels, mid, 1, norm, relu=True)
+        self.conv2 = conv_norm(mid, mid, 3, norm, dilation=dilation, relu=True)
+        self.conv3 = conv_norm(mid, out_channels, 1, norm, relu=True)
 
     def forward(self, x):
-        if self.has_pool:
-            x = max_pool_2x2(x, self.pool_stride)
-        convs = [self.conv1, self.conv2, self.conv3] + ([self.shortcut] if self.shortcut is not None else [])
-        if x.is_cuda and x.shape[1] % 8 == 0 and all(isinstance(c.norm, FrozenBatchNorm2d) for c in convs):
+        x = self.pooled(x)
+        convs = [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
+        if x.is_cuda and x.shape[1] % 8 == 0 and _all_frozen(convs):
             sc = self.shortcut
             return bottleneck_fused(
                 x, self.conv1.weight, self.conv1.norm.scale_bias(), self.conv2.weight, self.conv2.norm.scale_bias(),
                 self.conv3.weight, self.conv3.norm.scale_bias(), sc.weight if sc is not None else None,
                 sc.norm.scale_bias() if sc is not None else None, 1, 1, self.conv2.padding[0], self.conv2.dilation[0], 1)
-        out = self.conv2(self.conv1(x))
-        return self.conv3(out, residual=self.shortcut(x) if self.shortcut is not None else x)
+        skip = x if self.shortcut is None else self.shortcut(x)
+        return self.conv3(self.conv2(self.conv1(x)), residual=skip)
 
 
 class ThreeConvStem(CNNBlockBase):
-    """conv3x3/2 -> conv3x3 -> conv3x3 (each + norm + ReLU) -> MaxPool2d(2, 2): stride 4."""
+    """conv3x3/2 -> conv3x3 -> conv3x3 (each + norm + ReLU) -> MaxPool2d(2, 2): stride 4 (resnet_wsl_v2.py:370-429)."""
 
     def __init__(self, in_channels=3, out_channels=64, norm="BN"):
         super().__init__(in_channels, out_channels, 4)
         self.in_channels = in_channels
-        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False,
-                            norm=get_norm(norm, out_channels), activation=F.relu)
-        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False,
-                            norm=get_norm(norm, out_channels), activation=F.relu)
-        self.conv3 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False,
-                            norm=get_norm(norm, out_channels), activation=F.relu)
-        for layer in (self.conv1, self.conv2, self.conv3):
-            _msra(layer)
+        self.conv1 = conv_norm(in_channels, out_channels, 3, norm, stride=2, relu=True)
+        self.conv2 = conv_norm(out_channels, out_channels, 3, norm, relu=True)
+        self.conv3 = conv_norm(out_channels, out_channels, 3, norm, relu=True)
 
     def forward(self, x):
         return max_pool_2x2(self.conv3(self.conv2(self.conv1(x))), 2)
@@ -82,34 +97,24 @@ class ThreeConvStem(CNNBlockBase):
 
 @BACKBONE_REGISTRY.register()
 def build_wsl_resnet_v2_backbone(cfg, input_shape):
-    """cfg keys as at resnet_wsl_v2.py:638-726 (bottleneck depths; no deformable stages)."""
-    norm = cfg.MODEL.RESNETS.NORM
-    stem = ThreeConvStem(in_channels=input_shape.channels, out_channels=cfg.MODEL.RESNETS.STEM_OUT_CHANNELS, norm=norm)
-    depth = cfg.MODEL.RESNETS.DEPTH
-    if depth not in (50, 101, 152):
-        raise NotImplementedError("jtsm_amd build_wsl_resnet_v2_backbone: bottleneck depths 50/101/152")
-    if any(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE):
-        raise NotImplementedError("deformable conv is outside the JTSM path (SURVEY 2.1)")
-    num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
-    bottleneck_channels = num_groups * cfg.MODEL.RESNETS.WIDTH_PER_GROUP
-    in_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
-    out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
-    res5_dilation = cfg.MODEL.RESNETS.RES5_DILATION
-    assert res5_dilation in {1, 2}, "res5_dilation cannot be {}.".format(res5_dilation)
-    out_features = cfg.MODEL.RESNETS.OUT_FEATURES
-    blocks_per_stage = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
-    last = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features if f != "stem")
+    """cfg keys as at resnet_wsl_v2.py:638-726 (no deformable stages).  Stage table: res3 halves the map through its
+    first block's pool; res4 does too unless RES5_DILATION is 2, in which case res4 AND res5 dilate their 3x3s by 2
+    and res4's pool runs at stride 1 (the DC5 configs: stride-8 output); res5 never pools."""
+    r, counts = resnet_cfg(cfg)
+    basic = r.DEPTH in (18, 34)
+    stem = ThreeConvStem(in_channels=input_shape.channels, out_channels=r.STEM_OUT_CHANNELS, norm=r.NORM)
+    cin, cout, mid = r.STEM_OUT_CHANNELS, r.RES2_OUT_CHANNELS, r.NUM_GROUPS * r.WIDTH_PER_GROUP
     stages = []
-    for idx, stage in enumerate(range(2, last + 1)):
-        n = blocks_per_stage[idx]
-        dilation = res5_dilation if stage in (4, 5) else 1
-        first_stride = 2 if stage == 3 or (stage == 4 and res5_dilation == 1) else 1
-        stages.append(ResNet.make_stage(
-            PooledBottleneckBlock, n, in_channels=in_channels, out_channels=out_channels, norm=norm,
-            bottleneck_channels=bottleneck_channels, stride_in_1x1=cfg.MODEL.RESNETS.STRIDE_IN_1X1, dilation=dilation,
-            num_groups=num_groups, stride_per_block=[first_stride] + [1] * (n - 1),
-            has_pool_per_block=[stage in (3, 4)] + [False] * (n - 1)))
-        in_channels = out_channels
-        out_channels *= 2
-        bottleneck_channels *= 2
-    return ResNet(stem, stages, out_features=out_features).freeze(cfg.MODEL.BACKBONE.FREEZE_AT)
+    for number, n in enumerate(counts, start=2):
+        dilation = r.RES5_DILATION if number in (4, 5) else 1
+        first_stride = 2 if number == 3 or (number == 4 and r.RES5_DILATION == 1) else 1
+        common = dict(in_channels=cin, out_channels=cout, norm=r.NORM, dilation=dilation,
+                      stride_per_block=[first_stride] + [1] * (n - 1),
+                      has_pool_per_block=[number in (3, 4)] + [False] * (n - 1))
+        if basic:
+            stages.append(ResNet.make_stage(PooledBasicBlock, n, **common))
+        else:
+            stages.append(ResNet.make_stage(PooledBottleneckBlock, n, bottleneck_channels=mid,
+                                            stride_in_1x1=r.STRIDE_IN_1X1, num_groups=r.NUM_GROUPS, **common))
+        cin, cout, mid = cout, cout * 2, mid * 2
+    return ResNet(stem, stages, out_features=r.OUT_FEATURES).freeze(cfg.MODEL.BACKBONE.FREEZE_AT)

@@ -16,23 +16,38 @@ from jtsm_amd.layers.elementwise import channel_sum, relu_backward  # noqa: E402
 
 CL = torch.channels_last
 REL = 1e-4
+# fp16 operands round at 2^-11 = 4.9e-4 relative each; a contraction's error relative to its largest output stays
+# below 2e-3 on these cases (measured ~3e-4): the stated fp16 tolerance of BASELINE configs[4]'s extra leg.
+REL_BY_MATH = {"f32": 1e-4, "bf16x3": 1e-4, "f16": 2e-3}
 
 
-@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["f32", "bf16x3", "f16"])
 def conv_math(request):
-    """Every case runs in both contraction arithmetics: exact fp32 MFMA, and split-bf16 (three bf16 MFMA
-    products per fp32 product, csrc/conv_x3.h) — the same 1e-4 bar for both."""
+    """Every case runs in every contraction arithmetic: exact fp32 MFMA and split-bf16 (three bf16 MFMA
+    products per fp32 product, csrc/conv_x3.h) at the same 1e-4 bar, and the fp16 path (one fp16 plane per operand,
+    fp32 accumulate) at its own stated tolerance."""
+    global REL
     old = K.MATH
     K.set_math(request.param)
     K.planes_clear()
+    REL = REL_BY_MATH[request.param]
     yield request.param
+    REL = 1e-4
     K.set_math(old)
     K.planes_clear()
 
 
-def close(a, b, what=""):
+def close(a, b, what="", chain=False):
+    """chain: the value went through ReLU gates computed from forward activations.  In fp16 a pre-activation within
+    2^-11 of zero can land on the other side of the gate than the fp32 oracle's, which changes a gradient term
+    outright at that element (a discrete effect, not an arithmetic error): the fp16 bar for such tensors is a
+    relative L2 error of 2e-2 instead of the max-norm bar."""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     assert a.shape == b.shape, (what, a.shape, b.shape)
+    if chain and K.MATH == "f16":
+        l2 = float((a - b).norm() / (b.norm() + 1e-30))
+        assert l2 <= 2e-2, "%s: relative L2 error %.3e" % (what, l2)
+        return
     ref = b.abs().max().item() + 1e-30
     err = (a - b).abs().max().item()
     assert err <= REL * ref, "%s: max err %.3e vs max ref %.3e (rel %.2e)" % (what, err, ref, err / ref)
@@ -128,9 +143,9 @@ def test_autograd_bottleneck_like_chain(cuda):
     y = K.conv2d_fused(o, wd[2], *sbd[2], xd, 1, 0, 1, True)
     close(y, y0, "fwd")
     y.backward(dy.to(cuda))
-    close(xd.grad, x.grad, "dx")
+    close(xd.grad, x.grad, "dx", chain=True)
     for i in range(3):
-        close(wd[i].grad, ws[i].grad, "dw%d" % i)
+        close(wd[i].grad, ws[i].grad, "dw%d" % i, chain=True)
 
 
 def test_linear_dan_shape_slice(cuda):
