@@ -225,7 +225,7 @@ def main():
             "metric": "images/sec training, R50-FPN JTSM panoptic, 2x1024x1024, 1/2/4/8 GPU",
             "value": round(ims, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if conv_math == "f32" else "bf16x3", "data": "synthetic",
+            "vs_baseline": None, "dtype": conv_math, "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: projects/WSL JTSM panoptic R50-FPN composite, COCO-shaped synthetic, "
                             "%d x 3x%dx%d per GPU, %d proposals + %d superpixels per image; MIL + 4 OICR refinements + "

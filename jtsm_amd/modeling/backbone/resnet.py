@@ -108,7 +108,9 @@ class BasicStem(CNNBlockBase):
 class ResNet(Backbone):
     """stem, then stages `res2`, `res3`, ...; returns the requested subset of {"stem", "res2", ...}."""
 
-    def __init__(self, stem, stages, num_classes=None, out_features=None):
+    def __init__(self, stem, stages, num_classes=None, out_features=None, pad_to_stride=False):
+        """pad_to_stride: report the last stage's stride as `size_divisibility` (the WSL v2 network does,
+        projects/WSL/wsl/modeling/backbone/resnet_wsl_v2.py:474,495-497; detectron2's own ResNet reports 0)."""
         super().__init__()
         if num_classes is not None:
             raise NotImplementedError("the classification head is outside the JTSM path")
@@ -131,6 +133,11 @@ class ResNet(Backbone):
         if unknown:
             raise ValueError("ResNet: unknown out_features %s (have %s)" % (unknown, sorted(channels)))
         self._declare_outputs(wanted, {f: channels[f] for f in wanted}, {f: strides[f] for f in wanted})
+        self._size_divisibility = stride if pad_to_stride else 0
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
 
     @property
     def stages(self):

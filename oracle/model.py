@@ -166,8 +166,8 @@ def frozen_bn(p, name, x, eps=1e-5):
     return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
 
 
-def conv_bn(p, name, x, stride=1, pad=0, relu=False):
-    y = frozen_bn(p, name + ".norm", F.conv2d(x, p[name + ".weight"], None, stride, pad))
+def conv_bn(p, name, x, stride=1, pad=0, relu=False, dil=1):
+    y = frozen_bn(p, name + ".norm", F.conv2d(x, p[name + ".weight"], None, stride, pad, dil))
     return F.relu(y) if relu else y
 
 
@@ -199,6 +199,119 @@ def resnet_fpn(p, x, depth=50):
                                     p["backbone.fpn_output%d.bias" % lvl], 1, 1)
     out["p6"] = F.max_pool2d(out["p5"], 1, 2, 0)
     return out
+
+
+# ----------------------------------------------------------------------------- ResNet-WS v2, dilated C5 (shipped configs)
+STAGES_WSR = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3), 50: (3, 4, 6, 3), 101: (3, 4, 23, 3)}
+
+
+def init_params_dc5(seed=0, depth=18, nt=20, ns=2, dan_dims=(4096, 4096), refine_k=4, random_bn=True, input_gain=1.0):
+    """Seeded weights of the shipped single-level composite (projects/WSL/configs/PascalVOC-PanopticSegmentation/
+    jtsm_WSR_{18,50}_DC5_1x.yaml): ResNet-WS v2 with dilated res4/res5 (resnet_wsl_v2.py), DAN, MIL + refinements,
+    two mask heads on res5; the TwoClassHead has no parameters.  state_dict names as the product's."""
+    g = torch.Generator().manual_seed(seed)
+    p = {}
+
+    def msra(name, o, i, k):
+        p[name] = torch.randn(o, i, k, k, generator=g) * math.sqrt(2.0 / (o * k * k))
+
+    def bn(name, c):
+        if random_bn:
+            p[name + ".weight"] = torch.rand(c, generator=g) * 0.5 + 0.75
+            p[name + ".bias"] = torch.randn(c, generator=g) * 0.1
+            p[name + ".running_mean"] = torch.randn(c, generator=g) * 0.1
+            p[name + ".running_var"] = torch.rand(c, generator=g) * 0.5 + 0.75
+        else:
+            p[name + ".weight"], p[name + ".bias"] = torch.ones(c), torch.zeros(c)
+            p[name + ".running_mean"], p[name + ".running_var"] = torch.zeros(c), torch.ones(c)
+
+    bb = "backbone."
+    for j, cin in enumerate((3, 64, 64)):
+        msra("%sstem.conv%d.weight" % (bb, j + 1), 64, cin, 3)
+        bn("%sstem.conv%d.norm" % (bb, j + 1), 64)
+    p[bb + "stem.conv1.weight"] *= input_gain
+    basic = depth in (18, 34)
+    cin = 64
+    for si, nblocks in enumerate(STAGES_WSR[depth]):
+        stage = "res%d" % (si + 2)
+        cout = (64 if basic else 256) * 2 ** si
+        mid = 64 * 2 ** si
+        for b in range(nblocks):
+            pre = "%s%s.%d." % (bb, stage, b)
+            if cin != cout:
+                msra(pre + "shortcut.weight", cout, cin, 1)
+                bn(pre + "shortcut.norm", cout)
+            if basic:
+                msra(pre + "conv1.weight", cout, cin, 3)
+                bn(pre + "conv1.norm", cout)
+                msra(pre + "conv2.weight", cout, cout, 3)
+                bn(pre + "conv2.norm", cout)
+            else:
+                msra(pre + "conv1.weight", mid, cin, 1)
+                bn(pre + "conv1.norm", mid)
+                msra(pre + "conv2.weight", mid, mid, 3)
+                bn(pre + "conv2.norm", mid)
+                msra(pre + "conv3.weight", cout, mid, 1)
+                bn(pre + "conv3.norm", cout)
+            cin = cout
+    c5 = cin
+    rh = "roi_heads."
+    d_in = c5 * 7 * 7
+    for i, d in enumerate(dan_dims):
+        p["%sbox_head.fc%d.weight" % (rh, i + 1)] = torch.randn(d, d_in, generator=g) * (0.005 if i else 0.002)
+        p["%sbox_head.fc%d.bias" % (rh, i + 1)] = torch.full((d,), 0.1)
+        d_in = d
+    nmil = nt + ns - 1
+    for nm in ("cls", "det"):
+        bound = math.sqrt(6.0 / (d_in + nmil))
+        p["%sbox_predictor.%s.weight" % (rh, nm)] = (torch.rand(nmil, d_in, generator=g) * 2 - 1) * bound
+        p["%sbox_predictor.%s.bias" % (rh, nm)] = torch.zeros(nmil)
+    for k in range(refine_k):
+        p["%sbox_refinery_%d.cls_score.weight" % (rh, k)] = torch.randn(nt + 1, d_in, generator=g) * 0.01
+        p["%sbox_refinery_%d.cls_score.bias" % (rh, k)] = torch.zeros(nt + 1)
+        p["%sbox_refinery_%d.bbox_pred.weight" % (rh, k)] = torch.randn(nt * 4, d_in, generator=g) * 0.001
+        p["%sbox_refinery_%d.bbox_pred.bias" % (rh, k)] = torch.zeros(nt * 4)
+    for head in ("mask_head", "mask_refinery_0"):
+        for k in range(4):
+            msra("%s%s.mask_fcn%d.weight" % (rh, head, k + 1), 256, c5 if k == 0 else 256, 3)
+            p["%s%s.mask_fcn%d.bias" % (rh, head, k + 1)] = torch.zeros(256)
+        p["%s%s.deconv.weight" % (rh, head)] = torch.randn(256, 256, 2, 2, generator=g) * math.sqrt(2.0 / (256 * 4))
+        p["%s%s.deconv.bias" % (rh, head)] = torch.zeros(256)
+        p["%s%s.predictor.weight" % (rh, head)] = torch.randn(nt, 256, 1, 1, generator=g) * 0.001
+        p["%s%s.predictor.bias" % (rh, head)] = torch.zeros(nt)
+    p["pixel_mean"] = torch.tensor(PIXEL_MEAN).view(-1, 1, 1)
+    p["pixel_std"] = torch.ones(3, 1, 1)
+    return p
+
+
+def wsr_v2_dc5(p, x, depth, res5_dilation=2):
+    """ResNet-WS v2 forward (resnet_wsl_v2.py:102-119 BasicBlock, :229-251 BottleneckBlock, :418-429 stem, :694-700
+    stage table): no strided convolution; res3 / res4 pool their first block's input."""
+    bb = "backbone."
+    for j in (1, 2, 3):
+        x = conv_bn(p, "%sstem.conv%d" % (bb, j), x, 2 if j == 1 else 1, 1, True)
+    x = F.max_pool2d(x, 2, 2)
+    basic = depth in (18, 34)
+    for si, nblocks in enumerate(STAGES_WSR[depth]):
+        number = si + 2
+        dil = res5_dilation if number in (4, 5) else 1
+        for b in range(nblocks):
+            pre = "%sres%d.%d." % (bb, number, b)
+            if b == 0 and number in (3, 4):
+                if number == 3 or res5_dilation == 1:
+                    x = F.max_pool2d(x, 2, 2)
+                else:
+                    x = F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, 1)
+            sc = conv_bn(p, pre + "shortcut", x) if (pre + "shortcut.weight") in p else x
+            if basic:
+                out = conv_bn(p, pre + "conv1", x, 1, dil, True, dil)
+                out = conv_bn(p, pre + "conv2", out, 1, dil, False, dil)
+            else:
+                out = conv_bn(p, pre + "conv1", x, 1, 0, True)
+                out = conv_bn(p, pre + "conv2", out, 1, dil, True, dil)
+                out = conv_bn(p, pre + "conv3", out)
+            x = F.relu(out + sc)
+    return x
 
 
 # ----------------------------------------------------------------------------- box utilities
@@ -246,15 +359,15 @@ def assign_levels(boxes, min_level=2, max_level=5, canonical_size=224, canonical
     return torch.clamp(lv, min=min_level, max=max_level).to(torch.int64) - min_level
 
 
-def match_and_label(prop_boxes, tgt):
+def match_and_label(prop_boxes, tgt, nt=NUM_THINGS):
     """IoU-match every proposal to the pseudo GT of its image (threshold 0.5, no sub-sampling)."""
     iou = pairwise_iou(tgt["boxes"], prop_boxes)
     if iou.shape[0] == 0:
         R = prop_boxes.shape[0]
-        return dict(classes=torch.full((R,), NUM_THINGS, dtype=torch.int64), idx=torch.zeros(R, dtype=torch.int64))
+        return dict(classes=torch.full((R,), nt, dtype=torch.int64), idx=torch.zeros(R, dtype=torch.int64))
     val, idx = iou.max(dim=0)
     classes = tgt["classes"][idx].clone()
-    classes[val < 0.5] = NUM_THINGS
+    classes[val < 0.5] = nt
     return dict(classes=classes, idx=idx, boxes=tgt["boxes"][idx], scores=tgt["scores"][idx],
                 weights=tgt["weights"][idx])
 
@@ -275,13 +388,13 @@ def rois_with_batch(boxes_list):
                       for i, b in enumerate(boxes_list)])
 
 
-def moi_pool_levels(feats, boxes_list, oh_list, superpixels, res=7):
+def moi_pool_levels(feats, boxes_list, oh_list, superpixels, res=7, single=False):
     """Multi-level MOIPool.  The reference only works single-level (F2); defined here as: each roi is
     pooled on its FPN level with that level's scale; output AND argmax are scattered back."""
     rois = rois_with_batch(boxes_list)
     L = max(o.shape[1] for o in oh_list)
     oh = torch.cat([F.pad(o, (0, L - o.shape[1])) for o in oh_list]).to(torch.int32)
-    lv = assign_levels(rois[:, 1:])
+    lv = torch.zeros(rois.shape[0], dtype=torch.int64) if single else assign_levels(rois[:, 1:])
     C = feats[0].shape[1]
     out = torch.zeros(rois.shape[0], C, res, res)
     arg = torch.full((rois.shape[0], C, res, res), -1, dtype=torch.int32)
@@ -333,9 +446,10 @@ class _RoiAlignLevel(torch.autograd.Function):
                                                      res, B, C, H, W, 0, True)), None, None, None
 
 
-def roi_align_levels(feats, rois, img_size, res):
-    """ROIPooler with ROIAlignV2 (aligned=True, sampling_ratio=0), detectron2/modeling/poolers.py:190-249."""
-    lv = assign_levels(rois[:, 1:])
+def roi_align_levels(feats, rois, img_size, res, single=False):
+    """ROIPooler with ROIAlignV2 (aligned=True, sampling_ratio=0), detectron2/modeling/poolers.py:190-249
+    (single: one feature map, no level assignment, :216-217)."""
+    lv = torch.zeros(rois.shape[0], dtype=torch.int64) if single else assign_levels(rois[:, 1:])
     out = torch.zeros(rois.shape[0], feats[0].shape[1], res, res)
     for l, f in enumerate(feats):
         sel = torch.nonzero(lv == l)[:, 0]
@@ -354,14 +468,14 @@ def mil_image_probs(scores, counts):
     return torch.cat([s.sum(0, keepdim=True) for s in scores.split(counts)]).clamp(1e-6, 1.0 - 1e-6)
 
 
-def oicr_losses(logits, deltas, prop_boxes, lab):
+def oicr_losses(logits, deltas, prop_boxes, lab, nt=NUM_THINGS):
     """Weighted CE / weighted L1 of one refinement branch; lab: dict of cat'ed classes, boxes, weights."""
     w = lab["weights"].clone()
     w[lab["classes"] == -1] = 0.0
     valid = (w > 1e-12).to(w.dtype).sum()
     ce = F.cross_entropy(logits, lab["classes"], reduction="none", ignore_index=-1)
     loss_cls = (ce * w).sum() / valid
-    fg = torch.nonzero((lab["classes"] >= 0) & (lab["classes"] < NUM_THINGS))[:, 0]
+    fg = torch.nonzero((lab["classes"] >= 0) & (lab["classes"] < nt))[:, 0]
     cols = 4 * lab["classes"][fg][:, None] + torch.arange(4)
     tgt = box_deltas(prop_boxes, lab["boxes"])
     l1 = (deltas[fg[:, None], cols] - tgt[fg]).abs()          # smooth_l1 with beta = 0
@@ -375,7 +489,7 @@ def linear_relu_drop(p, name, x, drop):
     return x if drop is None else x * drop
 
 
-def image_labels(gt_classes_list, sem_seg):
+def image_labels(gt_classes_list, sem_seg, nt=NUM_THINGS, ns=NUM_STUFF):
     """(B,133) one-hot of present things ‖ present stuff (roi_heads.py:145-161; roi_heads_jtsm.py:165-194)."""
     things = [torch.unique(g) for g in gt_classes_list]
     stuff = []
@@ -383,11 +497,11 @@ def image_labels(gt_classes_list, sem_seg):
         u = torch.unique(s)
         u = u[(u != 255) & (u != 0)] - 1
         stuff.append(u.to(torch.int64))
-    oh = torch.zeros(len(things), NUM_MIL)
+    oh = torch.zeros(len(things), nt + ns - 1)
     for i, (t, s) in enumerate(zip(things, stuff)):
         oh[i, t] = 1
-        oh[i, NUM_THINGS + s] = 1
-    return things, [s + NUM_THINGS for s in stuff], oh
+        oh[i, nt + s] = 1
+    return things, [s + nt for s in stuff], oh
 
 
 def eroded_rect_masks(boxes, H, W, erode=2):
@@ -398,11 +512,11 @@ def eroded_rect_masks(boxes, H, W, erode=2):
             (ys <= b[:, 3] - erode)).to(torch.float32)
 
 
-def pgt_sem_seg(tgt_list, H, W):
+def pgt_sem_seg(tgt_list, H, W, nt=NUM_THINGS):
     out = torch.zeros(len(tgt_list), H, W, dtype=torch.int64)
     for i, t in enumerate(tgt_list):
         masks = eroded_rect_masks(t["boxes"], H, W) > 0.5
-        vals = t["classes"] - NUM_THINGS + 1
+        vals = t["classes"] - nt + 1
         for j in torch.argsort(t["scores"], descending=False):
             out[i][masks[j]] = vals[j]
         for j in range(vals.numel()):
@@ -435,20 +549,29 @@ def semseg_head(p, feats):
 
 
 # ----------------------------------------------------------------------------- the step
-def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_aux=False):
+def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_aux=False, arch="fpn",
+                   nt=NUM_THINGS, ns=NUM_STUFF):
     """batch: dict(images=[(3,H,W)], boxes=[(R_i,4)], objectness=[(R_i,)], oh_labels=[(R_i,L) int],
     superpixels=(B,H,W) int32, gt_classes=[(n_i,) int64], sem_seg=(B,H,W) int64).
-    Returns the loss dict (keys as in SURVEY §5 'Metrics / logging')."""
-    x = preprocess(p, batch["images"])
+    arch "fpn": the R50/R101-FPN composite with SemSegFPNHead; arch "dc5": the shipped single-level composite
+    (ResNet-WS v2 dilated C5, one feature map at stride 8, TwoClassHead = no semantic loss), nt thing / ns semantic
+    classes.  Returns the loss dict (keys as in SURVEY §5 'Metrics / logging')."""
+    single = arch == "dc5"
+    NUM_THINGS, NUM_MIL = nt, nt + ns - 1   # (shadow the module constants: the body below is written with them)
+    x = preprocess(p, batch["images"], 8 if single else 32)
     Himg, Wimg = x.shape[2:]
-    feats = resnet_fpn(p, x, depth)
-    levels = [feats["p%d" % l] for l in (2, 3, 4, 5)]
+    if single:
+        feats = {"res5": wsr_v2_dc5(p, x, depth)}
+        levels = [feats["res5"]]
+    else:
+        feats = resnet_fpn(p, x, depth)
+        levels = [feats["p%d" % l] for l in (2, 3, 4, 5)]
     counts = [len(b) for b in batch["boxes"]]
-    things, stuff, labels_oh = image_labels(batch["gt_classes"], batch["sem_seg"])
+    things, stuff, labels_oh = image_labels(batch["gt_classes"], batch["sem_seg"], nt, ns)
     aux = {}
 
     # ---- box branch: MOIPool -> scale -> DAN -> MIL -> K OICR refinements
-    pooled, argmax = moi_pool_levels(levels, batch["boxes"], batch["oh_labels"], batch["superpixels"])
+    pooled, argmax = moi_pool_levels(levels, batch["boxes"], batch["oh_labels"], batch["superpixels"], single=single)
     nvalid = (argmax[:, 0] != -1).reshape(argmax.shape[0], -1).sum(1).to(torch.float32)
     mask_scale = argmax.shape[2] * argmax.shape[3] * (nvalid + 1).reciprocal()
     pooled = pooled * mask_scale.view(-1, 1, 1, 1)
@@ -470,16 +593,16 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
     prev_scores = list(scores.detach().split(counts))
     prev_boxes = [b[:, None, :].expand(len(b), NUM_MIL, 4) for b in batch["boxes"]]
     sem_tgts = [mine_top1(pb, ps, st, ip) for pb, ps, st, ip in zip(prev_boxes, prev_scores, stuff, img_probs)]
-    sem_target = pgt_sem_seg(sem_tgts, Himg, Wimg)
+    sem_target = pgt_sem_seg(sem_tgts, Himg, Wimg, nt)
     prev_boxes = [pb[:, :NUM_THINGS] for pb in prev_boxes]
     for k in range(refine_k):
         tg = [mine_top1(pb, ps, th, ip) for pb, ps, th, ip in zip(prev_boxes, prev_scores, things, img_probs)]
-        lab = [match_and_label(b, t) for b, t in zip(batch["boxes"], tg)]
+        lab = [match_and_label(b, t, nt) for b, t in zip(batch["boxes"], tg)]
         cat = {f: torch.cat([l[f] for l in lab]) for f in ("classes", "boxes", "weights")}
         pre = "roi_heads.box_refinery_%d." % k
         z = F.linear(h, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"])
         d = F.linear(h, p[pre + "bbox_pred.weight"], p[pre + "bbox_pred.bias"])
-        losses["loss_cls_r%d" % k], losses["loss_box_reg_r%d" % k] = oicr_losses(z, d, all_boxes, cat)
+        losses["loss_cls_r%d" % k], losses["loss_box_reg_r%d" % k] = oicr_losses(z, d, all_boxes, cat, nt)
         prev_scores = list(F.softmax(z.detach(), dim=-1).split(counts))
         prev_boxes = [pb.view(-1, NUM_THINGS, 4) for pb in apply_deltas(d.detach(), all_boxes).split(counts)]
         aux["pgt_idx_r%d" % k] = [t["idx"] for t in tg]
@@ -487,7 +610,7 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
 
     # ---- mask branch: top-1 pseudo GT from the last refinement -> fg proposals -> two mask heads
     tg = [mine_top1(pb, ps, th, ip) for pb, ps, th, ip in zip(prev_boxes, prev_scores, things, img_probs)]
-    lab = [match_and_label(b, t) for b, t in zip(batch["boxes"], tg)]
+    lab = [match_and_label(b, t, nt) for b, t in zip(batch["boxes"], tg)]
     fg_rois, fg_cls, tgt_rois, gt_masks = [], [], [], []
     base = 0
     for i, (b, l, t) in enumerate(zip(batch["boxes"], lab, tg)):
@@ -499,7 +622,7 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
         base += t["boxes"].shape[0]
     fg_rois, fg_cls, tgt_rois = torch.cat(fg_rois), torch.cat(fg_cls), torch.cat(tgt_rois)
     aux.update(fg_rois=fg_rois, fg_classes=fg_cls)
-    mfeat = roi_align_levels(levels, fg_rois, Himg, 14)
+    mfeat = roi_align_levels(levels, fg_rois, Himg, 14, single=single)
     gt28 = torch.from_numpy(P.roi_align_forward(torch.cat(gt_masks)[:, None].numpy(), tgt_rois.numpy(), 1.0, 28,
                                                 28, 0, True))[:, 0] >= 0.5
     ar = torch.arange(fg_rois.shape[0])
@@ -514,16 +637,17 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
     logits2 = mask_head_layers(p, "roi_heads.mask_refinery_0.", mfeat)
     losses["loss_mask_r0"] = mask_loss(logits2, tgt2)
 
-    # ---- semantic branch
-    sl = semseg_head(p, feats)
-    sl = F.interpolate(sl, scale_factor=4.0, mode="bilinear", align_corners=False)
-    losses["loss_sem_seg"] = F.cross_entropy(sl, sem_target, reduction="mean", ignore_index=255)
+    # ---- semantic branch (the TwoClassHead of the shipped configs has no loss, seg_heads.py:231-275)
+    if not single:
+        sl = semseg_head(p, feats)
+        sl = F.interpolate(sl, scale_factor=4.0, mode="bilinear", align_corners=False)
+        losses["loss_sem_seg"] = F.cross_entropy(sl, sem_target, reduction="mean", ignore_index=255)
     aux["sem_target"] = sem_target
     return (losses, aux) if return_aux else losses
 
 
 # ----------------------------------------------------------------------------- synthetic batch
-def synthetic_batch(seed, B=2, size=1024, R=2000, sp_block=32, n_things=3, n_stuff=2):
+def synthetic_batch(seed, B=2, size=1024, R=2000, sp_block=32, n_things=3, n_stuff=2, nt=NUM_THINGS, ns=NUM_STUFF):
     g = torch.Generator().manual_seed(seed)
     grid = size // sp_block
     ids = (torch.arange(size)[:, None] // sp_block) * grid + (torch.arange(size)[None, :] // sp_block)
@@ -544,8 +668,8 @@ def synthetic_batch(seed, B=2, size=1024, R=2000, sp_block=32, n_things=3, n_stu
         iny = (cy[None, :] >= bx[:, 1:2]) & (cy[None, :] <= bx[:, 3:4])
         inx = (cy[None, :] >= bx[:, 0:1]) & (cy[None, :] <= bx[:, 2:3])
         out["oh_labels"].append((iny[:, :, None] & inx[:, None, :]).reshape(R, -1).to(torch.int32))
-        out["gt_classes"].append(torch.randperm(NUM_THINGS, generator=g)[:n_things].sort().values)
-        st = torch.randperm(NUM_STUFF - 1, generator=g)[:n_stuff] + 1
+        out["gt_classes"].append(torch.randperm(nt, generator=g)[:n_things].sort().values)
+        st = torch.randperm(ns - 1, generator=g)[:n_stuff] + 1
         band = size // (n_stuff + 1)
         for j, s in enumerate(st):
             sem[i, (j + 1) * band:(j + 2) * band] = s

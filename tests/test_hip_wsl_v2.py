@@ -17,10 +17,10 @@ from jtsm_amd.modeling import build_model  # noqa: E402
 from jtsm_amd.utils.synthetic import synthetic_inputs  # noqa: E402
 
 
-def dc5_cfg(device):
+def dc5_cfg(device, depth=50):
     cfg = get_cfg()
     add_wsl_config(cfg)
-    cfg.merge_from_file(os.path.join(ROOT, "configs", "jtsm_WSR_50_DC5_1x.yaml"))
+    cfg.merge_from_file(os.path.join(ROOT, "configs", "jtsm_WSR_%d_DC5_1x.yaml" % depth))
     cfg.MODEL.DEVICE = device
     return cfg
 
@@ -59,14 +59,19 @@ def stock_v2_forward(backbone, x):
         for b in stage:
             if b.has_pool:
                 x = F.max_pool2d(x, 2, 2) if b.pool_stride == 2 else F.max_pool2d(F.pad(x, (0, 1, 0, 1)), 2, 1)
-            out = F.relu(_conv(x, b.conv1)); out = F.relu(_conv(out, b.conv2)); out = _conv(out, b.conv3)
+            out = F.relu(_conv(x, b.conv1))
+            if hasattr(b, "conv3"):
+                out = F.relu(_conv(out, b.conv2)); out = _conv(out, b.conv3)
+            else:
+                out = _conv(out, b.conv2)
             x = F.relu(out + (_conv(x, b.shortcut) if b.shortcut is not None else x))
     return x
 
 
-def test_dc5_backbone_features_match_stock_torch(cuda):
+@pytest.mark.parametrize("depth", [50, 18])
+def test_dc5_backbone_features_match_stock_torch(cuda, depth):
     torch.manual_seed(0)
-    model = build_model(dc5_cfg("cuda"))
+    model = build_model(dc5_cfg("cuda", depth))
     bb = model.backbone
     with torch.no_grad():
         for m in bb.modules():           # non-trivial frozen-BN statistics
@@ -74,11 +79,12 @@ def test_dc5_backbone_features_match_stock_torch(cuda):
                 m.running_var.uniform_(0.5, 1.5); m.running_mean.normal_(0, 0.1)
                 m.weight.uniform_(0.8, 1.2); m.bias.normal_(0, 0.1)
         bb.stem.conv1.weight.mul_(1.0 / 64)
-    assert bb.output_shape()["res5"].stride == 8 and bb.output_shape()["res5"].channels == 2048
+    c5 = 2048 if depth == 50 else 512
+    assert bb.output_shape()["res5"].stride == 8 and bb.output_shape()["res5"].channels == c5
     assert not any(p.requires_grad for p in bb.parameters())           # FREEZE_AT 5
     x = torch.rand(2, 3, 96, 128) * 255
     y = bb(x.to(cuda).contiguous(memory_format=torch.channels_last))["res5"]
-    assert tuple(y.shape) == (2, 2048, 12, 16)
+    assert tuple(y.shape) == (2, c5, 12, 16)
     ref = stock_v2_forward(bb.double().cpu(), x.double())
     err = (y.detach().cpu().double() - ref).abs().max().item() / ref.abs().max().item()
     assert err <= 1e-4, err
@@ -104,6 +110,61 @@ def test_dc5_composite_training_step(cuda):
             assert p.grad is None, n
         elif p.requires_grad:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+
+
+@pytest.mark.parametrize("depth", [18, 50])
+def test_dc5_composite_matches_oracle(cuda, depth):
+    """The shipped single-level configuration (ResNet-WS v2 18 = BasicBlock / 50 = Bottleneck, dilated C5, frozen
+    backbone, single-level MOIPool + ROIAlign on res5, DAN, MIL + 4 refinements, two mask heads, TwoClassHead)
+    against oracle/model.py's `dc5` architecture on the same seeded weights and batch: every loss at 1e-4, the integer
+    artefacts (mined rows, labels, foreground set, pseudo semantic target) bit-exact, head gradients."""
+    from model_util import to_batched_inputs
+    from oracle import model as OM
+
+    dan = (4096, 4096) if depth == 18 else (2048, 4096)
+    params = OM.init_params_dc5(seed=11, depth=depth, nt=20, ns=2, dan_dims=dan, input_gain=1.0 / 64)
+    batch = OM.synthetic_batch(77, B=2, size=256, R=120, sp_block=8, n_stuff=1, nt=20, ns=2)
+    names = [k for k in params if k.startswith("roi_heads.")]
+    for n in names:
+        params[n].requires_grad_(True)
+    losses0, aux0 = OM.forward_losses(params, batch, depth=depth, return_aux=True, arch="dc5", nt=20, ns=2)
+    sum(losses0.values()).backward()
+
+    model = build_model(dc5_cfg("cuda", depth))
+    missing, unexpected = model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    assert not missing and not unexpected
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    assert sorted(n for n, p in model.named_parameters() if p.requires_grad) == sorted(names)
+    losses = model(to_batched_inputs(batch))
+    sum(losses.values()).backward()
+    assert set(losses) == set(losses0) and "loss_sem_seg" not in losses
+    for k in sorted(losses0):
+        a, b = float(losses[k].detach()), float(losses0[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
+    aux = model.roi_heads.aux
+    cnt = aux["things_cnt"].cpu().tolist()
+    for k in range(4):
+        pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
+        for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
+            assert cnt[i] == b.numel() and torch.equal(pad[i, :cnt[i]], b)
+        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+    assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"]) and torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
+    assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
+    a, b = aux["pooled_argmax"].cpu().contiguous(), aux0["pooled_argmax"]
+    assert torch.equal(a == -1, b == -1) and (a != b).float().mean().item() < 2e-3
+    got = dict(model.named_parameters())
+    worst = {}
+    for n in names:
+        if n.endswith("box_predictor.det.bias"):
+            continue   # exactly zero in exact arithmetic
+        g = got[n].grad
+        if n.endswith("box_head.fc1.weight"):
+            g = model.roi_heads.box_head._hwc_cols(g, False)
+        g0 = params[n].grad
+        worst[n] = (g.cpu().double() - g0.double()).abs().max().item() / (g0.abs().max().item() + 1e-8)
+    bad = {k: v for k, v in worst.items() if v > 1e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]
 
 
 def test_dc5_inference_contract(cuda):

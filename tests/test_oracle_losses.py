@@ -91,3 +91,26 @@ def test_mil_restated_matches_loops_and_analytic_gradient():
         gD[r0:r0 + n] = gp * (sc - b * ps)
         r0 += n
     assert torch.allclose(C.grad.double(), gC, atol=1e-7) and torch.allclose(D.grad.double(), gD, atol=1e-7)
+
+
+def test_oracle_dc5_architecture_runs_and_trains_heads_only():
+    """oracle/model.py's `dc5` architecture (the shipped single-level configuration, ResNet-WS v2 18): finite
+    losses without a semantic term, stride-8 feature map, gradients for the heads."""
+    import torch
+
+    from oracle import model as OM
+
+    p = OM.init_params_dc5(seed=1, depth=18, nt=20, ns=2, dan_dims=(64, 64), input_gain=1.0 / 64)
+    x = OM.preprocess(p, [torch.rand(3, 64, 96) * 255], 8)
+    f = OM.wsr_v2_dc5(p, x, 18)
+    assert tuple(f.shape) == (1, 512, 8, 12)
+    batch = OM.synthetic_batch(5, B=1, size=128, R=40, sp_block=8, n_stuff=1, nt=20, ns=2)
+    names = [k for k in p if k.startswith("roi_heads.")]
+    for n in names:
+        p[n].requires_grad_(True)
+    losses = OM.forward_losses(p, batch, depth=18, arch="dc5", nt=20, ns=2)
+    assert "loss_sem_seg" not in losses and {"loss_cls", "loss_cls_r3", "loss_box_reg_r3", "loss_mask"} <= set(losses)
+    total = sum(losses.values())
+    assert bool(torch.isfinite(total))
+    total.backward()
+    assert all(p[n].grad is not None for n in names if "mask_refinery" not in n or float(losses["loss_mask"]) > 0)
