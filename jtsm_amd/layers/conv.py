@@ -238,6 +238,25 @@ def refresh_weight_planes():
             e.version = e.w._version
 
 
+# Where a parameter's weight gradient should be WRITTEN (engine/dp.py): (data_ptr, numel) of the parameter -> a view
+# into its flat gradient bucket with the parameter's strides.  A weight-gradient launch whose parameter has a slot
+# (and no gradient yet this step) writes there directly, so the data-parallel exchange never copies it.
+GRAD_SLOTS = {}
+
+
+def grad_slot(w, params=None):
+    """The bucket view for weight `w` (a parameter or a dense view of one), or None."""
+    if not GRAD_SLOTS or w is None:
+        return None
+    view = GRAD_SLOTS.get((w.data_ptr(), w.numel()))
+    if view is None:
+        return None
+    base = w._base if w._base is not None else w
+    if base.grad is not None:       # a second backward into the same step: let autograd accumulate
+        return None
+    return view
+
+
 # Per-shape launch facts (the ctypes shape struct, output size, FLOPs, workspace sizes, bf16x3 eligibility)
 # are computed once: a training step calls the same ~90 shapes over and over.
 class _Plan(object):
@@ -484,18 +503,25 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     return dx
 
 
-def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=None, out=None):
+def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=None, out=None, w=None):
+    """`out`: accumulate into this tensor.  `w`: the weight being differentiated — when the data-parallel exchange
+    has registered a gradient slot for it, the result is written there (a fresh result, not an accumulation)."""
     _check(dy, x, row_scale)
     dy, x = _cl(dy), _cl(x)
     pl = _plan(x.shape, w_shape, stride, pad, dil)
     s = pl.s
     lib = L.lib()
+    slot = grad_slot(w) if out is None else None
+    if slot is not None:   # same bytes as the OHWI result the kernels write (the parameter is dense, channels_last)
+        n, taps = w_shape[0], w_shape[2] * w_shape[3]
+        slot = slot.as_strided(tuple(w_shape), (taps * w_shape[1], 1, w_shape[3] * w_shape[1], w_shape[1]))
     if MATH != "f32" and pl.x3[2]:
         gh, gl = _hl(planes_of(dy, grad=True))
         xh, xl = _hl(planes_of(x))
         fresh = out is None
         if fresh:   # deterministic slab kernel: writes every element, nothing to clear
-            out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL)
+            out = slot if slot is not None else torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device,
+                                                            memory_format=CL)
         nbytes = pl.ws[2]
         ws = _scratch(nbytes, x.device)
         if MATH == "f16":
@@ -509,7 +535,8 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
         return out
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
-        out = torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL).zero_()
+        out = slot.zero_() if slot is not None else \
+            torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device, memory_format=CL).zero_()
     L.check(_timed(_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_f32(
         L.ptr(dy), L.ptr(x), L.ptr(out), pl.ref, L.ptr(row_scale), int(zero), L.stream()), pl.desc),
             "conv2d_backward_weight")
@@ -555,7 +582,7 @@ class _ConvFused(Function):
                 w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
                 dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale)
+            dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale, w=w)
         if bias_needs_grad and ctx.needs_input_grad[3]:
             db = channel_sum(g)
         if dw is not None and dw.stride() != w.stride() and w.shape[2] == 1 and w.shape[3] == 1:

@@ -54,16 +54,16 @@ class _BottleneckFn(Function):
         dx = dw1 = dw2 = dw3 = dws = None
         g3 = relu_backward(dy, y3, emit_planes=x3)                       # the block's own output gate
         if need[7]:
-            dw3 = K.conv2d_backward_weight(g3, y2, tuple(w3.shape), 1, 0, 1, row_scale=s3)
+            dw3 = K.conv2d_backward_weight(g3, y2, tuple(w3.shape), 1, 0, 1, row_scale=s3, w=w3)
         # gradient at conv2's output, gated by its ReLU in the epilogue
         d2 = _dgrad(g3, w3, s3, tuple(y2.shape), 1, 0, 1, relu_mask=y2, emit_planes=True)
         if need[4]:
-            dw2 = K.conv2d_backward_weight(d2, y1, tuple(w2.shape), stride2, pad2, dil2, row_scale=s2)
+            dw2 = K.conv2d_backward_weight(d2, y1, tuple(w2.shape), stride2, pad2, dil2, row_scale=s2, w=w2)
         d1 = _dgrad(d2, w2, s2, tuple(y1.shape), stride2, pad2, dil2, relu_mask=y1, emit_planes=True)
         if need[1]:
-            dw1 = K.conv2d_backward_weight(d1, x, tuple(w1.shape), stride1, 0, 1, row_scale=s1)
+            dw1 = K.conv2d_backward_weight(d1, x, tuple(w1.shape), stride1, 0, 1, row_scale=s1, w=w1)
         if ws is not None and need[10]:
-            dws = K.conv2d_backward_weight(g3, x, tuple(ws.shape), stride_s, 0, 1, row_scale=ss)
+            dws = K.conv2d_backward_weight(g3, x, tuple(ws.shape), stride_s, 0, 1, row_scale=ss, w=ws)
         if need[0]:
             xs = tuple(x.shape)
             if ws is None:

@@ -1,0 +1,89 @@
+"""Worker of tests/test_hip_dp.py: one rank of a data-parallel training step of the REAL model.
+
+    python tests/dp_worker.py RANK WORLD PORT OUTDIR [collective]
+
+WORLD > 1: ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one device; the exchange code path —
+buckets, kernel-side gradient slots, hooks, side stream, end-of-backward callback — is the one bench.py runs).
+WORLD == 0 (the reference computation): a single process runs BOTH shards, averages the two gradients itself and takes
+the same optimizer step.  Saves {name: parameter after the step} to OUTDIR/rank{RANK}.pt."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def build(device):
+    from model_util import jtsm_cfg
+    from jtsm_amd.modeling import build_model
+
+    torch.manual_seed(0)
+    model = build_model(jtsm_cfg(str(device)))
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    with torch.no_grad():
+        model.backbone.bottom_up.stem.conv1.weight.mul_(1.0 / 64)
+    return model
+
+
+def optimizer(model):
+    from jtsm_amd.solver import SGD
+
+    decay = [p for n, p in model.named_parameters() if p.requires_grad and not n.endswith(".bias")]
+    bias = [p for n, p in model.named_parameters() if p.requires_grad and n.endswith(".bias")]
+    return SGD([{"params": decay, "lr": 1e-3, "weight_decay": 5e-4}, {"params": bias, "lr": 2e-3, "weight_decay": 0.0}],
+               lr=1e-3, momentum=0.9)
+
+
+def shard(rank, device):
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+    return synthetic_inputs(1234 + rank, batch=2, size=256, proposals=120, sp_block=8, device=device, cluster=0.2)
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    collective = sys.argv[5] if len(sys.argv) > 5 else None
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    model = build(device)
+    opt = optimizer(model)
+    if world > 1:
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        from jtsm_amd.engine import dp
+        dp.init_distributed("gloo", device)
+        net = dp.wrap_data_parallel(model, device, collective)
+        assert isinstance(net, dp.DataParallel)
+        losses = net(shard(rank, device))
+        sum(losses.values()).backward()
+        ex = net.exchange
+        # every trainable parameter's gradient now lives in its flat bucket, with the parameter's own strides
+        for p in ex._slot:
+            assert p.grad is not None and p.grad.data_ptr() == ex._slot[p][1].data_ptr() and p.grad.stride() == p.stride()
+        info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes, "loss": float(sum(losses.values()))}
+    else:
+        grads = []
+        for r in range(2):
+            model.zero_grad(set_to_none=True)
+            losses = model(shard(r, device))
+            sum(losses.values()).backward()
+            grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                p.grad = ((grads[0][n] + grads[1][n]) / 2).contiguous(memory_format=torch.preserve_format)
+                if p.grad.stride() != p.stride():
+                    p.grad = torch.empty_like(p).copy_(p.grad)
+        info = {}
+    opt.step()
+    torch.cuda.synchronize()
+    state = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    torch.save({"params": state, "info": info}, os.path.join(out, "rank%d.pt" % rank))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

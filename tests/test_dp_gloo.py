@@ -1,8 +1,9 @@
 """CPU suite: the N>1 plumbing of bench.py (jtsm_amd/engine/dp.py) with world_size 2 on gloo.
-The HIP model itself cannot run without a GPU, so a small torch module stands in for it: what is
-checked is the data-parallel contract of SURVEY §8e — per-rank batches differ (seed 1234 + rank), every
-rank ends the step with identical parameters, and the applied gradient is the MEAN over ranks of the
-per-rank mean losses' gradients."""
+The HIP model itself cannot run without a GPU (tests/test_hip_dp.py runs it, two ranks, on the GPU box), so a small
+torch module stands in for it here: what is checked is the data-parallel contract of SURVEY §8e on this repo's own
+exchange (flat buckets, per-parameter hooks, end-of-backward callback) — per-rank batches differ (seed 1234 + rank),
+every rank ends the step with identical gradients living in the flat buckets, and the applied gradient is the MEAN
+over ranks of the per-rank mean losses' gradients."""
 import os
 import socket
 
@@ -32,6 +33,15 @@ def _worker(rank, world, port, out):
     x, y = torch.randn(2, 8, generator=g), torch.randn(2, 3, generator=g)
     loss = ((net(x) - y) ** 2).mean()                       # mean over THIS rank's 2 samples
     loss.backward()
+    assert isinstance(net, dp.DataParallel) and net.exchange.collective == "allreduce"   # gloo has no reduce-scatter
+    for p in model.parameters():     # gradients are views into the flat bucket, with the parameter's strides
+        view = net.exchange._slot[p][1]
+        assert p.grad.data_ptr() == view.data_ptr() and p.grad.stride() == p.stride()
+    # a second step reuses the buckets: hooks, counters and the end-of-backward callback re-arm
+    first = torch.cat([p.grad.flatten() for p in model.parameters()]).clone()
+    model.zero_grad(set_to_none=True)
+    ((net(x) - y) ** 2).mean().backward()
+    assert torch.equal(first, torch.cat([p.grad.flatten() for p in model.parameters()]))
     grads = torch.cat([p.grad.flatten() for p in model.parameters()])
     t = dp.max_over_ranks(float(rank + 1), torch.device("cpu"))
     dp.fence()

@@ -162,9 +162,13 @@ def test_dc5_composite_matches_oracle(cuda, depth):
         if n.endswith("box_head.fc1.weight"):
             g = model.roi_heads.box_head._hwc_cols(g, False)
         g0 = params[n].grad
-        worst[n] = (g.cpu().double() - g0.double()).abs().max().item() / (g0.abs().max().item() + 1e-8)
-    bad = {k: v for k, v in worst.items() if v > 1e-2}
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]
+        d = g.cpu().double() - g0.double()
+        # (max-norm, L2) relative errors.  A ReLU gate of fc1 / fc2 or a max-pool winner that falls on the other side
+        # in the two summation orders changes whole gradient rows (a discrete effect, see test_hip_model.py): the
+        # max-norm bar is loose, the L2 bar — which a handful of flipped rows barely moves — is tight.
+        worst[n] = (d.abs().max().item() / (g0.abs().max().item() + 1e-8), (d.norm() / (g0.double().norm() + 1e-12)).item())
+    bad = {k: v for k, v in worst.items() if v[0] > 5e-2 or v[1] > 5e-3}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]
 
 
 def test_dc5_inference_contract(cuda):
