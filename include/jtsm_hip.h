@@ -402,6 +402,25 @@ int jtsm_oicr_backward_f32(const float* cls_logits, int ld_cls, int num_cls, con
  * never materialised; the sampling arithmetic is that of jtsm_roi_align_forward_f32. */
 int jtsm_rect_mask_targets_f32(const float* rois, const float* rects, uint8_t* out, int N, int side, int H, int W,
                                float erode, void* stream);
+/* Mask targets from superpixel evidence (object_evidence, projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:
+ * 1928-1994): target n is the union of the superpixels that row oh_row[n] of oh_labels (R, L) int32 marks, in image
+ * img_of[n] of superpixels (B, H, W) int32, cropped to rois[n] at side x side as BitMasks.crop_and_resize does
+ * (detectron2/structures/masks.py:169-200) and thresholded at 0.5.  oh_row[n] < 0 gives an all-zero target. */
+int jtsm_sp_mask_targets_f32(const float* rois, const int32_t* oh_row, const int32_t* img_of, const int32_t* oh_labels,
+                             int L, const int32_t* superpixels, uint8_t* out, int N, int side, int H, int W,
+                             void* stream);
+/* Targets of the mask refinery (get_pgt_mask, roi_heads_jtsm.py:1997-2022): probs (N, M, M) pasted into the H x W
+ * image at rois[n] (paste_masks_in_image, detectron2/layers/mask_ops.py:74-152, >= threshold) and cropped back to
+ * the same box at side x side (crop_and_resize, >= 0.5), without storing the pasted image. */
+int jtsm_paste_crop_targets_f32(const float* probs, const float* rois, uint8_t* out, int N, int M, int side, int H,
+                                int W, float threshold, void* stream);
+/* The "top_k nearest" targets of the mask branch (roi_heads_jtsm.py:840-905): near_rows (B, Gmax, top_k) int32 = for
+ * every pseudo box the top_k foreground proposals (labels != bg_label) of its image by IoU, descending, ties by row,
+ * -1 padded; matched_near (R) int32 = for every foreground proposal the near target (a proposal row) with the
+ * highest IoU, first maximum in (pseudo box, rank) order; -1 for the others. */
+int jtsm_near_targets_f32(const float* proposals, const int32_t* bag_offsets, int B, int R, const int32_t* labels,
+                          int bg_label, const float* pgt_box, const int32_t* counts, int Gmax, int top_k,
+                          int32_t* near_rows, int32_t* matched_near, void* stream);
 
 /* Mask loss — mask_rcnn_loss (detectron2/modeling/roi_heads/mask_head.py:31-112, used by
  * projects/WSL/wsl/modeling/roi_heads/mask_head.py): mean binary cross-entropy with logits between the

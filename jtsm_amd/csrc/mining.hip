@@ -150,6 +150,98 @@ __global__ __launch_bounds__(256) void match_label_kernel(const float* __restric
   if (gt_scores) gt_scores[r] = pgt_score[o];
 }
 
+// ---- the "10 nearest" targets of the mask branch (roi_heads_jtsm.py:840-905): for every pseudo-GT box, the top_k
+// FOREGROUND proposals of its image by IoU with it (torch.topk over pairwise_iou(targets, fg proposals), k = min(#fg,
+// top_k)); ordering here: IoU descending, equal IoUs by ascending proposal row.  One workgroup per (image, pseudo box);
+// round j picks the smallest key (−IoU, row) greater than round j-1's.  near_rows (B, Gmax, K): proposal rows, -1 pad.
+__device__ __forceinline__ float iou_tp(const float* __restrict__ q /* target */, const float* __restrict__ p) {
+#pragma clang fp contract(off)
+  const float area_q = (q[2] - q[0]) * (q[3] - q[1]), area_p = (p[2] - p[0]) * (p[3] - p[1]);
+  const float w = fmaxf(fminf(q[2], p[2]) - fmaxf(q[0], p[0]), 0.f);
+  const float h = fmaxf(fminf(q[3], p[3]) - fmaxf(q[1], p[1]), 0.f);
+  const float inter = w * h;
+  return inter > 0.f ? inter / (area_q + area_p - inter) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void near_targets_kernel(const float* __restrict__ proposals,
+                                                           const int* __restrict__ bag_off,
+                                                           const int* __restrict__ labels, int bg_label,
+                                                           const float* __restrict__ pgt_box,
+                                                           const int* __restrict__ counts, int Gmax, int K,
+                                                           int* __restrict__ near_rows) {
+  __shared__ float s_iou[256];
+  __shared__ int s_row[256];
+  __shared__ float last_iou;
+  __shared__ int last_row;
+  const int img = blockIdx.x / Gmax, g = blockIdx.x % Gmax;
+  int* out = near_rows + (size_t)blockIdx.x * K;
+  if (g >= counts[img]) {
+    for (int k = threadIdx.x; k < K; k += blockDim.x) out[k] = -1;
+    return;
+  }
+  const int r0 = bag_off[img], r1 = bag_off[img + 1];
+  const float* q = pgt_box + 4 * ((size_t)img * Gmax + g);
+  if (threadIdx.x == 0) { last_iou = 2.f; last_row = -1; }
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    const float li = last_iou;
+    const int lr = last_row;
+    float best = -1.f;
+    int at = -1;
+    for (int r = r0 + threadIdx.x; r < r1; r += blockDim.x) {
+      if (labels[r] == bg_label || labels[r] < 0) continue;           // foreground proposals only
+      const float v = iou_tp(q, proposals + 4 * (size_t)r);
+      const bool after = v < li || (v == li && r > lr);               // strictly after the previous pick
+      if (after && (v > best || (v == best && r < at))) { best = v; at = r; }
+    }
+    s_iou[threadIdx.x] = best;
+    s_row[threadIdx.x] = at;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+      if (threadIdx.x < st) {
+        const float a = s_iou[threadIdx.x], b = s_iou[threadIdx.x + st];
+        const int ra = s_row[threadIdx.x], rb = s_row[threadIdx.x + st];
+        if (rb >= 0 && (ra < 0 || b > a || (b == a && rb < ra))) { s_iou[threadIdx.x] = b; s_row[threadIdx.x] = rb; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      out[k] = s_row[0];
+      last_iou = s_iou[0];
+      last_row = s_row[0] >= 0 ? s_row[0] : 0x7fffffff;   // exhausted: nothing comes after
+      if (s_row[0] < 0) last_iou = -2.f;
+    }
+    __syncthreads();
+  }
+}
+
+// Second labelling pass against the near targets (label_and_sample_proposals(instances, near_targets),
+// roi_heads_jtsm.py:893-905 -> roi_heads.py:306-340): each foreground proposal takes the mask of the near target with
+// the highest IoU (first maximum in list order: pseudo box major, rank minor).  matched_near[r] = that target's
+// proposal row (-1 for non-foreground proposals / images without targets).
+__global__ __launch_bounds__(256) void match_near_kernel(const float* __restrict__ proposals, const int* __restrict__ bag_off,
+                                                         int B, int R, const int* __restrict__ labels, int bg_label,
+                                                         const int* __restrict__ near_rows, const int* __restrict__ counts,
+                                                         int Gmax, int K, int* __restrict__ matched_near) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  if (labels[r] == bg_label || labels[r] < 0) { matched_near[r] = -1; return; }
+  int img = 0;
+  while (img + 1 < B && r >= bag_off[img + 1]) ++img;
+  const float* p = proposals + 4 * (size_t)r;
+  float best = -1.f;
+  int at = -1;
+  const int n = counts[img];
+  for (int g = 0; g < n; ++g)
+    for (int k = 0; k < K; ++k) {
+      const int row = near_rows[((size_t)img * Gmax + g) * K + k];
+      if (row < 0) break;
+      const float v = iou_tp(proposals + 4 * (size_t)row, p);
+      if (v > best) { best = v; at = row; }
+    }
+  matched_near[r] = at;
+}
+
 // ---- pseudo semantic target (get_pgt_sem_seg, roi_heads_jtsm.py:2025-2070, with the rectangle substitution of
 // SURVEY F8): every pseudo box paints its rectangle shrunk by `erode` pixels with value class - class_base, in
 // ascending score order (the best box ends on top); then, in list order, a class whose pixels were all painted
@@ -273,6 +365,22 @@ int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int
                      bag_offsets, B, R, pgt_box, classes, counts, pgt_weight, pgt_score, Gmax, iou_thresh, bg_label,
                      labels, matched, gt_boxes, gt_weights, gt_scores);
   JTSM_CHECK_LAUNCH("match_label");
+  return JTSM_OK;
+}
+
+int jtsm_near_targets_f32(const float* proposals, const int32_t* bag_offsets, int B, int R, const int32_t* labels,
+                          int bg_label, const float* pgt_box, const int32_t* counts, int Gmax, int top_k,
+                          int32_t* near_rows, int32_t* matched_near, void* stream) {
+  JTSM_REQUIRE(B > 0 && R >= 0 && Gmax > 0 && top_k > 0 && top_k <= 64, "near_targets: bad sizes");
+  JTSM_REQUIRE(proposals && bag_offsets && labels && pgt_box && counts && near_rows && matched_near,
+               "near_targets: null pointer");
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(near_targets_kernel, dim3(B * Gmax), dim3(256), 0, st, proposals, bag_offsets, labels, bg_label,
+                     pgt_box, counts, Gmax, top_k, near_rows);
+  if (R > 0)
+    hipLaunchKernelGGL(match_near_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, proposals, bag_offsets, B, R, labels,
+                       bg_label, near_rows, counts, Gmax, top_k, matched_near);
+  JTSM_CHECK_LAUNCH("near_targets");
   return JTSM_OK;
 }
 

@@ -605,6 +605,107 @@ __global__ __launch_bounds__(256) void rect_mask_targets_kernel(const float* __r
   }
 }
 
+// ---- mask targets from SUPERPIXEL EVIDENCE (object_evidence, roi_heads_jtsm.py:1928-1994, the reference's own
+// grabCut-free construction): the instance mask of a (near) target is the union of the superpixels its oh_labels row
+// marks — an image that is never rasterised here: pixel (y, x) of target t is oh_labels[t][superpixels[y][x]] != 0.
+// Thread (roi, ph, pw) runs the ROIAlign(1.0, sampling 0, aligned) arithmetic of BitMasks.crop_and_resize
+// (structures/masks.py:169-200) on that image and thresholds at 0.5.
+__global__ __launch_bounds__(256) void sp_mask_targets_kernel(const float* __restrict__ rois,        // (N,4) boxes
+                                                              const int* __restrict__ oh_row,        // (N) label row
+                                                              const int* __restrict__ img_of,        // (N) image
+                                                              const int* __restrict__ oh_labels, int L,
+                                                              const int* __restrict__ sp,            // (B,H,W)
+                                                              unsigned char* __restrict__ out, long total, int side,
+                                                              int H, int W) {
+#pragma clang fp contract(off)
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % side), ph = (int)((idx / side) % side);
+    const long n = idx / side / side;
+    const int row = oh_row[n];
+    if (row < 0) { out[idx] = 0; continue; }
+    const float roi5[5] = {0.f, rois[n * 4], rois[n * 4 + 1], rois[n * 4 + 2], rois[n * 4 + 3]};
+    const RoiGeom<float> g = geom_box<float>(roi5, 1.0f, side, side, 0, true);
+    const int* lab = oh_labels + (size_t)row * L;
+    const int* s = sp + (size_t)img_of[n] * H * W;
+    const int cells = g.gh * g.gw;
+    const float count = (float)(cells > 1 ? cells : 1);
+    float acc = 0.f;
+    for (int iy = 0; iy < g.gh; ++iy)
+      for (int ix = 0; ix < g.gw; ++ix) {
+        const Tap<float> t = sample_tap<float, false>(g, H, W, ph, pw, iy, ix);
+        if (t.pos[0] < 0) continue;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int id = s[t.pos[k]];
+          v[k] = ((unsigned)id < (unsigned)L && lab[id] != 0) ? 1.f : 0.f;
+        }
+        acc += t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
+      }
+    out[idx] = (acc / count) >= 0.5f ? 1 : 0;
+  }
+}
+
+// ---- targets of the mask REFINERY (get_pgt_mask, roi_heads_jtsm.py:1997-2022): the previous head's class
+// probability (M x M) is pasted into the image at the proposal box (paste_masks_in_image: grid_sample bilinear,
+// zeros, align_corners=False, >= threshold; detectron2/layers/mask_ops.py:74-152) and that bitmask is cropped back to
+// the same box at side x side (crop_and_resize).  Fused: the pasted image is evaluated per ROIAlign tap, never stored.
+// (The reference additionally encodes the bitmask as polygons and rasterises them again — skipped, see DESIGN.)
+__device__ __forceinline__ float pc_tap(const float* __restrict__ m, int M, int iy, int ix) {
+  return (iy >= 0 && iy < M && ix >= 0 && ix < M) ? m[iy * M + ix] : 0.f;
+}
+__device__ __forceinline__ float pasted_bit(const float* __restrict__ m, int M, float x0, float y0, float x1, float y1,
+                                            int x, int y, float threshold) {
+#pragma clang fp contract(off)
+  const float gy = ((float)y + 0.5f - y0) / (y1 - y0) * 2.f - 1.f;
+  const float iy = ((gy + 1.f) * (float)M - 1.f) / 2.f;
+  const float fy = floorf(iy);
+  const float gx = ((float)x + 0.5f - x0) / (x1 - x0) * 2.f - 1.f;
+  const float ix = ((gx + 1.f) * (float)M - 1.f) / 2.f;
+  const float fx = floorf(ix);
+  float acc = 0.f;
+  if (fx >= -1.f && fx < (float)M && fy >= -1.f && fy < (float)M) {
+    const int iy0 = (int)fy, iy1 = iy0 + 1, ix0 = (int)fx, ix1 = ix0 + 1;
+    const float wy1 = iy - fy, wy0 = (fy + 1.f) - iy, wx1 = ix - fx, wx0 = (fx + 1.f) - ix;
+    acc += pc_tap(m, M, iy0, ix0) * (wx0 * wy0);
+    acc += pc_tap(m, M, iy0, ix1) * (wx1 * wy0);
+    acc += pc_tap(m, M, iy1, ix0) * (wx0 * wy1);
+    acc += pc_tap(m, M, iy1, ix1) * (wx1 * wy1);
+  }
+  return acc >= threshold ? 1.f : 0.f;
+}
+
+__global__ __launch_bounds__(256) void paste_crop_targets_kernel(const float* __restrict__ probs,   // (N, M, M)
+                                                                 const float* __restrict__ rois,    // (N, 4)
+                                                                 unsigned char* __restrict__ out, long total, int M,
+                                                                 int side, int H, int W, float threshold) {
+#pragma clang fp contract(off)
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int pw = (int)(idx % side), ph = (int)((idx / side) % side);
+    const long n = idx / side / side;
+    const float x0 = rois[n * 4], y0 = rois[n * 4 + 1], x1 = rois[n * 4 + 2], y1 = rois[n * 4 + 3];
+    const float roi5[5] = {0.f, x0, y0, x1, y1};
+    const RoiGeom<float> g = geom_box<float>(roi5, 1.0f, side, side, 0, true);
+    const float* m = probs + (size_t)n * M * M;
+    const int cells = g.gh * g.gw;
+    const float count = (float)(cells > 1 ? cells : 1);
+    float acc = 0.f;
+    for (int iy = 0; iy < g.gh; ++iy)
+      for (int ix = 0; ix < g.gw; ++ix) {
+        const Tap<float> t = sample_tap<float, false>(g, H, W, ph, pw, iy, ix);
+        if (t.pos[0] < 0) continue;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int y = t.pos[k] / W, x = t.pos[k] - y * W;
+          v[k] = pasted_bit(m, M, x0, y0, x1, y1, x, y, threshold);
+        }
+        acc += t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
+      }
+    out[idx] = (acc / count) >= 0.5f ? 1 : 0;
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -704,6 +805,33 @@ int jtsm_roi_sample_table_f32(const float* rois, int rotated, int M, int H, int 
                        as_stream(stream), rois, M, H, W, spatial_scale, pooled_h, pooled_w,
                        sampling_ratio, aligned, grid, pos, w, cap);
   JTSM_CHECK_LAUNCH("roi_sample_table");
+  return JTSM_OK;
+}
+
+int jtsm_sp_mask_targets_f32(const float* rois, const int32_t* oh_row, const int32_t* img_of, const int32_t* oh_labels,
+                             int L, const int32_t* superpixels, uint8_t* out, int N, int side, int H, int W,
+                             void* stream) {
+  JTSM_REQUIRE(N >= 0 && side > 0 && H > 0 && W > 0 && L > 0, "sp_mask_targets: bad sizes");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(rois && oh_row && img_of && oh_labels && superpixels && out, "sp_mask_targets: null pointer");
+  const long total = (long)N * side * side;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(sp_mask_targets_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), rois, oh_row, img_of,
+                     oh_labels, L, superpixels, out, total, side, H, W);
+  JTSM_CHECK_LAUNCH("sp_mask_targets");
+  return JTSM_OK;
+}
+
+int jtsm_paste_crop_targets_f32(const float* probs, const float* rois, uint8_t* out, int N, int M, int side, int H,
+                                int W, float threshold, void* stream) {
+  JTSM_REQUIRE(N >= 0 && M > 0 && side > 0 && H > 0 && W > 0, "paste_crop_targets: bad sizes");
+  if (N == 0) return JTSM_OK;
+  JTSM_REQUIRE(probs && rois && out, "paste_crop_targets: null pointer");
+  const long total = (long)N * side * side;
+  const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+  hipLaunchKernelGGL(paste_crop_targets_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), probs, rois, out, total,
+                     M, side, H, W, threshold);
+  JTSM_CHECK_LAUNCH("paste_crop_targets");
   return JTSM_OK;
 }
 

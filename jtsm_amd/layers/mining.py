@@ -93,3 +93,49 @@ def rect_mask_targets(rois, rects, side, height, width, erode=2.0):
     L.check(L.lib().jtsm_rect_mask_targets_f32(L.ptr(rois), L.ptr(rects), L.ptr(out), n, side, height, width,
                                                L.f32(erode), L.stream()), "rect_mask_targets")
     return out.to(torch.bool)
+
+
+@torch.no_grad()
+def near_targets(proposals, bag_offsets, labels, bg_label, pgt, counts, top_k=10):
+    """The mask branch's "top_k nearest" targets (roi_heads_jtsm.py:840-905), sync-free:
+    -> (near_rows (B,G,top_k) int32, matched_near (R,) int32); see jtsm_near_targets_f32."""
+    proposals = proposals.contiguous()
+    R, dev = proposals.shape[0], proposals.device
+    B, G = pgt["boxes"].shape[:2]
+    near = torch.empty((B, G, top_k), dtype=torch.int32, device=dev)
+    matched = torch.empty(R, dtype=torch.int32, device=dev)
+    L.check(L.lib().jtsm_near_targets_f32(L.ptr(proposals), L.ptr(bag_offsets), B, R, L.ptr(labels), int(bg_label),
+                                          L.ptr(pgt["boxes"]), L.ptr(counts), G, int(top_k), L.ptr(near),
+                                          L.ptr(matched), L.stream()), "near_targets")
+    return near, matched
+
+
+@torch.no_grad()
+def sp_mask_targets(rois, oh_rows, img_of, oh_labels, superpixels, side):
+    """(N, side, side) bool targets from superpixel evidence: the union of the superpixels marked by row oh_rows[n]
+    of oh_labels, cropped to rois[n] (libjtsm_hip.so: jtsm_sp_mask_targets_f32)."""
+    L.require_gpu(rois, oh_labels, superpixels)
+    rois = rois.to(torch.float32).contiguous()
+    oh_labels = oh_labels.to(torch.int32).contiguous()
+    superpixels = superpixels.to(torch.int32).contiguous()
+    n = rois.shape[0]
+    _, h, w = superpixels.shape
+    out = torch.empty((n, side, side), dtype=torch.uint8, device=rois.device)
+    L.check(L.lib().jtsm_sp_mask_targets_f32(L.ptr(rois), L.ptr(oh_rows.to(torch.int32).contiguous()),
+                                             L.ptr(img_of.to(torch.int32).contiguous()), L.ptr(oh_labels),
+                                             oh_labels.shape[1], L.ptr(superpixels), L.ptr(out), n, side, h, w,
+                                             L.stream()), "sp_mask_targets")
+    return out.to(torch.bool)
+
+
+@torch.no_grad()
+def paste_crop_targets(probs, rois, side, height, width, threshold=0.5):
+    """(N, side, side) bool targets of the mask refinery: probs (N, M, M) pasted at rois and cropped back
+    (libjtsm_hip.so: jtsm_paste_crop_targets_f32)."""
+    L.require_gpu(probs, rois)
+    probs, rois = probs.to(torch.float32).contiguous(), rois.to(torch.float32).contiguous()
+    n, m = probs.shape[0], probs.shape[-1]
+    out = torch.empty((n, side, side), dtype=torch.uint8, device=rois.device)
+    L.check(L.lib().jtsm_paste_crop_targets_f32(L.ptr(probs), L.ptr(rois), L.ptr(out), n, m, side, height, width,
+                                                L.f32(threshold), L.stream()), "paste_crop_targets")
+    return out.to(torch.bool)

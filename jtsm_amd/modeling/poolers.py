@@ -34,7 +34,10 @@ def assign_boxes_to_levels(box_lists, min_level, max_level, canonical_box_size, 
     [min_level, max_level], returned 0-based (poolers.py:22-58)."""
     box_sizes = torch.sqrt(cat([boxes.area() for boxes in box_lists]))
     level_assignments = torch.floor(canonical_level + torch.log2(box_sizes / canonical_box_size + 1e-8))
-    level_assignments = torch.clamp(level_assignments, min=min_level, max=max_level)
+    # (a degenerate box — negative or NaN area — must still land on a level: the level kernels write only the rois
+    # they own, and an unowned roi would return uninitialised memory)
+    level_assignments = torch.clamp(torch.nan_to_num(level_assignments, nan=float(min_level)), min=min_level,
+                                    max=max_level)
     return level_assignments.to(torch.int64) - min_level
 
 
@@ -199,12 +202,14 @@ class ROIPooler(nn.Module):
             max_len = max(l.size(1) for l in oh_labels_list)
             labels = cat([torch.nn.functional.pad(l.to(torch.int32), (0, max_len - l.size(1))) for l in oh_labels_list])
             labels = labels.contiguous()
+            # kept for the mask branch's superpixel-evidence targets (same rows as the concatenated boxes)
+            self.last_oh_labels, self.last_superpixels = labels, sp
         if num_level_assignments == 1:
             if moi:
                 return self.level_poolers[0](x[0], pooler_fmt_boxes, labels, sp)
             return self.level_poolers[0](x[0], pooler_fmt_boxes)
         if level_ids is not None:
-            level_assignments = cat(level_ids).to(torch.int64)
+            level_assignments = cat(level_ids).to(torch.int64).clamp(0, num_level_assignments - 1)
         else:
             level_assignments = assign_boxes_to_levels(box_lists, self.min_level, self.max_level,
                                                        self.canonical_box_size, self.canonical_level)

@@ -13,10 +13,18 @@ MI355X mapping of the box branch (the reference issues ~40 small launches + K+1 
 Pseudo-label mining (top-1 per present class, IoU matching) stays in torch ops on the device, as in
 the reference; it is label generation, not differentiated.
 
-Declared substitutions (identical in oracle/model.py): grabCut + polygon pseudo
-masks are replaced by the matched pseudo-GT rectangle shrunk by 2 px; the mask refinery is trained on
-the thresholded 28x28 prediction of the first head instead of its paste -> polygon -> rasterise
-round trip; the "10 nearest" evidence step is skipped.
+Mask pseudo labels, all on the device and without host round trips:
+  * the "10 nearest" targets (:840-905): per pseudo box the top-10 foreground proposals by IoU, then every
+    foreground proposal takes the mask of its best-matching near target (csrc/mining.hip: near_targets);
+  * that mask is the reference's own grabCut-free construction, SUPERPIXEL EVIDENCE (object_evidence :1928-1994):
+    the union of the superpixels the target's oh_labels row marks, cropped to the proposal at 28x28
+    (csrc/roi_align.hip: sp_mask_targets — the full-image mask is never rasterised);
+  * the mask refinery trains on get_pgt_mask's paste -> crop of the first head's prediction (:1997-2022,
+    csrc/roi_align.hip: paste_crop_targets).
+Declared substitutions (identical in oracle/model.py): grabCut itself (the reference's live branch of
+object_evidence, an OpenCV CPU routine) is replaced by the superpixel evidence above; masks stay bitmasks where the
+reference encodes them as polygons and rasterises those again (cv2.findContours / pycocotools); the pseudo SEMANTIC
+target still paints pseudo-GT rectangles shrunk by 2 px.  MASK_TARGETS = "rect" restores round 1's rectangles.
 """
 from typing import Dict, List, Optional
 
@@ -24,7 +32,8 @@ import torch
 import torch.nn.functional as F
 
 from ...layers.conv import linear_fused, linear_fused_split
-from ...layers.mining import match_label, mine_top1, pad_class_lists, paint_sem_seg, rect_mask_targets, row_lse
+from ...layers.mining import (match_label, mine_top1, near_targets, pad_class_lists, paint_sem_seg,
+                              paste_crop_targets, rect_mask_targets, row_lse, sp_mask_targets)
 from ...layers.roi_align import roi_align
 from ...layers.shape_spec import ShapeSpec
 from ...structures import Boxes, ImageList, Instances
@@ -137,6 +146,8 @@ class JTSMROIHeads(ROIHeads):
             self.mask_refinery.append(head)
         self.pgt_sem_seg = None
         self.aux = {}
+        self.mask_mined_top_k = 10            # roi_heads_jtsm.py:420 (self.mask_mined_top_k = 10)
+        self.mask_targets = "evidence"        # "evidence" (reference semantics) or "rect" (round-1 rectangles)
 
     # ------------------------------------------------------------------ label mining (no grad)
     @torch.no_grad()
@@ -326,6 +337,9 @@ class JTSMROIHeads(ROIHeads):
         pg = mine_top1(prev_logits, all_boxes, offsets, things_cls, things_cnt, self.pred_class_img_logits,
                        lse=row_lse(prev_logits), deltas=prev_deltas)
         lab = match_label(all_boxes, offsets, pg, things_cls, things_cnt, self.num_classes)
+        if self.mask_targets == "evidence":
+            lab["near_rows"], lab["matched_near"] = near_targets(all_boxes, offsets, lab["labels"], self.num_classes, pg,
+                                                                 things_cnt, self.mask_mined_top_k)
         with torch.no_grad():
             is_fg = lab["labels"] != self.num_classes
             ends = torch.tensor(list(torch.tensor(counts).cumsum(0)), dtype=torch.int64)       # host-known row ranges
@@ -355,10 +369,18 @@ class JTSMROIHeads(ROIHeads):
             img_of = torch.bucketize(fg, offsets[1:].to(torch.int64), right=True)          # image of each fg row
             # targets: the matched pseudo-GT rectangle (shrunk by 2 px) cropped to the proposal at 28x28 with
             # ROIAlign(1.0, sampling 0, aligned) and thresholded at 0.5 (structures/masks.py:169-200) — analytic kernel
-            G = things_cls.shape[1]
-            matched = pg["boxes"].reshape(-1, 4)[img_of * G + lab["matched"][fg].to(torch.int64)]
             side = 2 * self.mask_pooler.output_size[0]
-            gt_masks = rect_mask_targets(fg_boxes, matched, side, height, width)
+            if self.mask_targets == "evidence":
+                # the matched near target's superpixel-evidence mask, cropped to the proposal (never rasterised)
+                oh_all = self.box_pooler.last_oh_labels
+                sp = self.box_pooler.last_superpixels
+                gt_masks = sp_mask_targets(fg_boxes, lab["matched_near"][fg], img_of, oh_all, sp, side)
+                self.aux["near_rows"], self.aux["matched_near"] = lab["near_rows"], lab["matched_near"][fg]
+            else:
+                G = things_cls.shape[1]
+                matched = pg["boxes"].reshape(-1, 4)[img_of * G + lab["matched"][fg].to(torch.int64)]
+                gt_masks = rect_mask_targets(fg_boxes, matched, side, height, width)
+            self.aux["mask_targets"] = gt_masks
         fg_box_lists = [Boxes(b) for b in fg_boxes.split(per_image)]
         mask_features = self.mask_pooler(feats, fg_box_lists)
         self.aux.update(fg_rois=torch.cat([img_of.to(torch.float32)[:, None], fg_boxes], dim=1), fg_classes=gt_classes)
@@ -368,7 +390,11 @@ class JTSMROIHeads(ROIHeads):
             with torch.no_grad():
                 n = pred_mask_logits.size(0)
                 sel = pred_mask_logits.detach()[torch.arange(n, device=gt_classes.device), gt_classes]
-                gt_masks = sel > 0.0                                            # sigmoid > 0.5
+                if self.mask_targets == "evidence":   # get_pgt_mask: paste the class probability, crop it back
+                    gt_masks = paste_crop_targets(sel.sigmoid(), fg_boxes, side, height, width, 0.5)
+                else:
+                    gt_masks = sel > 0.0                                        # sigmoid > 0.5
+                self.aux["mask_targets_r%d" % k] = gt_masks
             pred_mask_logits, _ = head.layers(mask_features)
             losses["loss_mask_r" + str(k)] = mask_rcnn_loss(pred_mask_logits, gt_classes, gt_masks)
         return losses

@@ -21,10 +21,14 @@ What each function follows (paths relative to the reference tree):
   mask_branch           .../roi_heads_jtsm.py:754-948; .../mask_head.py:23-103,266-343; structures/masks.py:169-200
   semseg_head           detectron2/modeling/meta_arch/semantic_seg.py:103-188
   pgt_sem_seg           .../roi_heads_jtsm.py:2025-2070
-Declared substitutions (also made by the product path): grabCut / polygon pseudo-masks
-are replaced by the pseudo-GT rectangle eroded by 2 px; the "nearest 10" evidence step and the
-paste->polygon->rasterise round trip of get_pgt_mask are replaced by thresholding the first head's
-own 28x28 prediction.  Dropout is a caller-supplied mask (None = off).
+  near targets          .../roi_heads_jtsm.py:840-905 (top-10 foreground proposals per pseudo box, second labelling)
+  evidence masks        .../roi_heads_jtsm.py:1928-1994 (object_evidence, superpixel branch)
+  refinery targets      .../roi_heads_jtsm.py:1997-2022 (get_pgt_mask: paste, then crop_and_resize)
+Declared substitutions (also made by the product path): grabCut (object_evidence's live branch, OpenCV) is
+replaced by the reference's own superpixel-evidence construction; masks stay bitmasks where the reference
+encodes them as polygons and rasterises those again; the pseudo SEMANTIC target paints pseudo-GT rectangles
+eroded by 2 px.  mask_targets="rect" selects round 1's rectangle masks + thresholded refinery targets.
+Dropout is a caller-supplied mask (None = off).
 """
 import math
 
@@ -549,8 +553,25 @@ def semseg_head(p, feats):
 
 
 # ----------------------------------------------------------------------------- the step
+def near_targets_and_masks(boxes, sel, tgt, oh, sp, top_k=10):
+    """Mask labels of one image.  boxes (R,4) proposals, sel (N,) foreground rows, tgt: top-1 pseudo GT, oh (R,L)
+    int labels, sp (H,W) int superpixels.  Returns (near (G*k,) proposal rows, matched (N,) index into near,
+    masks (G*k,H,W) float evidence masks)."""
+    n = sel.numel()
+    if n == 0 or tgt["boxes"].shape[0] == 0:
+        return sel.new_zeros(0), sel.new_zeros(0), torch.zeros((0,) + tuple(sp.shape))
+    iou = pairwise_iou(tgt["boxes"], boxes[sel])                              # (G, N) targets x fg proposals
+    k = min(n, top_k)
+    order = torch.argsort(iou, dim=1, descending=True, stable=True)[:, :k]    # ties: lower row first
+    near = sel[order.reshape(-1)]                                             # pseudo box major, rank minor
+    matched = pairwise_iou(boxes[near], boxes[sel]).max(dim=0).indices        # first maximum (matcher.py:61-103)
+    masks = (torch.gather(oh[near].to(torch.int64), 1, sp.reshape(1, -1).to(torch.int64).expand(near.numel(), -1))
+             != 0).to(torch.float32).reshape(near.numel(), *sp.shape)
+    return near, matched, masks
+
+
 def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_aux=False, arch="fpn",
-                   nt=NUM_THINGS, ns=NUM_STUFF):
+                   nt=NUM_THINGS, ns=NUM_STUFF, mask_targets="evidence"):
     """batch: dict(images=[(3,H,W)], boxes=[(R_i,4)], objectness=[(R_i,)], oh_labels=[(R_i,L) int],
     superpixels=(B,H,W) int32, gt_classes=[(n_i,) int64], sem_seg=(B,H,W) int64).
     arch "fpn": the R50/R101-FPN composite with SemSegFPNHead; arch "dc5": the shipped single-level composite
@@ -611,17 +632,26 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
     # ---- mask branch: top-1 pseudo GT from the last refinement -> fg proposals -> two mask heads
     tg = [mine_top1(pb, ps, th, ip) for pb, ps, th, ip in zip(prev_boxes, prev_scores, things, img_probs)]
     lab = [match_and_label(b, t, nt) for b, t in zip(batch["boxes"], tg)]
-    fg_rois, fg_cls, tgt_rois, gt_masks = [], [], [], []
-    base = 0
+    fg_rois, fg_cls, tgt_rois, gt_masks, near_rows = [], [], [], [], []
+    base = row0 = 0
+    sp_pad = F.pad(batch["superpixels"], (0, Wimg - batch["superpixels"].shape[2], 0, Himg - batch["superpixels"].shape[1]))
     for i, (b, l, t) in enumerate(zip(batch["boxes"], lab, tg)):
         sel = torch.nonzero((l["classes"] >= 0) & (l["classes"] < NUM_THINGS))[:, 0]
         fg_rois.append(torch.cat([torch.full((len(sel), 1), float(i)), b[sel]], 1))
         fg_cls.append(l["classes"][sel])
-        tgt_rois.append(torch.cat([(base + l["idx"][sel]).to(b.dtype)[:, None], b[sel]], 1))
-        gt_masks.append(eroded_rect_masks(t["boxes"], Himg, Wimg))
-        base += t["boxes"].shape[0]
+        if mask_targets == "evidence":
+            near, matched, masks = near_targets_and_masks(b, sel, t, batch["oh_labels"][i], sp_pad[i])
+            tgt_rois.append(torch.cat([(base + matched).to(b.dtype)[:, None], b[sel]], 1))
+            gt_masks.append(masks)
+            near_rows.append(near + row0)
+            base += masks.shape[0]
+        else:
+            tgt_rois.append(torch.cat([(base + l["idx"][sel]).to(b.dtype)[:, None], b[sel]], 1))
+            gt_masks.append(eroded_rect_masks(t["boxes"], Himg, Wimg))
+            base += t["boxes"].shape[0]
+        row0 += b.shape[0]
     fg_rois, fg_cls, tgt_rois = torch.cat(fg_rois), torch.cat(fg_cls), torch.cat(tgt_rois)
-    aux.update(fg_rois=fg_rois, fg_classes=fg_cls)
+    aux.update(fg_rois=fg_rois, fg_classes=fg_cls, near_rows=near_rows)
     mfeat = roi_align_levels(levels, fg_rois, Himg, 14, single=single)
     gt28 = torch.from_numpy(P.roi_align_forward(torch.cat(gt_masks)[:, None].numpy(), tgt_rois.numpy(), 1.0, 28,
                                                 28, 0, True))[:, 0] >= 0.5
@@ -633,7 +663,21 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
         return F.binary_cross_entropy_with_logits(z[ar, fg_cls], target.to(torch.float32))
 
     losses["loss_mask"] = mask_loss(logits, gt28)
-    tgt2 = logits.detach()[ar, fg_cls] > 0.0      # sigmoid > 0.5 of the first head's own prediction
+    aux["mask_targets"] = gt28
+    if mask_targets == "evidence" and fg_rois.shape[0] > 0:
+        # get_pgt_mask: the class probability pasted into the image at the proposal box, cropped back to the box
+        from .inference import paste_masks_in_image
+        prob = logits.detach()[ar, fg_cls].sigmoid()
+        tgt2 = torch.zeros_like(gt28)
+        for s0 in range(0, fg_rois.shape[0], 64):   # (chunks: the pasted images are full size)
+            sl_ = slice(s0, min(s0 + 64, fg_rois.shape[0]))
+            pasted = paste_masks_in_image(prob[sl_], fg_rois[sl_, 1:], (Himg, Wimg), 0.5).to(torch.float32)
+            rr = torch.cat([torch.arange(pasted.shape[0], dtype=torch.float32)[:, None], fg_rois[sl_, 1:]], 1)
+            tgt2[sl_] = torch.from_numpy(P.roi_align_forward(pasted[:, None].numpy(), rr.numpy(), 1.0, 28, 28, 0,
+                                                             True))[:, 0] >= 0.5
+    else:
+        tgt2 = logits.detach()[ar, fg_cls] > 0.0      # sigmoid > 0.5 of the first head's own prediction
+    aux["mask_targets_r0"] = tgt2
     logits2 = mask_head_layers(p, "roi_heads.mask_refinery_0.", mfeat)
     losses["loss_mask_r0"] = mask_loss(logits2, tgt2)
 

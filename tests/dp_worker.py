@@ -62,7 +62,7 @@ def main():
         # every trainable parameter's gradient now lives in its flat bucket, with the parameter's own strides
         for p in ex._slot:
             assert p.grad is not None and p.grad.data_ptr() == ex._slot[p][1].data_ptr() and p.grad.stride() == p.stride()
-        info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes, "loss": float(sum(losses.values()))}
+        info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes, "loss": float(sum(losses.values()).detach())}
     else:
         grads = []
         for r in range(2):
@@ -72,9 +72,7 @@ def main():
             grads.append({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
         for n, p in model.named_parameters():
             if p.requires_grad:
-                p.grad = ((grads[0][n] + grads[1][n]) / 2).contiguous(memory_format=torch.preserve_format)
-                if p.grad.stride() != p.stride():
-                    p.grad = torch.empty_like(p).copy_(p.grad)
+                p.grad = torch.empty_like(p).copy_((grads[0][n] + grads[1][n]) / 2)
         info = {}
     opt.step()
     torch.cuda.synchronize()

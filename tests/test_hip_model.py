@@ -86,6 +86,33 @@ def test_integer_artefacts_bit_exact(step):
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
     assert torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
     assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
+    # mask pseudo labels: the "10 nearest" foreground proposals of every pseudo box (rows, in order), and the
+    # superpixel-evidence targets of the first mask head — bit-exact; the refinery's paste -> crop targets come from
+    # each side's own logits (1e-5 apart), so a pixel whose pasted probability sits on 0.5 may differ
+    near = aux["near_rows"].cpu()
+    for i, want in enumerate(aux0["near_rows"]):
+        got = near[i, :cnt[i]].reshape(-1)
+        assert torch.equal(got[got >= 0].to(torch.int64), want), (i, got, want)
+    assert aux["mask_targets"].shape[0] > 0
+    assert torch.equal(aux["mask_targets"].cpu(), aux0["mask_targets"])
+    assert (aux["mask_targets_r0"].cpu() != aux0["mask_targets_r0"]).float().mean().item() < 2e-3
+
+
+def test_rectangle_mask_targets_mode_still_matches(cuda):
+    """MASK_TARGETS = "rect" (round 1's substitution: eroded pseudo-GT rectangles, thresholded refinery targets)
+    stays available and stays in parity with the oracle's same mode."""
+    params = OM.init_params(seed=3, random_bn=True, input_gain=1.0 / 64)
+    batch = OM.synthetic_batch(1234, B=2, size=256, R=160, sp_block=8)
+    losses0 = OM.forward_losses(params, batch, mask_targets="rect")
+    model = build_model(jtsm_cfg("cuda"))
+    model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    model.roi_heads.mask_targets = "rect"
+    losses = model(to_batched_inputs(batch))
+    for k in ("loss_mask", "loss_mask_r0"):
+        a, b = float(losses[k].detach()), float(losses0[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
 
 
 def test_gradients_match(step):
