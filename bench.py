@@ -41,23 +41,77 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 reference leg")
+    ap.add_argument("--cluster", type=float, default=0.1,
+                    help="fraction of the proposals drawn around the image's object rectangles (utils/synthetic.py): "
+                         "gives the mask branch a realistic foreground count; 0 = the plain uniform recipe")
+    ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] extra leg (R101, fp16)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank code-path rehearsal on a single GPU: every rank uses device 0 and the gloo backend "
                          "(not a measurement)")
     return ap.parse_args()
 
 
-def build(device):
+def build(device, depth=50):
     from model_util import jtsm_cfg
     from jtsm_amd.modeling import build_model
 
     torch.manual_seed(0)                       # identical random-init weights on every rank
-    model = build_model(jtsm_cfg(str(device)))
+    model = build_model(jtsm_cfg(str(device), depth=depth))
     model.train()
     # random msra weights are not matched to 0..255 inputs; keep activations O(1) (as in the parity tests)
     with torch.no_grad():
         model.backbone.bottom_up.stem.conv1.weight.mul_(1.0 / 64)
+        if depth > 50:   # 33 random-init residual blocks double the variance each: damp every block's last norm
+            for n, b in model.named_buffers():
+                if n.endswith("conv3.norm.weight"):
+                    b.mul_(0.3)
     return model
+
+
+def config4_leg(device, args):
+    """BASELINE configs[4] as an EXTRA leg (never the headline: fp16 is narrower than the reference's fp32):
+    R101-FPN JTSM panoptic, Cityscapes-shaped 2 x 3 x 1024 x 2048 per GPU, fp16 MFMA path (one fp16 plane per operand,
+    v_mfma_f32_32x32x16_f16, fp32 accumulate, fp32 losses), same step (fwd + bwd + SGD)."""
+    from jtsm_amd.layers import conv as conv_layers
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+
+    old = conv_layers.MATH
+    conv_layers.set_math("f16")
+    try:
+        model = build(device, depth=101)
+        opt = make_optimizer(model)
+        inputs = synthetic_inputs(1234, batch=args.batch, size=1024, width=2048, proposals=args.proposals,
+                                  device=device, cluster=args.cluster)
+
+        def step():
+            losses = model(inputs)
+            total = sum(losses.values())
+            total.backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            return total
+
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        steps = max(3, args.steps // 2)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            last = step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out = {"value": round(args.batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
+               "dtype": "f16", "steps": steps, "final_loss": round(float(last.detach()), 5),
+               "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
+               "workload": "BASELINE configs[4] on ONE GPU: R101-FPN JTSM panoptic, %d x 3x1024x2048, %d proposals + %d "
+                           "superpixels per image, fp16 MFMA path (fp16 operand planes, fp32 accumulate / losses / "
+                           "master weights, gradient planes x 2^%d)" % (args.batch, args.proposals, 32 * 64,
+                                                                       conv_layers.GRAD_SHIFT)}
+        del model, opt, inputs
+        torch.cuda.empty_cache()
+        return out
+    finally:
+        conv_layers.set_math(old)
 
 
 def make_optimizer(model, fused=True):
@@ -77,24 +131,41 @@ def make_optimizer(model, fused=True):
     return torch.optim.SGD(groups, lr=lr, momentum=0.9)
 
 
+def _mfma_peak(variant):
+    """Dense MFMA roof (TFLOP/s of ALGORITHMIC FLOPs) of a contraction instantiation: split-bf16 issues three bf16
+    products per algorithmic product; the fp16 instantiations (NP = 1) one; the igemm_* kernels are fp32 MFMA."""
+    if "_x3_" not in variant:
+        return FP32_MFMA_PEAK_TFLOPS
+    if variant.endswith(",1>") or variant.endswith("<1>"):
+        return BF16_MFMA_PEAK_TFLOPS
+    return BF16_MFMA_PEAK_TFLOPS / 3.0
+
+
 def roofline_leg(step_fn):
+    """One extra, untimed step with hipEvents around EVERY library launch (contractions: layers/conv.py LAUNCH_LOG,
+    with the split-K finishing pass separated by the library's mid-event; everything else: _lib.TIMING).  Returns the
+    roofline object of the kernel with the largest time per step — whatever its kind — and `rooflines`: one object
+    for every kernel above 2 % of the step's kernel time."""
+    from jtsm_amd import _lib
     from jtsm_amd.layers import conv
 
-    conv.LAUNCH_LOG = []
+    conv.LAUNCH_LOG, _lib.TIMING = [], []
     step_fn()
     torch.cuda.synchronize()
     log, conv.LAUNCH_LOG = conv.LAUNCH_LOG, None
+    other, _lib.TIMING = _lib.TIMING, None
     per = {}
-    finish_ms = 0.0
-    for variant, flops, span, shape in log:
-        d = per.setdefault(variant, {"launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "roof_ms": 0.0,
-                                     "hbm_bound_ms": 0.0})
-        # split-bf16 kernels issue three bf16 MFMA products per algorithmic (fp32) product: price the algorithmic
-        # rate against a third of the dense bf16 peak
-        mfma_peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if "_x3_" in variant else FP32_MFMA_PEAK_TFLOPS
+
+    def slot(name, bound):
+        return per.setdefault(name, {"bound": bound, "launches": 0, "flops": 0.0, "bytes": 0.0, "ms": 0.0, "roof_ms": 0.0,
+                                     "hbm_bound_ms": 0.0, "unknown_bytes": 0})
+
+    for variant, flops, span, shape, finish_bytes in log:
+        d = slot(str(variant), "mfma")
+        d["peak"] = _mfma_peak(str(variant))
         nbytes = float(shape[-1]) if shape is not None else 0.0
         k = span.kernel_ms()            # the contraction kernel alone (library hook), as rocprofv3 reports it
-        t_mfma = flops / (mfma_peak * 1e12) * 1e3
+        t_mfma = flops / (d["peak"] * 1e12) * 1e3
         t_hbm = nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
         d["launches"] += 1
         d["flops"] += flops
@@ -103,53 +174,101 @@ def roofline_leg(step_fn):
         d["roof_ms"] += max(t_mfma, t_hbm)          # the tighter roof of THIS launch's shape
         if t_hbm > t_mfma:
             d["hbm_bound_ms"] += k
-        finish_ms += max(span.call_ms() - k, 0.0)   # its split-K finishing pass, when there is one
-    for d in per.values():
-        d["tflops"] = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
-        d["gbs"] = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
-        d["avg_us"] = 1e3 * d["ms"] / d["launches"]
-    dom = max(per, key=lambda k: per[k]["ms"])
-    D = per[dom]
-    x3 = "_x3_" in dom
-    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3 else FP32_MFMA_PEAK_TFLOPS
-    traffic = None
+        fin = max(span.call_ms() - k, 0.0)           # its split-K finishing pass, when there is one
+        if finish_bytes > 0:
+            f = slot("splitk_finish<4>", "hbm")
+            f["launches"] += 1
+            f["bytes"] += finish_bytes
+            f["ms"] += fin
+            f["roof_ms"] += finish_bytes / (HBM_PEAK_GBS * 1e9) * 1e3
+            f["hbm_bound_ms"] += fin
+    for name, span, nbytes in other:
+        d = slot(name, "hbm")
+        ms = span.ms()
+        d["launches"] += 1
+        d["ms"] += ms
+        if nbytes is None:
+            d["unknown_bytes"] += 1
+        else:
+            d["bytes"] += nbytes
+            d["roof_ms"] += nbytes / (HBM_PEAK_GBS * 1e9) * 1e3
+            d["hbm_bound_ms"] += ms
+    total_ms = sum(d["ms"] for d in per.values())
+
+    def describe(name, d):
+        tflops = d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0
+        gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9 if d["ms"] > 0 else 0.0
+        # one instantiation serves shapes on both sides of the ridge: `bound` is the roof that holds for the larger
+        # share of the kernel's time
+        hbm = d["bound"] == "hbm" or d["hbm_bound_ms"] > 0.5 * d["ms"]
+        out = {"kernel": name, "ms_per_step": round(d["ms"], 3), "share_of_kernel_time": round(d["ms"] / total_ms, 4),
+               "launches_per_step": d["launches"], "avg_launch_us": round(1e3 * d["ms"] / max(d["launches"], 1), 2)}
+        if d["bound"] == "hbm" and d["unknown_bytes"]:
+            out.update({"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+                        "note": "no algorithmic byte count attached to this entry point"})
+            return out
+        if hbm:
+            out.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "algorithmic_mb_per_launch": round(d["bytes"] / max(d["launches"], 1) / 1e6, 3)})
+        else:
+            out.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": round(d["peak"], 1), "unit": "TFLOP/s",
+                        "frac": round(tflops / d["peak"], 4),
+                        "algorithmic_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+                        "algorithmic_mb_per_launch": round(d["bytes"] / d["launches"] / 1e6, 2)})
+        if d["bound"] == "mfma":
+            out.update({"mfma_frac": round(tflops / d["peak"], 4), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "hbm_bound_share_of_time": round(d["hbm_bound_ms"] / d["ms"], 3) if d["ms"] > 0 else None,
+                        # per-launch roofline: sum over launches of max(flops/peak_mfma, bytes/peak_hbm) / measured time
+                        "roofline_time_frac": round(d["roof_ms"] / d["ms"], 4) if d["ms"] > 0 else None})
+        return out
+
+    traffic_tab = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.isfile(pmc):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command
-        t = json.load(open(pmc)).get("kernels", {}).get(dom)
-        if t:
-            traffic = {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "source": "profiles/pmc_traffic.json",
-                       "note": t.get("note", "")}
-    total_ms = sum(d["ms"] for d in per.values())
-    total_fl = sum(d["flops"] for d in per.values())
-    # One instantiation serves shapes on both sides of the ridge (res2's 64-channel layers are HBM-bound, res4's
-    # are MFMA-bound): the kernel's `bound` is the roof that holds for the larger share of its time.
-    hbm = D["hbm_bound_ms"] > 0.5 * D["ms"]
-    out = {"bound": "hbm", "kernel": dom, "achieved": round(D["gbs"], 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": round(D["gbs"] / HBM_PEAK_GBS, 4)} if hbm else \
-          {"bound": "mfma", "kernel": dom, "achieved": round(D["tflops"], 2), "peak": round(peak, 1),
-           "unit": "TFLOP/s", "frac": round(D["tflops"] / peak, 4)}
-    out.update({
-        "traffic": traffic,
-        "peak_note": ("mfma roof: dense bf16 MFMA peak %.0f TFLOP/s / 3 bf16 products per fp32 product "
-                      "(csrc/conv_x3.h), algorithmic fp32 FLOPs / time" % BF16_MFMA_PEAK_TFLOPS if x3 else
-                      "mfma roof: dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)") +
-                     "; hbm roof: 8 TB/s, algorithmic bytes = each operand read once + the result written once",
-        "mfma_frac": round(D["tflops"] / peak, 4), "hbm_frac": round(D["gbs"] / HBM_PEAK_GBS, 4),
-        "hbm_bound_share_of_time": round(D["hbm_bound_ms"] / D["ms"], 3) if D["ms"] > 0 else None,
-        # per-launch roofline: sum over launches of max(flops/peak_mfma, bytes/peak_hbm) / measured time
-        "roofline_time_frac": round(D["roof_ms"] / D["ms"], 4) if D["ms"] > 0 else None,
-        "launches_per_step": D["launches"], "avg_launch_us": round(D["avg_us"], 2),
-        "algorithmic_gflop_per_launch": round(D["flops"] / D["launches"] / 1e9, 3),
-        "algorithmic_mb_per_launch": round(D["bytes"] / D["launches"] / 1e6, 2),
-        "all_contractions": {"tflops": round(total_fl / ((total_ms + finish_ms) * 1e-3) / 1e12, 2),
-                             "ms_per_step": round(total_ms + finish_ms, 3), "splitk_finish_ms": round(finish_ms, 3),
-                             "gflop_per_step": round(total_fl / 1e9, 1),
-                             "roofline_time_frac": round(sum(v["roof_ms"] for v in per.values()) / total_ms, 4),
-                             "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
-                                               "tflops": round(v["tflops"], 2), "gbs": round(v["gbs"], 1),
-                                               "roofline_time_frac": round(v["roof_ms"] / v["ms"], 4)}
-                                           for k, v in sorted(per.items()) if v["ms"] > 0}},
-    })
+        traffic_tab = json.load(open(pmc)).get("kernels", {})
+
+    def traffic_of(name):
+        t = traffic_tab.get(name)
+        if not t:
+            return None
+        return {"hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "source": "profiles/pmc_traffic.json",
+                "note": t.get("note", "")}
+
+    ranked = sorted(per.items(), key=lambda kv: -kv[1]["ms"])
+    dom_name, D = ranked[0]
+    out = describe(dom_name, D)
+    out["traffic"] = traffic_of(dom_name)
+    out["peak_note"] = ("mfma roofs: dense bf16 / fp16 MFMA peak %.0f TFLOP/s (split-bf16 kernels: / 3 bf16 products per "
+                        "fp32 product, csrc/conv_x3.h), fp32 MFMA %.1f; algorithmic FLOPs / time.  hbm roof: 8 TB/s; "
+                        "algorithmic bytes = every operand read once + the result written once (split-K finishing: every "
+                        "slab read once + result, planes and epilogue operands once)" % (BF16_MFMA_PEAK_TFLOPS,
+                                                                                         FP32_MFMA_PEAK_TFLOPS))
+    rooflines = []
+    for name, d in ranked:
+        if d["ms"] < 0.02 * total_ms:
+            break
+        r = describe(name, d)
+        r["traffic"] = traffic_of(name)
+        rooflines.append(r)
+    contr = {k: v for k, v in per.items() if v["bound"] == "mfma"}
+    c_ms = sum(v["ms"] for v in contr.values())
+    c_fl = sum(v["flops"] for v in contr.values())
+    fin_ms = per.get("splitk_finish<4>", {"ms": 0.0})["ms"]
+    out["kernel_time_ms_per_step"] = round(total_ms, 3)
+    out["rooflines_over_2pct"] = rooflines
+    out["all_contractions"] = {
+        "tflops": round(c_fl / ((c_ms + fin_ms) * 1e-3) / 1e12, 2), "ms_per_step": round(c_ms + fin_ms, 3),
+        "splitk_finish_ms": round(fin_ms, 3), "gflop_per_step": round(c_fl / 1e9, 1),
+        "roofline_time_frac": round(sum(v["roof_ms"] for v in contr.values()) / c_ms, 4) if c_ms > 0 else None,
+        "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                          "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                          "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                          "roofline_time_frac": round(v["roof_ms"] / v["ms"], 4)}
+                      for k, v in sorted(contr.items()) if v["ms"] > 0}}
+    out["other_entry_points"] = {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                     "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if not v["unknown_bytes"] and v["ms"] > 0 else None}
+                                 for k, v in ranked if v["bound"] == "hbm" and v["ms"] >= 0.01}
     return out
 
 
@@ -191,8 +310,9 @@ def main():
     from jtsm_amd.layers import conv as conv_layers
     conv_math = conv_layers.MATH
     model = build(device)
-    inputs = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device)
-    # one process per GPU; bucketed RCCL all-reduce of gradients overlapped with the backward
+    inputs = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device,
+                              cluster=args.cluster)
+    # one process per GPU; this repo's own bucketed reduce-scatter + all-gather over RCCL, overlapped with the backward
     net = dp.wrap_data_parallel(model, device)
     opt = make_optimizer(model)
 
@@ -229,16 +349,21 @@ def main():
             "config": {
                 "workload": "BASELINE configs[2]: projects/WSL JTSM panoptic R50-FPN composite, COCO-shaped synthetic, "
                             "%d x 3x%dx%d per GPU, %d proposals + %d superpixels per image; MIL + 4 OICR refinements + "
-                            "2 mask heads + sem-seg head; fwd + bwd + all-reduce + SGD" % (
-                                args.batch, args.size, args.size, args.proposals, (args.size // 32) ** 2),
+                            "2 mask heads + sem-seg head; fwd + bwd + gradient exchange + SGD; %d %% of the proposals "
+                            "are jittered copies of the image's 3 object rectangles (the way real proposal sets crowd "
+                            "around objects), the rest uniform" % (
+                                args.batch, args.size, args.size, args.proposals, (args.size // 32) ** 2,
+                                round(100 * args.cluster)),
                 "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                "substitutions": "grabCut/polygon pseudo-masks -> eroded pseudo-GT rectangles (SURVEY F8, §8d); dropout on",
+                "substitutions": "grabCut -> the reference's own superpixel-evidence masks (object_evidence, "
+                                 "roi_heads_jtsm.py:1928-1994); polygon encoding of masks skipped (bitmasks); pseudo semantic "
+                                 "target from eroded pseudo-GT rectangles; dropout on",
                 "weights": "random init (msra/xavier as the reference), FrozenBN identity, stem x1/64",
                 "math": ("contractions in split-bf16: fp32 operands -> bf16 hi+lo planes, a_lo*b_hi + a_hi*b_lo + a_hi*b_hi "
                          "on v_mfma_f32_32x32x16_bf16 with fp32 accumulate; measured error <= 6e-6 relative per layer "
                          "against fp64 (bar 1e-4); everything else fp32. JTSM_CONV_MATH=f32 selects exact fp32 MFMA "
                          "(see `exact_fp32`)") if conv_math != "f32" else "exact fp32 MFMA contractions",
-                "torch_device_ops": ["dropout", "DDP all-reduce", "sort / gather / rasterisation glue of the label path"],
+                "torch_device_ops": ["dropout", "sort / gather glue of the label path", "RCCL collectives (N > 1)"],
                 "final_loss": round(loss_value, 5), "lr": 1e-7,
                 "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
             },
@@ -263,6 +388,10 @@ def main():
         out["exact_fp32"] = {"value": round(args.batch * args.steps / dt32, 3), "unit": "images/sec",
                              "ms_per_step": round(1e3 * dt32 / args.steps, 3), "dtype": "f32",
                              "note": "JTSM_CONV_MATH=f32: v_mfma_f32_32x32x2_f32 contractions, same model, same step"}
+    if world == 1 and not args.no_config4:
+        del net, opt, model, inputs
+        torch.cuda.empty_cache()
+        out["config4_fp16"] = config4_leg(device, args)
     if world > 1:
         torch.distributed.barrier()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

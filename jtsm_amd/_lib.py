@@ -39,7 +39,68 @@ def lib():
                      "jtsm_moi_pool_backward_levels_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_size_t
+    if TIMING is not None:
+        return _TimedLib(_lib)
     return _lib
+
+
+# ---- optional per-entry-point timing (bench.py's roofline leg) ------------------------------------------------
+# While TIMING is a list, every compute entry point called through `timed_lib()` is bracketed by hipEvents on the
+# launch stream and logged as (name, EventSpan, algorithmic bytes or None).  Call sites that know their algorithmic
+# traffic announce it with note_bytes() right before the call.  Nothing of this runs in normal operation.
+TIMING = None
+_pending_bytes = None
+_UNTIMED = ("jtsm_event_", "jtsm_last_error", "jtsm_version", "jtsm_device_count", "jtsm_conv_set_mid_event",
+            "jtsm_conv_plan", "jtsm_conv_bf16x3_plan", "jtsm_conv_bf16x3_eligible", "jtsm_conv_out_size",
+            "jtsm_conv2d_")   # (the contractions carry their own, finer instrumentation: layers/conv.py LAUNCH_LOG)
+
+
+def note_bytes(nbytes):
+    """Algorithmic HBM bytes of the NEXT library call (only looked at while TIMING is recording)."""
+    global _pending_bytes
+    if TIMING is not None:
+        _pending_bytes = float(nbytes)
+
+
+class EventSpan(object):
+    __slots__ = ("a", "b")
+
+    def __init__(self, raw):
+        self.a, self.b = raw.jtsm_event_create(), raw.jtsm_event_create()
+
+    def ms(self):
+        out = C.c_float()
+        return out.value if lib().jtsm_event_elapsed_ms(C.c_void_p(self.a), C.c_void_p(self.b), C.byref(out)) == 0 else 0.0
+
+    def __del__(self):
+        try:
+            for e in (self.a, self.b):
+                lib().jtsm_event_destroy(C.c_void_p(e))
+        except Exception:
+            pass
+
+
+class _TimedLib(object):
+    def __init__(self, raw):
+        self._raw = raw
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if TIMING is None or name.endswith("_workspace_bytes") or name.startswith(_UNTIMED):
+            return fn
+        raw = self._raw
+
+        def timed(*args):
+            global _pending_bytes
+            span = EventSpan(raw)
+            st = stream()
+            raw.jtsm_event_record(C.c_void_p(span.a), st)
+            rc = fn(*args)
+            raw.jtsm_event_record(C.c_void_p(span.b), st)
+            TIMING.append((name, span, _pending_bytes))
+            _pending_bytes = None
+            return rc
+        return timed
 
 
 def check(rc, what=""):
@@ -69,12 +130,22 @@ def stream():
     return C.c_void_p(_raw_stream(_device_index))
 
 
+def _check_device(t):
+    """One process drives ONE GPU (stream() caches its index): a tensor on another device must not be launched on
+    this device's stream."""
+    if _device_index is not None and t.device.index is not None and t.device.index != _device_index:
+        raise RuntimeError("jtsm_amd: this process launches on cuda:%d but got a tensor on %s (one process per GPU)"
+                           % (_device_index, t.device))
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise RuntimeError(
                 "jtsm_amd operators run only on the HIP device (got a %s tensor); "
                 "there is no CPU path in the product" % t.device)
+        if t is not None:
+            _check_device(t)
 
 
 def f32(x):

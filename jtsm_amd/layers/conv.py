@@ -71,6 +71,7 @@ def _split(t, grad=False):
         raise RuntimeError("split_bf16: tensor must be channels_last (4-d) or contiguous")
     buf = _planes_buf(t.numel(), t.device)
     hi, lo = _hl(buf)
+    L.note_bytes((6.0 if MATH == "f16" else 8.0) * t.numel())   # fp32 read, planes written
     if MATH == "f16":
         L.check(L.lib().jtsm_split_f16_f32(L.ptr(t), hi, C.c_long(t.numel()), GRAD_SHIFT if grad else 0, L.stream()),
                 "split_f16")
@@ -232,6 +233,7 @@ def refresh_weight_planes():
             if len(_WTABLES) > 8:
                 _WTABLES.clear()
             _WTABLES[tkey] = tab
+        L.note_bytes((6.0 if MATH == "f16" else 8.0) * sum(e.w.numel() for _, e in stale))
         L.check(L.lib().jtsm_split_bf16_multi_f32(L.ptr(tab[0]), len(stale), C.c_long(tab[1]), int(transposed),
                                                   L.stream()), "split_bf16_multi")
         for _, e in stale:
@@ -303,15 +305,24 @@ def _x3_variant(s, role):
         return None
     v = [C.c_int() for _ in range(6)]
     L.check(L.lib().jtsm_conv_bf16x3_plan(C.byref(s), role, *[C.byref(x) for x in v]), "conv_bf16x3_plan")
-    wm, wn, tm, tn, nbuf, _ = [x.value for x in v]
+    wm, wn, tm, tn, nbuf, splits = [x.value for x in v]
+    np_ = ",1" if MATH == "f16" else ""    # the fp16 instantiations carry NP = 1 as their last template argument
     if role == 2:
         if nbuf == 0:
-            return "igemm_x3_wgrad_halo_kernel"
-        return "igemm_x3_wgrad_kernel<%d,%d,%d,%d,%d>" % (wm, wn, tm, tn, nbuf)
+            return _Variant("igemm_x3_wgrad_halo_kernel" + ("<1>" if MATH == "f16" else ""), splits)
+        return _Variant("igemm_x3_wgrad_kernel<%d,%d,%d,%d,%d%s>" % (wm, wn, tm, tn, nbuf, np_), splits)
     if nbuf == 0:   # the LDS-halo 3x3 kernel
-        return "igemm_x3_halo_kernel<%s,%d,%d,%d,%d,%d>" % (_ROLE_NAME[role], 16 if wm == 4 else 8, wm, wn, tn,
-                                                           21 if wm == 4 else 12)
-    return "igemm_x3_kernel<%s,%d,%d,%d,%d,%d>" % (_ROLE_NAME[role], wm, wn, tm, tn, nbuf)
+        return _Variant("igemm_x3_halo_kernel<%s,%d,%d,%d,%d,%d%s>" % (_ROLE_NAME[role], 16 if wm == 4 else 8, wm, wn,
+                                                                       tn, 21 if wm == 4 else 12, np_), splits)
+    return _Variant("igemm_x3_kernel<%s,%d,%d,%d,%d,%d%s>" % (_ROLE_NAME[role], wm, wn, tm, tn, nbuf, np_), splits)
+
+
+class _Variant(str):
+    """Kernel instantiation name that also remembers the K slices of the call (for the finishing pass's bytes)."""
+    def __new__(cls, name, splits=1):
+        o = str.__new__(cls, name)
+        o.splits = splits
+        return o
 
 
 class LaunchSpan(object):
@@ -343,12 +354,19 @@ class LaunchSpan(object):
             pass
 
 
-def _timed(variant, flops, call, shape=None, extra_elems=0):
+def _timed(variant, flops, call, shape=None, extra_elems=0, out_elems=0, planes=False):
     """`extra_elems`: elements of the fused epilogue's extra fp32 operands (residual, accumulate, ReLU mask) — part
-    of the launch's algorithmic bytes."""
+    of the launch's algorithmic bytes.  `out_elems` / `planes`: size of the result and whether its operand planes are
+    emitted — what a split-K finishing pass moves: every slab read once, the result (+ planes, + the epilogue's extra
+    operands) written / read once."""
     if LAUNCH_LOG is None:
         return call()
-    if shape is not None and extra_elems:
+    splits = getattr(variant, "splits", 1)
+    finish_bytes = 0.0
+    if splits > 1:
+        plane_b = (2.0 if MATH == "f16" else 4.0) if planes else 0.0
+        finish_bytes = out_elems * (4.0 * splits + 4.0 + plane_b) + 4.0 * extra_elems
+    if shape is not None and extra_elems and splits <= 1:
         shape = shape[:-1] + (shape[-1] + 4.0 * extra_elems,)
     lib = L.lib()
     span = LaunchSpan()
@@ -358,7 +376,7 @@ def _timed(variant, flops, call, shape=None, extra_elems=0):
     rc = call()
     lib.jtsm_conv_set_mid_event(None)
     lib.jtsm_event_record(C.c_void_p(span.b), st)
-    LAUNCH_LOG.append((variant, flops, span, shape))
+    LAUNCH_LOG.append((variant, flops, span, shape, finish_bytes))
     return rc
 
 
@@ -376,9 +394,11 @@ def _variant(s, role, has_kscale=False):
     k, bm, bn, sp = C.c_int(), C.c_int(), C.c_int(), C.c_int()
     L.check(L.lib().jtsm_conv_plan(C.byref(s), role, int(has_kscale), C.byref(k), C.byref(bm), C.byref(bn),
                                    C.byref(sp)), "conv_plan")
+    splits = 1 if role == 2 else sp.value      # (the fp32 weight gradient accumulates with atomics: no finishing pass)
     if k.value == 0:
-        return "igemm_kernel<%s,%d,%d>" % (_ROLE_NAME[role], bm.value, bn.value)
-    return "igemm_dma_kernel<%s,%d,%d,%d>" % (_ROLE_NAME[role], bm.value, bn.value, 2 if k.value == 1 else 1)
+        return _Variant("igemm_kernel<%s,%d,%d>" % (_ROLE_NAME[role], bm.value, bn.value), splits)
+    return _Variant("igemm_dma_kernel<%s,%d,%d,%d>" % (_ROLE_NAME[role], bm.value, bn.value, 2 if k.value == 1 else 1),
+                    splits)
 
 
 def _desc(s):
@@ -447,17 +467,19 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
         if MATH == "f16":
             L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f16(
                 xh, wh, L.ptr(y), yh, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-                L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward_f16")
+                L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual), y.numel(), ybuf is not None),
+                    "conv2d_forward_f16")
         else:
             L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
                 xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-                L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward_bf16x3")
+                L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual), y.numel(), ybuf is not None),
+                    "conv2d_forward_bf16x3")
         if ybuf is not None:
             planes_put(y, ybuf)
         return y
     L.check(_timed(_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f32(
         L.ptr(x), L.ptr(w), L.ptr(y), pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual)), "conv2d_forward")
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual), y.numel()), "conv2d_forward")
     return y
 
 
@@ -486,19 +508,19 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         if MATH == "f16":
             L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_f16(
                 gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), GRAD_SHIFT, L.ptr(ws),
-                C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
-                    "conv2d_backward_data_f16")
+                C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask), dx.numel(),
+                    dbuf is not None), "conv2d_backward_data_f16")
         else:
             L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_bf16x3(
                 gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), L.ptr(relu_mask), L.ptr(ws),
-                C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
-                    "conv2d_backward_data_bf16x3")
+                C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask), dx.numel(),
+                    dbuf is not None), "conv2d_backward_data_bf16x3")
         if dbuf is not None:
             planes_put(dx, dbuf)
         return dx
     L.check(_timed(_variant(s, 1, kscale is not None), pl.flops, lambda: lib.jtsm_conv2d_backward_data_f32(
         L.ptr(dy), L.ptr(w), L.ptr(dx), pl.ref, L.ptr(kscale), L.ptr(accumulate), L.ptr(relu_mask),
-        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask)),
+        L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(accumulate) + _numel(relu_mask), dx.numel()),
             "conv2d_backward_data")
     return dx
 
@@ -527,11 +549,11 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
         if MATH == "f16":
             L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_f16(
                 gh, xh, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes),
-                L.stream()), pl.desc), "conv2d_backward_weight_f16")
+                L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_f16")
         else:
             L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
                 gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws), C.c_size_t(nbytes),
-                L.stream()), pl.desc), "conv2d_backward_weight_bf16x3")
+                L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_bf16x3")
         return out
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:

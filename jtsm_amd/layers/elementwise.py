@@ -26,6 +26,7 @@ def relu_backward(dy, y, emit_planes=False):
         from . import conv
         buf = conv._planes_buf(n, y.device)
         hi, lo = conv._hl(buf)
+        L.note_bytes((14.0 if conv.MATH == "f16" else 16.0) * n)   # dy, y read; g and its planes written
         if conv.MATH == "f16":
             L.check(L.lib().jtsm_relu_backward_split_f16(L.ptr(dy), L.ptr(y), L.ptr(g), hi, C.c_long(n), conv.GRAD_SHIFT,
                                                          L.stream()), "relu_backward_split_f16")
@@ -49,6 +50,7 @@ def channel_sum(g):
         g = g.contiguous()
         rows, ch = g.shape
     out = torch.empty(ch, dtype=g.dtype, device=g.device)
+    L.note_bytes(4.0 * g.numel())
     L.check(L.lib().jtsm_channel_sum_f32(L.ptr(g), L.ptr(out), C.c_long(rows), ch, L.stream()), "channel_sum")
     return out
 
@@ -315,6 +317,7 @@ class _SemSegCE(torch.autograd.Function):
         lib = L.lib()
         out = torch.empty(2, dtype=torch.float32, device=logits.device)
         wsb = torch.empty(lib.jtsm_semseg_ce_workspace_bytes(n, hs, ws, scale), dtype=torch.uint8, device=logits.device)
+        L.note_bytes(4.0 * n * hs * ws * c + 8.0 * target.numel())     # stride-4 logits + full-resolution labels
         L.check(lib.jtsm_semseg_ce_forward_f32(L.ptr(logits), ld, c, L.ptr(target), L.ptr(out), L.ptr(wsb), n, hs, ws,
                                                scale, C.c_long(ignore_index), L.stream()), "semseg_ce_forward")
         ctx.save_for_backward(logits, target, out, wsb)
@@ -328,6 +331,7 @@ class _SemSegCE(torch.autograd.Function):
         n, c, hs, ws = logits.shape
         dfull = torch.empty((n, hs, ws, ld), dtype=torch.float32, device=logits.device)
         g = g.to(torch.float32).contiguous()
+        L.note_bytes(4.0 * n * hs * ws * c + 8.0 * target.numel() + 4.0 * dfull.numel())
         L.check(L.lib().jtsm_semseg_ce_backward_f32(L.ptr(logits), ld, c, L.ptr(target), L.ptr(out), L.ptr(g),
                                                     L.ptr(dfull), L.ptr(wsb), n, hs, ws, scale,
                                                     C.c_long(ignore_index), L.stream()), "semseg_ce_backward")

@@ -66,6 +66,9 @@ class _AlignLevels(Function):
         out = torch.empty((M, C, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)  # every roi is on exactly one level, whose kernel writes all of its bins
         for lvl, (f, sc) in enumerate(zip(feats, scales)):
             B, _, H, W = f.shape
+            # algorithmic bytes: this level's share of the output + the level's map read once (an upper
+            # bound on the unique feature bytes touched) + the rois
+            L.note_bytes(4.0 * (out.numel() / len(feats) + f.numel() + rois.numel()))
             L.check(L.lib().jtsm_roi_align_forward_level_f32(
                 L.ptr(f), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(out), B, C, H, W, M, L.f32(sc), res, res,
                 sampling_ratio, int(aligned), L.stream()), "roi_align_forward_level")
@@ -86,6 +89,7 @@ class _AlignLevels(Function):
                 continue
             B, C, H, W = shape
             gi = torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
+            L.note_bytes(4.0 * (g.numel() / len(shapes) + gi.numel() + rois.numel()))   # read g, write the map
             L.check(L.lib().jtsm_roi_align_backward_level_f32(
                 L.ptr(g), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(gi), B, C, H, W, rois.shape[0], L.f32(sc),
                 res, res, sampling_ratio, int(aligned), L.stream()), "roi_align_backward_level")
@@ -113,6 +117,8 @@ class _MOILevels(Function):
         ptrs = (C.c_void_p * nl)(*[f.data_ptr() for f in feats])
         ws = torch.empty(lib.jtsm_moi_pool_levels_workspace_bytes(B, Hs, Ws, nl, M, Lw), dtype=torch.uint8,
                          device=rois.device)
+        # algorithmic bytes: every map, the labels and the superpixels read once; output + argmax written
+        L.note_bytes(4.0 * (sum(f.numel() for f in feats) + oh_labels.numel() + superpixels.numel() + 2 * out.numel()))
         L.check(lib.jtsm_moi_pool_forward_levels_f32(
             ptrs, Hs, Ws, sc, nl, L.ptr(rois), L.ptr(roi_level), L.ptr(oh_labels), L.ptr(superpixels), L.ptr(out),
             L.ptr(arg), L.ptr(ws), B, Cc, M, Lw, superpixels.shape[1], superpixels.shape[2], res, res, L.stream()),
@@ -138,6 +144,7 @@ class _MOILevels(Function):
         lib = L.lib()
         ws = torch.empty(max(lib.jtsm_moi_pool_backward_levels_workspace_bytes(Hs, Ws, nl, B, rois.shape[0]), 16),
                          dtype=torch.uint8, device=g.device)
+        L.note_bytes(4.0 * (2 * g.numel() + sum(t.numel() for t in grads)))   # gradient + argmax read, maps written
         L.check(lib.jtsm_moi_pool_backward_levels_f32(
             L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
             L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "moi_pool_backward_levels")

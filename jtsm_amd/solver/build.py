@@ -70,6 +70,7 @@ class SGD(torch.optim.Optimizer):
             host[:nwords].copy_(torch.tensor(rows, dtype=torch.int64).view(-1))
             table = st["dev"][:nwords]
             table.copy_(host[:nwords], non_blocking=True)
+            L.note_bytes(20.0 * sum(r[3] for r in rows))   # param, grad, momentum read; param, momentum written
             L.check(L.lib().jtsm_sgd_momentum_multi_f32(L.ptr(table), len(rows), C.c_long(blocks), int(bool(first)),
                                                         L.stream()), "sgd_momentum_multi")
             torch.autograd.graph.increment_version(touched)   # updated behind autograd's back: say so

@@ -53,6 +53,8 @@ def test_two_ranks_real_model_step_is_mean_of_means(cuda, tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     worst = {}
     for n in ref:
+        if n.endswith("box_predictor.det.bias"):
+            continue   # its gradient is exactly zero in exact arithmetic (softmax over the bag): rounding noise only
         a, b = r0["params"][n].double(), ref[n].double()
         scale = (b - b.mean()).abs().max().item() + 1e-12
         worst[n] = (a - b).abs().max().item() / scale
