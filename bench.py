@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 reference leg")
-    ap.add_argument("--cluster", type=float, default=0.1,
+    ap.add_argument("--cluster", type=float, default=0.25,
                     help="fraction of the proposals drawn around the image's object rectangles (utils/synthetic.py): "
                          "gives the mask branch a realistic foreground count; 0 = the plain uniform recipe")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] extra leg (R101, fp16)")

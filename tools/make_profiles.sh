@@ -7,12 +7,12 @@ set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/art
 mkdir -p $A
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact > $A/pmc_fetch.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact > $A/pmc_write.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-config4 > $A/pmc_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-config4 > $A/pmc_write.log 2>&1 &&
 python tools/pmc_traffic.py $A/pmc profiles/pmc_traffic.json && cp profiles/pmc_traffic.json $A/pmc_traffic.json &&
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $A/pmc/mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact > $A/pmc_mfma.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $A/pmc/mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-config4 > $A/pmc_mfma.log 2>&1 &&
 (cd tools && python pmc_mfma.py ../$A/pmc/mfma ../profiles/pmc_mfma.json) && cp profiles/pmc_mfma.json $A/pmc_mfma.json &&
-rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact > $A/prof_bench.json 2> $A/prof.log &&
+rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 > $A/prof_bench.json 2> $A/prof.log &&
 cp $A/prof/r_kernel_stats.csv $A/kernel_stats.csv &&
 python bench.py --steps 20 --warmup 5 > $A/bench.json 2> $A/bench.err &&
 python tools/stock_baseline.py > $A/stock.json 2> $A/stock.err &&
