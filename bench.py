@@ -41,9 +41,11 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 reference leg")
-    ap.add_argument("--cluster", type=float, default=0.25,
-                    help="fraction of the proposals drawn around the image's object rectangles (utils/synthetic.py): "
-                         "gives the mask branch a realistic foreground count; 0 = the plain uniform recipe")
+    ap.add_argument("--cluster", type=float, default=1.0,
+                    help="fraction of the proposals that are jittered copies of --objects rectangles per image "
+                         "(utils/synthetic.py): gives the mask branch a realistic foreground count; 0 = the plain "
+                         "uniform recipe of round 1")
+    ap.add_argument("--objects", type=int, default=40, help="proposal groups per image (see --cluster)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] extra leg (R101, fp16)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank code-path rehearsal on a single GPU: every rank uses device 0 and the gloo backend "
@@ -81,7 +83,7 @@ def config4_leg(device, args):
         model = build(device, depth=101)
         opt = make_optimizer(model)
         inputs = synthetic_inputs(1234, batch=args.batch, size=1024, width=2048, proposals=args.proposals,
-                                  device=device, cluster=args.cluster)
+                                  device=device, cluster=args.cluster, objects=args.objects)
 
         def step():
             losses = model(inputs)
@@ -311,7 +313,7 @@ def main():
     conv_math = conv_layers.MATH
     model = build(device)
     inputs = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device,
-                              cluster=args.cluster)
+                              cluster=args.cluster, objects=args.objects)
     # one process per GPU; this repo's own bucketed reduce-scatter + all-gather over RCCL, overlapped with the backward
     net = dp.wrap_data_parallel(model, device)
     opt = make_optimizer(model)
@@ -350,10 +352,12 @@ def main():
                 "workload": "BASELINE configs[2]: projects/WSL JTSM panoptic R50-FPN composite, COCO-shaped synthetic, "
                             "%d x 3x%dx%d per GPU, %d proposals + %d superpixels per image; MIL + 4 OICR refinements + "
                             "2 mask heads + sem-seg head; fwd + bwd + gradient exchange + SGD; %d %% of the proposals "
-                            "are jittered copies of the image's 3 object rectangles (the way real proposal sets crowd "
-                            "around objects), the rest uniform" % (
+                            "are jittered copies (each edge +-12 %%) of %d rectangles per image, the way real proposal "
+                            "sets crowd around regions, the rest uniform — so that a mined pseudo box has O(100) "
+                            "foreground proposals whichever one the random-init detector picks (`round1_workload`: "
+                            "the uniform recipe of round 1)" % (
                                 args.batch, args.size, args.size, args.proposals, (args.size // 32) ** 2,
-                                round(100 * args.cluster)),
+                                round(100 * args.cluster), args.objects),
                 "global_batch": args.batch * world, "parallelism": "dp%d" % world,
                 "substitutions": "grabCut -> the reference's own superpixel-evidence masks (object_evidence, "
                                  "roi_heads_jtsm.py:1928-1994); polygon encoding of masks skipped (bitmasks); pseudo semantic "
@@ -388,6 +392,23 @@ def main():
         out["exact_fp32"] = {"value": round(args.batch * args.steps / dt32, 3), "unit": "images/sec",
                              "ms_per_step": round(1e3 * dt32 / args.steps, 3), "dtype": "f32",
                              "note": "JTSM_CONV_MATH=f32: v_mfma_f32_32x32x2_f32 contractions, same model, same step"}
+    if world == 1 and args.cluster > 0 and not args.no_exact:
+        # continuity with round 1: the same model and step on the uniform proposal recipe (foreground rois ~ 7)
+        inputs_u = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device)
+        inputs, keep = inputs_u, inputs
+        for _ in range(2):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dtu = time.perf_counter() - t0
+        out["round1_workload"] = {"value": round(args.batch * args.steps / dtu, 3), "unit": "images/sec",
+                                  "ms_per_step": round(1e3 * dtu / args.steps, 3), "dtype": conv_math,
+                                  "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
+                                  "note": "uniform-random proposals (--cluster 0), the workload BENCH_r01 measured"}
+        inputs = keep
     if world == 1 and not args.no_config4:
         del net, opt, model, inputs
         torch.cuda.empty_cache()

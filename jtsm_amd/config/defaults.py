@@ -24,6 +24,15 @@ _DEFAULTS = {
         "BACKBONE": {"NAME": "build_resnet_backbone", "FREEZE_AT": 2},
         "FPN": {"IN_FEATURES": [], "OUT_CHANNELS": 256, "NORM": "", "FUSE_TYPE": "sum"},
         "PROPOSAL_GENERATOR": {"NAME": "RPN", "MIN_SIZE": 0},
+        # detectron2/config/defaults.py:156-222 (anchor generator, RPN)
+        "ANCHOR_GENERATOR": {"NAME": "DefaultAnchorGenerator", "SIZES": [[32, 64, 128, 256, 512]],
+                             "ASPECT_RATIOS": [[0.5, 1.0, 2.0]], "ANGLES": [[-90, 0, 90]], "OFFSET": 0.0},
+        "RPN": {"HEAD_NAME": "StandardRPNHead", "IN_FEATURES": ["res4"], "BOUNDARY_THRESH": -1,
+                "IOU_THRESHOLDS": [0.3, 0.7], "IOU_LABELS": [0, -1, 1], "BATCH_SIZE_PER_IMAGE": 256,
+                "POSITIVE_FRACTION": 0.5, "BBOX_REG_LOSS_TYPE": "smooth_l1", "BBOX_REG_LOSS_WEIGHT": 1.0,
+                "BBOX_REG_WEIGHTS": (1.0, 1.0, 1.0, 1.0), "SMOOTH_L1_BETA": 0.0, "LOSS_WEIGHT": 1.0,
+                "PRE_NMS_TOPK_TRAIN": 12000, "PRE_NMS_TOPK_TEST": 6000, "POST_NMS_TOPK_TRAIN": 2000,
+                "POST_NMS_TOPK_TEST": 1000, "NMS_THRESH": 0.7},
         "RESNETS": {"DEPTH": 50, "OUT_FEATURES": ["res4"], "NUM_GROUPS": 1, "NORM": "FrozenBN",
                     "WIDTH_PER_GROUP": 64, "STRIDE_IN_1X1": True, "RES5_DILATION": 1, "RES2_OUT_CHANNELS": 256,
                     "STEM_OUT_CHANNELS": 64, "DEFORM_ON_PER_STAGE": [False, False, False, False],

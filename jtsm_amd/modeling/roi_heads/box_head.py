@@ -89,3 +89,49 @@ class DiscriminativeAdaptionNeck(nn.Module):
     def output_shape(self):
         o = self._output_size
         return ShapeSpec(channels=o) if isinstance(o, int) else ShapeSpec(channels=o[0], height=o[1], width=o[2])
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class FastRCNNConvFCHead(nn.Module):
+    """[conv3x3 + ReLU] x NUM_CONV then [Linear + ReLU] x NUM_FC — detectron2/modeling/roi_heads/box_head.py:26-118
+    (the standard box head of BASELINE configs[0]; flattening keeps the reference's (c, h, w) column order)."""
+
+    def __init__(self, cfg, input_shape: ShapeSpec):
+        super().__init__()
+        b = cfg.MODEL.ROI_BOX_HEAD
+        if b.NORM:
+            raise NotImplementedError("FastRCNNConvFCHead: conv norm '%s' is not supported" % b.NORM)
+        self._output_size = (input_shape.channels, input_shape.height, input_shape.width)
+        self.conv_norm_relus, self.fcs = [], []
+        for k in range(b.NUM_CONV):
+            conv = Conv2d(self._output_size[0], b.CONV_DIM, kernel_size=3, padding=1, bias=True,
+                          activation=torch.nn.functional.relu)
+            nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+            nn.init.constant_(conv.bias, 0)
+            self.add_module("conv{}".format(k + 1), conv)
+            self.conv_norm_relus.append(conv)
+            self._output_size = (b.CONV_DIM, self._output_size[1], self._output_size[2])
+        for k in range(b.NUM_FC):
+            fc = Linear(int(np.prod(self._output_size)), b.FC_DIM)
+            nn.init.kaiming_uniform_(fc.weight, a=1)      # c2_xavier_fill
+            nn.init.constant_(fc.bias, 0)
+            self.add_module("fc{}".format(k + 1), fc)
+            self.fcs.append(fc)
+            self._output_size = b.FC_DIM
+        if not (self.conv_norm_relus or self.fcs):
+            raise ValueError("FastRCNNConvFCHead needs NUM_CONV + NUM_FC > 0")
+
+    def forward(self, x):
+        for layer in self.conv_norm_relus:
+            x = layer(x)
+        if self.fcs:
+            if x.dim() > 2:
+                x = x.reshape(x.shape[0], -1)             # logical (c, h, w) order, as torch.flatten gives
+            for fc in self.fcs:
+                x = fc(x, relu=True)
+        return x
+
+    @property
+    def output_shape(self):
+        o = self._output_size
+        return ShapeSpec(channels=o) if isinstance(o, int) else ShapeSpec(channels=o[0], height=o[1], width=o[2])

@@ -79,3 +79,12 @@ class MaskRCNNConvUpsampleWSLHead(nn.Module):
             x = layer(x)
         x = self.deconv(x, relu=True)
         return self.predictor(x), x
+
+
+@ROI_MASK_HEAD_REGISTRY.register()
+class MaskRCNNConvUpsampleHead(MaskRCNNConvUpsampleWSLHead):
+    """detectron2/modeling/roi_heads/mask_head.py:201-290 — the same layers (state_dict keys included) as the WSL
+    variant, which only adds the second return value of `layers`."""
+
+    def forward(self, x):
+        return self.layers(x)[0]

@@ -6,9 +6,11 @@ block s lies in box r, `n_things` thing classes, `n_stuff` stuff bands in the se
 
 `width` (default: `size`) makes the images size x width — BASELINE configs[4]'s Cityscapes shape is the same proposal
 recipe scaled by width / size in x.  `cluster` > 0 replaces that fraction of the proposals by jittered copies of
-`n_things` "object" rectangles per image (one per thing class), the way real proposal sets crowd around objects:
-a mined pseudo-GT box then has O(cluster * R / n_things) proposals above IoU 0.5, which is what gives the mask
-branch a realistic foreground count (uniform-random boxes almost never overlap that much)."""
+`objects` (default `n_things`) "object" rectangles per image, the way real proposal sets (MCG, selective search) crowd
+around regions: a mined pseudo-GT box that is one of those copies has O(cluster * R / objects) proposals above IoU 0.5,
+which is what gives the mask branch a realistic foreground count (uniform-random boxes almost never overlap that
+much).  With cluster = 1 every proposal belongs to a group, so the count no longer depends on WHICH proposal a
+randomly initialised detector happens to pick."""
 import math
 
 import torch
@@ -19,7 +21,7 @@ NUM_THINGS, NUM_STUFF = 80, 54
 
 
 def synthetic_inputs(seed, batch=2, size=1024, proposals=2000, sp_block=32, n_things=3, n_stuff=2, device="cpu",
-                     num_things=NUM_THINGS, num_stuff=NUM_STUFF, width=None, cluster=0.0):
+                     num_things=NUM_THINGS, num_stuff=NUM_STUFF, width=None, cluster=0.0, objects=None):
     g = torch.Generator().manual_seed(seed)
     width = size if width is None else width
     sx = width / float(size)
@@ -40,11 +42,16 @@ def synthetic_inputs(seed, batch=2, size=1024, proposals=2000, sp_block=32, n_th
         if cluster > 0:
             # (drawn after everything the plain recipe draws, so cluster = 0 reproduces it bit for bit)
             nc = int(round(cluster * proposals))
-            ox = torch.rand(n_things, generator=g) * width * 0.6
-            oy = torch.rand(n_things, generator=g) * size * 0.6
-            ow = (torch.rand(n_things, generator=g) * 0.25 + 0.12) * width
-            ohh = (torch.rand(n_things, generator=g) * 0.25 + 0.12) * size
-            which = torch.randint(0, n_things, (nc,), generator=g)
+            no = n_things if objects is None else int(objects)
+            ox = torch.rand(no, generator=g) * width * 0.6
+            oy = torch.rand(no, generator=g) * size * 0.6
+            if objects is None:
+                ow = (torch.rand(no, generator=g) * 0.25 + 0.12) * width
+                ohh = (torch.rand(no, generator=g) * 0.25 + 0.12) * size
+            else:   # many groups: log-uniform sides like the plain recipe, so the groups span the FPN levels
+                ow = torch.exp(torch.rand(no, generator=g) * (hi - lo) + lo) * sx
+                ohh = torch.exp(torch.rand(no, generator=g) * (hi - lo) + lo)
+            which = torch.randint(0, no, (nc,), generator=g)
             jit = (torch.rand(nc, 4, generator=g) - 0.5) * 0.24          # each edge moves by up to 12 % of the side
             obj = torch.stack([ox, oy, ox + ow, oy + ohh], 1)[which]
             side = torch.stack([ow, ohh, ow, ohh], 1)[which]
