@@ -114,6 +114,9 @@ class DevicePrefetcher:
     # ---- consumer thread: one async copy per batch on the side stream, device views, widening
     def _launch(self, batch, slot, plan, off):
         self.bytes_last = off
+        # the stream the training step runs on — looked up BEFORE entering the side stream's context (inside it,
+        # current_stream() is the side stream itself and record_stream() on it would be a no-op)
+        consumer = torch.cuda.current_stream(self.device)
         with torch.cuda.stream(self.stream):
             if slot.free is not None:
                 self.stream.wait_event(slot.free)                                 # do not overwrite tensors still in use
@@ -126,7 +129,8 @@ class DevicePrefetcher:
                 d = slot.device[o:o + nbytes].view(wire).view(shape)
                 if wire != dtype:
                     d = d.to(dtype)                                                # widen on the device
-                    d.record_stream(torch.cuda.current_stream(self.device))        # allocated here, used over there
+                    d.record_stream(consumer)   # allocated on the side stream, read on the compute stream: the caching
+                    # allocator must not hand this block to a later widening while a step still reads it
                 table[path] = d
             ready = torch.cuda.Event()
             ready.record(self.stream)

@@ -29,7 +29,7 @@ class SGD(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        rows, blocks, device, first, keep, touched = [], 0, None, None, [], []
+        rows, blocks, device, keep, touched = [], 0, None, [], []
         for group in self.param_groups:
             lr, wd, mu = _f32_bits(group["lr"]), _f32_bits(group["weight_decay"]), _f32_bits(group["momentum"])
             for p in group["params"]:
@@ -39,13 +39,10 @@ class SGD(torch.optim.Optimizer):
                 if not p.is_cuda or p.dtype != torch.float32:
                     raise RuntimeError("jtsm_amd SGD updates float32 parameters on the HIP device only")
                 st = self.state[p]
-                fresh = "momentum_buffer" not in st
-                if fresh:
-                    st["momentum_buffer"] = torch.empty_like(p, memory_format=torch.preserve_format)
-                if first is None:
-                    first = fresh
-                elif first != fresh:
-                    raise RuntimeError("jtsm_amd SGD: parameters must all be on their first step or none of them")
+                if "momentum_buffer" not in st:
+                    # a parameter's first gradient may come at any step (a layer unfrozen later, a head whose loss was
+                    # skipped): start from a zero buffer — mu * 0 + d is exactly torch.optim.SGD's first step (buf = d)
+                    st["momentum_buffer"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 buf = st["momentum_buffer"]
                 if g.stride() != p.stride() or buf.stride() != p.stride():
                     # the kernel walks p, grad and the momentum buffer in the same element order
@@ -58,21 +55,28 @@ class SGD(torch.optim.Optimizer):
                 blocks += (n + 1023) // 1024
                 device = p.device
         if rows:
-            # table upload without stalling the host: pinned staging buffers (two, alternating: the copy of step t
-            # is long done before step t+2 rewrites its buffer) and an asynchronous copy on the launch stream
+            # table upload without stalling the host: two alternating pinned staging buffers and an asynchronous copy on
+            # the launch stream; a buffer is rewritten only after the copy that last read it has finished (event)
             nwords = len(rows) * 8
-            st = self.__dict__.setdefault("_staging", {"host": [None, None], "dev": None, "turn": 0})
+            st = self.__dict__.setdefault("_staging", {"host": [None, None], "dev": None, "turn": 0,
+                                                       "copied": [None, None]})
             if st["dev"] is None or st["dev"].numel() < nwords or st["dev"].device != device:
                 st["host"] = [torch.empty(nwords, dtype=torch.int64).pin_memory() for _ in range(2)]
                 st["dev"] = torch.empty(nwords, dtype=torch.int64, device=device)
+                st["copied"] = [None, None]
             st["turn"] ^= 1
             host = st["host"][st["turn"]]
+            if st["copied"][st["turn"]] is not None:
+                st["copied"][st["turn"]].synchronize()
             host[:nwords].copy_(torch.tensor(rows, dtype=torch.int64).view(-1))
             table = st["dev"][:nwords]
             table.copy_(host[:nwords], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            st["copied"][st["turn"]] = ev
             L.note_bytes(20.0 * sum(r[3] for r in rows))   # param, grad, momentum read; param, momentum written
-            L.check(L.lib().jtsm_sgd_momentum_multi_f32(L.ptr(table), len(rows), C.c_long(blocks), int(bool(first)),
-                                                        L.stream()), "sgd_momentum_multi")
+            L.check(L.lib().jtsm_sgd_momentum_multi_f32(L.ptr(table), len(rows), C.c_long(blocks), 0, L.stream()),
+                    "sgd_momentum_multi")
             torch.autograd.graph.increment_version(touched)   # updated behind autograd's back: say so
         return loss
 

@@ -166,3 +166,27 @@ def test_prefetcher_delivers_identical_batches_and_model_trains(cuda):
     got = model(next(iter(D.DevicePrefetcher([batches[2]], "cuda"))))
     for k in ref:
         assert abs(float(ref[k].detach()) - float(got[k].detach())) <= 1e-6 * max(1.0, abs(float(ref[k].detach()))), k
+
+
+@pytest.mark.gpu
+def test_prefetcher_depth3_keeps_widened_tensors_intact_under_a_long_step(cuda):
+    """ADVICE r1: at depth >= 3 the widening of batch i+2 runs while step i may still be reading ITS widened tensors;
+    they were allocated on the side stream, so the allocator may only recycle them once the compute stream is done
+    (record_stream on the CONSUMER stream).  A long-running 'step' (a big matmul chain queued on the compute stream
+    before the labels are read) makes a premature reuse visible as corrupted labels."""
+    g = torch.Generator().manual_seed(0)
+    batches = []
+    for k in range(6):
+        sem = torch.randint(0, 54, (256, 256), generator=g)
+        oh = torch.randint(0, 2, (300, 1024), generator=g, dtype=torch.int32)
+        batches.append([{"image": torch.randint(0, 255, (3, 256, 256), generator=g, dtype=torch.uint8), "sem_seg": sem,
+                         "oh_labels": oh}])
+    pre = D.DevicePrefetcher(batches, "cuda", depth=3)
+    a = torch.randn(4096, 4096, device=cuda)
+    for host, dev in zip(batches, pre):
+        x = a
+        for _ in range(6):                       # ~ tens of ms of queued compute ahead of the reads below
+            x = x @ a * 1e-3
+        sem_d, oh_d = dev[0]["sem_seg"] + 0, dev[0]["oh_labels"] + 0      # read on the compute stream, after the matmuls
+        assert sem_d.dtype == torch.int64
+        assert torch.equal(sem_d.cpu(), host[0]["sem_seg"]) and torch.equal(oh_d.cpu(), host[0]["oh_labels"])

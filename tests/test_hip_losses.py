@@ -165,6 +165,31 @@ def test_fused_sgd_matches_torch_sgd(cuda):
     assert len(sd["state"]) == 4 and "momentum_buffer" in next(iter(sd["state"].values()))
 
 
+def test_fused_sgd_parameter_joining_late_matches_torch_sgd(cuda):
+    """A parameter whose first gradient arrives at a LATER step than the others (a head whose loss was skipped, a
+    layer unfrozen mid-training): torch.optim.SGD initialises momentum per parameter, and so does the fused update."""
+    from jtsm_amd.solver import SGD
+
+    g = torch.Generator().manual_seed(12)
+    ref = [torch.randn(40, 8, generator=g), torch.randn(17, generator=g)]
+    mine = [r.clone().to(cuda) for r in ref]
+    for t in ref + mine:
+        t.requires_grad_(True)
+    o_ref = torch.optim.SGD(ref, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    o_mine = SGD(mine, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    for step in range(4):
+        for i, (r, m) in enumerate(zip(ref, mine)):
+            if i == 1 and step < 2:          # the second parameter gets no gradient during the first two steps
+                r.grad = m.grad = None
+                continue
+            gr = torch.randn(r.shape, generator=g)
+            r.grad, m.grad = gr.clone(), gr.to(cuda)
+        o_ref.step()
+        o_mine.step()
+        for r, m in zip(ref, mine):
+            assert torch.allclose(m.detach().cpu(), r.detach(), rtol=1e-6, atol=1e-7), step
+
+
 @pytest.mark.parametrize("classes,pad", [(80, 0), (5, 3), (1, 0)])
 def test_mask_bce_matches_torch(cuda, classes, pad):
     """mask_bce_loss (one launch each way) vs F.binary_cross_entropy_with_logits on the gathered class channel,
