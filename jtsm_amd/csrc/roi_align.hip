@@ -237,97 +237,60 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
                                                        const int* __restrict__ roi_level, int level, int tiles_x,
                                                        int tiles_y, const int* __restrict__ census_max) {
 #pragma clang fp contract(off)
-  extern __shared__ __attribute__((aligned(16))) float acc[];   // [4 wavefronts][64 cells][64 channels]
+  // One workgroup per 8 x 8-cell tile; wavefront w owns channels 64 (w + 4 blockIdx.y) .. + 63 (lane = channel) and
+  // keeps the tile's 64 cells of those channels in REGISTERS.  Every wavefront walks the same list of rois that can
+  // reach the tile; per roi the bins that reach it are a small (ph, pw) rectangle found from the geometry (no scan
+  // over all PH x PW bins), and a bin's contribution g * wy[r] * wx[q] is applied as  v[q] = sum_pw g wx_pw[q]  then
+  // acc[r][q] += wy_ph[r] v[q]  (the column weights of the rectangle are staged once per roi in LDS).
+  constexpr int kMaxBins = 16;          // PW <= 16 (7 and 14 on the JTSM path); wider poolers use the scatter form
   __shared__ int roi_list[256];
-  __shared__ float roi_row[256][5];     // the listed rois' rows: the walk must not wait on global memory
-  __shared__ int pair_list[kPairCap];   // slot in roi_list * nbins + bin
+  __shared__ float roi_row[256][5];
   __shared__ int wave_count[4];
+  __shared__ float wxs[4][kMaxBins][kTile];
+  __shared__ int wpw[4][kMaxBins];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   int rel = blockIdx.x;
   const int tx = rel % tiles_x; rel /= tiles_x;
   const int ty = rel % tiles_y;
   const int b = rel / tiles_y;
   const int x0 = tx * kTile, y0 = ty * kTile, x1 = min(x0 + kTile, W) - 1, y1 = min(y0 + kTile, H) - 1;
-  const int c = blockIdx.y * 64 + lane;
+  const int c = (blockIdx.y * 4 + wv) * 64 + lane;
+  const bool live = c < C;              // wave-uniform (C % 64 == 0)
   const int nbins = PH * PW;
   float* __restrict__ out = gin + (size_t)b * H * W * C;
   if (*census_max > kCensusLimit) {   // piled-up rois somewhere: clear the map, the scatter form does the work
-    for (int cell = wv; cell < kTile * kTile; cell += 4) {
-      const int y = y0 + cell / kTile, x = x0 + cell % kTile;
-      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
-    }
+    if (live)
+      for (int cell = 0; cell < kTile * kTile; ++cell) {
+        const int y = y0 + cell / kTile, x = x0 + cell % kTile;
+        if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
+      }
     return;
   }
-  float* __restrict__ mine = acc + wv * (kTile * kTile * 64);
-  int np = 0;            // uniform
-  bool dirty = false;    // uniform: the accumulators are cleared when a first bin arrives (most tiles see none)
+  float acc[kTile][kTile];
+#pragma unroll
+  for (int r = 0; r < kTile; ++r)
+#pragma unroll
+    for (int q = 0; q < kTile; ++q) acc[r][q] = 0.f;
 
   // cells a sample coordinate range [lo, hi] can touch: floor(lo) .. floor(hi) + 1, after the clamp to the map
   auto reach = [](float lo, float hi, int n, int& a, int& z) {
     a = max((int)floorf(lo), 0);
     z = min((int)floorf(hi) + 1, n - 1);
   };
-
-  constexpr int kDepth = 8;
-  auto drain = [&]() {
-    if (np == 0) return;
-    if (!dirty) {
-      for (int i = t; i < kTile * kTile * 64; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      dirty = true;
+  // bilinear row (or column) weights of bin `p` of an axis on the tile's eight lines starting at `t0`
+  auto axis_weights = [](float origin, float bin, int grid, int p, int n, int t0, float (&w)[kTile]) {
+#pragma unroll
+    for (int r = 0; r < kTile; ++r) w[r] = 0.f;
+    for (int i = 0; i < grid; ++i) {
+      float y = origin + (float)p * bin + (float)((float)i + .5f) * bin / (float)grid;
+      if (y < -1.0f || y > (float)n) continue;
+      if (y <= 0.f) y = 0.f;
+      int yl = (int)y, yh;
+      if (yl >= n - 1) { yh = yl = n - 1; y = (float)yl; } else { yh = yl + 1; }
+      const float ly = y - (float)yl, hy = 1.f - ly;
+#pragma unroll
+      for (int r = 0; r < kTile; ++r) w[r] += (yl == t0 + r ? hy : 0.f) + (yh == t0 + r ? ly : 0.f);
     }
-    __syncthreads();
-    for (int j0 = wv; j0 < np; j0 += 4 * kDepth) {   // wavefront wv: listed bins wv, wv + 4, ...
-      float gos[kDepth];                             // kDepth gradients in flight before any is used
-#pragma unroll
-      for (int u = 0; u < kDepth; ++u) {
-        gos[u] = 0.f;
-        if (j0 + 4 * u < np) {
-          const int e = pair_list[j0 + 4 * u], i = e / nbins;
-          gos[u] = grad[((size_t)roi_list[i] * nbins + (e - i * nbins)) * C + c];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kDepth; ++u) {
-        if (j0 + 4 * u >= np) break;
-        const int e = pair_list[j0 + 4 * u];
-        const int i = e / nbins, bin = e - i * nbins;
-        const int ph = bin / PW, pw = bin - ph * PW;
-        const RoiGeom<float> g = geom_box<float>(roi_row[i], scale, PH, PW, sr, aligned != 0);
-        float wy[kTile], wx[kTile];
-#pragma unroll
-        for (int r = 0; r < kTile; ++r) wy[r] = wx[r] = 0.f;
-        for (int iy = 0; iy < g.gh; ++iy) {
-          float y = g.y0 + (float)ph * g.bh + (float)((float)iy + .5f) * g.bh / (float)g.gh;
-          if (y < -1.0f || y > (float)H) continue;
-          if (y <= 0.f) y = 0.f;
-          int yl = (int)y, yh;
-          if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else { yh = yl + 1; }
-          const float ly = y - (float)yl, hy = 1.f - ly;
-#pragma unroll
-          for (int r = 0; r < kTile; ++r) wy[r] += (yl == y0 + r ? hy : 0.f) + (yh == y0 + r ? ly : 0.f);
-        }
-        for (int ix = 0; ix < g.gw; ++ix) {
-          float x = g.x0 + (float)pw * g.bw + (float)((float)ix + .5f) * g.bw / (float)g.gw;
-          if (x < -1.0f || x > (float)W) continue;
-          if (x <= 0.f) x = 0.f;
-          int xl = (int)x, xh;
-          if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else { xh = xl + 1; }
-          const float lx = x - (float)xl, hx = 1.f - lx;
-#pragma unroll
-          for (int r = 0; r < kTile; ++r) wx[r] += (xl == x0 + r ? hx : 0.f) + (xh == x0 + r ? lx : 0.f);
-        }
-        const float gs = gos[u] / (float)(g.gh * g.gw);
-#pragma unroll
-        for (int r = 0; r < kTile; ++r) {
-          if (wy[r] == 0.f) continue;
-          const float gr = gs * wy[r];
-#pragma unroll
-          for (int q = 0; q < kTile; ++q)
-            if (wx[q] != 0.f) mine[(r * kTile + q) * 64 + lane] += gr * wx[q];
-        }
-      }
-    }
-    np = 0;
   };
 
   for (int base = 0; base < M; base += 256) {
@@ -350,37 +313,73 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
       for (int q = 0; q < 5; ++q) roi_row[slot][q] = rois[(size_t)n * 5 + q];
     }
     __syncthreads();
-    const int ncombo = nroi * nbins;
-    for (int k0 = 0; k0 < ncombo; k0 += 256) {
-      if (np > kPairCap - 256) drain();
-      const int k = k0 + t;
-      bool bh = false;
-      if (k < ncombo) {
-        const int i = k / nbins, bin = k - i * nbins;
-        const int ph = bin / PW, pw = bin - ph * PW;
+    if (live) {
+      for (int i = 0; i < nroi; ++i) {     // every wavefront walks the whole list (its own channels)
         const RoiGeom<float> g = geom_box<float>(roi_row[i], scale, PH, PW, sr, aligned != 0);
-        int ya, yz, xa, xz;
-        reach(g.y0 + (float)ph * g.bh, g.y0 + (float)(ph + 1) * g.bh, H, ya, yz);
-        reach(g.x0 + (float)pw * g.bw, g.x0 + (float)(pw + 1) * g.bw, W, xa, xz);
-        bh = ya <= y1 && yz >= y0 && xa <= x1 && xz >= x0;
+        const float* __restrict__ gro = grad + (size_t)roi_list[i] * nbins * C + c;
+        // the (pw) bins whose taps reach the tile's columns, and their column weights -> LDS (this wavefront's rows)
+        int npw = 0;
+        {
+          const int lo = max(0, (int)floorf(((float)x0 - 1.f - g.x0) / fmaxf(g.bw, 1e-6f)) - 1);
+          const int hi = min(PW - 1, (int)floorf(((float)x1 + 1.f - g.x0) / fmaxf(g.bw, 1e-6f)) + 1);
+          for (int pw = lo; pw <= hi && npw < kMaxBins; ++pw) {
+            int xa, xz;
+            reach(g.x0 + (float)pw * g.bw, g.x0 + (float)(pw + 1) * g.bw, W, xa, xz);
+            if (xa > x1 || xz < x0) continue;
+            float wx[kTile];
+            axis_weights(g.x0, g.bw, g.gw, pw, W, x0, wx);
+            if (lane < kTile) {
+              float v = 0.f;
+#pragma unroll
+              for (int q = 0; q < kTile; ++q) v = lane == q ? wx[q] : v;
+              wxs[wv][npw][lane] = v;
+            }
+            if (lane == 0) wpw[wv][npw] = pw;
+            ++npw;
+          }
+        }
+        if (npw == 0) continue;
+        const int lo = max(0, (int)floorf(((float)y0 - 1.f - g.y0) / fmaxf(g.bh, 1e-6f)) - 1);
+        const int hi = min(PH - 1, (int)floorf(((float)y1 + 1.f - g.y0) / fmaxf(g.bh, 1e-6f)) + 1);
+        const float inv = 1.f / (float)(g.gh * g.gw);
+        for (int ph = lo; ph <= hi; ++ph) {
+          int ya, yz;
+          reach(g.y0 + (float)ph * g.bh, g.y0 + (float)(ph + 1) * g.bh, H, ya, yz);
+          if (ya > y1 || yz < y0) continue;
+          float gk[kMaxBins];
+#pragma unroll
+          for (int k = 0; k < kMaxBins; ++k) gk[k] = k < npw ? gro[(size_t)(ph * PW + wpw[wv][k]) * C] : 0.f;
+          float wy[kTile];
+          axis_weights(g.y0, g.bh, g.gh, ph, H, y0, wy);
+          float v[kTile];
+#pragma unroll
+          for (int q = 0; q < kTile; ++q) v[q] = 0.f;
+#pragma unroll
+          for (int k = 0; k < kMaxBins; ++k) {
+            if (k >= npw) break;
+            const float gs = gk[k] * inv;
+#pragma unroll
+            for (int q = 0; q < kTile; ++q) v[q] += gs * wxs[wv][k][q];
+          }
+#pragma unroll
+          for (int r = 0; r < kTile; ++r) {
+            if (wy[r] == 0.f) continue;
+#pragma unroll
+            for (int q = 0; q < kTile; ++q) acc[r][q] += wy[r] * v[q];
+          }
+        }
       }
-      int cnt;
-      const int ps = compact256(bh, wave_count, cnt);
-      if (bh) pair_list[np + ps] = k;   // slot * nbins + bin
-      np += cnt;
     }
-    drain();                            // before the next chunk overwrites roi_list / roi_row
-    __syncthreads();
+    __syncthreads();                    // before the next chunk overwrites roi_list / roi_row
   }
-  __syncthreads();
-  // sum the four wavefronts' accumulators in a fixed order; wavefront wv writes cells wv, wv + 4, ...
-  constexpr int SLAB = kTile * kTile * 64;
-  for (int cell = wv; cell < kTile * kTile; cell += 4) {
-    const int y = y0 + cell / kTile, x = x0 + cell % kTile;
-    if (y > y1 || x > x1) continue;
-    const int o = cell * 64 + lane;
-    out[((size_t)y * W + x) * C + c] = dirty ? ((acc[o] + acc[SLAB + o]) + acc[2 * SLAB + o]) + acc[3 * SLAB + o] : 0.f;
-  }
+  if (!live) return;
+#pragma unroll
+  for (int r = 0; r < kTile; ++r)
+#pragma unroll
+    for (int q = 0; q < kTile; ++q) {
+      const int y = y0 + r, x = x0 + q;
+      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = acc[r][q];
+    }
 }
 
 // ---------------------------------------------------------------- NCHW (reference layout)
@@ -516,7 +515,7 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
   JTSM_REQUIRE(gin, "roi_align backward: null grad_input");
   // (a handful of rois — the mask branch's foreground set — is cheaper as memset + scatter than as one workgroup per
   // tile of the whole map: the gather starts at 8192 bins)
-  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && grad && rois &&
+  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && grad && rois && PW <= 16 &&
       (long)M * PH * PW >= 8192 && (long)M * PH * PW < (1L << 30)) {
     // gather form with the census guard: both forms are launched, the device-side census lets one of them return
     const int tiles_x = ceil_div(W, kTile), tiles_y = ceil_div(H, kTile), ntile = B * tiles_x * tiles_y;
@@ -528,7 +527,7 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
     hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, r32, M, (float)scale, PH, PW, sr,
                        aligned, H, W, roi_level, level, tiles_x, tiles_y, census);
     hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
-    hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 4 * kTile * kTile * 64 * sizeof(float), st, g32,
+    hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, ceil_div(C, 256)), dim3(256), 0, st, g32,
                        r32, reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
                        tiles_x, tiles_y, census + ntile);
     constexpr int V = WideVec<float>::value;

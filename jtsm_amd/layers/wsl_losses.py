@@ -66,6 +66,55 @@ def mil_loss(cls_logits, det_logits, bag_offsets, labels, mean_loss=True, max_ba
     return _MILLoss.apply(cls_logits, det_logits, bag_offsets, labels, mean_loss, int(max_bag_rows))
 
 
+class _MILScores(Function):
+    """scores = softmax_c(C) * per-bag softmax_r(D) with gradient to both logits (the reference-shaped
+    TSMOutputLayers.forward).  Forward: the HIP kernel; backward of an arbitrary upstream G:
+        dC = p (G q - sum_c G q p),   dD = q (G p - sum_{r in bag} G p q)      (p, q the two softmaxes)."""
+
+    @staticmethod
+    def forward(ctx, cls_logits, det_logits, bag_offsets, max_bag_rows):
+        L.require_gpu(cls_logits, det_logits, bag_offsets)
+        c, ldc = _rowmajor(cls_logits)
+        d, ldd = _rowmajor(det_logits)
+        if ldc != ldd:
+            c, d = c.contiguous(), d.contiguous()
+            ldc = c.shape[1]
+        R, nc = c.shape
+        nb = bag_offsets.numel() - 1
+        scores = torch.empty((R, nc), dtype=torch.float32, device=c.device)
+        probs = torch.empty((nb, nc), dtype=torch.float32, device=c.device)
+        loss = torch.empty((), dtype=torch.float32, device=c.device)
+        labels = torch.zeros((nb, nc), dtype=torch.float32, device=c.device)
+        ws = torch.empty(L.lib().jtsm_mil_workspace_bytes(nb, max_bag_rows, nc), dtype=torch.uint8, device=c.device)
+        L.check(L.lib().jtsm_mil_forward_f32(L.ptr(c), L.ptr(d), ldc, nc, L.ptr(bag_offsets), nb, max_bag_rows,
+                                             L.ptr(labels), 1, L.ptr(scores), L.ptr(probs), L.ptr(loss), L.ptr(ws),
+                                             L.stream()), "mil_forward")
+        ctx.save_for_backward(c, scores, bag_offsets)
+        return scores
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        c, scores, bag_offsets = ctx.saved_tensors
+        p = torch.softmax(c, dim=1)
+        q = scores / p.clamp_min(1e-38)
+        gs = g * scores                                              # G p q
+        dc = g * scores - p * gs.sum(dim=1, keepdim=True)            # p (G q - sum_c G q p)
+        bag_of = torch.bucketize(torch.arange(c.shape[0], device=c.device), bag_offsets[1:].to(torch.int64), right=True)
+        per_bag = torch.zeros((bag_offsets.numel() - 1, c.shape[1]), dtype=gs.dtype, device=gs.device).index_add_(0, bag_of, gs)
+        dd = gs - q * per_bag[bag_of]                                # q (G p - sum_r G p q)
+        return dc, dd, None, None
+
+
+def mil_scores(cls_logits, det_logits, counts):
+    """MIL scores (R, nc) of ragged bags (`counts` rows per image), differentiable."""
+    offs = [0]
+    for n in counts:
+        offs.append(offs[-1] + int(n))
+    bag_offsets = torch.tensor(offs, dtype=torch.int32).to(cls_logits.device, non_blocking=True)
+    return _MILScores.apply(cls_logits, det_logits, bag_offsets, max(max(counts), 1))
+
+
 class _OICRLoss(Function):
     @staticmethod
     def forward(ctx, cls_logits, box_deltas, labels, weights, proposals, gt_boxes):

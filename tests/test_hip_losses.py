@@ -44,6 +44,54 @@ def test_mil_forward_backward(cuda, counts, mean_loss):
     assert wd.grad[:, 2 * nc:].abs().max().item() == 0
 
 
+@pytest.mark.parametrize("mean_loss", [True, False])
+def test_tsm_output_layers_reference_shaped_surface(cuda, mean_loss):
+    """TSMOutputLayers.forward(x, proposals) -> (scores, zero deltas), .losses(predictions, proposals, oh),
+    .predict_probs_img / predict_probs / predict_boxes (fast_rcnn_tsm.py:548-598,672-694,790-854): values and the
+    gradients that reach the cls / det Linears, against the oracle's literal per-image softmax chain; and the same
+    loss as the fused score_and_loss path JTSMROIHeads uses."""
+    from jtsm_amd.modeling.roi_heads.fast_rcnn_tsm import TSMOutputLayers
+    from jtsm_amd.structures import Boxes, Instances
+
+    g = torch.Generator().manual_seed(17)
+    counts, feat = [37, 5, 90], 64
+    R, B = sum(counts), len(counts)
+    head = TSMOutputLayers(feat, num_classes=OM.NUM_THINGS, num_classes_stuff=OM.NUM_STUFF, mean_loss=mean_loss,
+                           box2box_transform=__import__("jtsm_amd.modeling.box_regression", fromlist=["x"]).Box2BoxTransform(
+                               weights=(10.0, 10.0, 5.0, 5.0))).to(cuda)
+    x = torch.randn(R, feat, generator=g)
+    y = (torch.rand(B, OM.NUM_MIL, generator=g) < 0.05).float()
+    boxes = torch.rand(R, 4, generator=g) * 100
+    boxes[:, 2:] += boxes[:, :2] + 4
+    props = [Instances((256, 256), proposal_boxes=Boxes(b.to(cuda))) for b in boxes.split(counts)]
+    # oracle chain on copies of the same weights
+    wc, bc = head.cls.weight.detach().cpu().clone().requires_grad_(), head.cls.bias.detach().cpu().clone().requires_grad_()
+    wd, bd = head.det.weight.detach().cpu().clone().requires_grad_(), head.det.bias.detach().cpu().clone().requires_grad_()
+    s0 = OM.mil_scores(F.linear(x, wc, bc), F.linear(x, wd, bd), counts)
+    p0 = OM.mil_image_probs(s0, counts)
+    l0 = F.binary_cross_entropy(p0, y, reduction="mean" if mean_loss else "sum") / (1 if mean_loss else B)
+    l0.backward()
+    pred = head(x.to(cuda), props)
+    assert pred[1].shape == (R, 4 * OM.NUM_MIL) and float(pred[1].abs().sum()) == 0.0
+    rel_close(pred[0], s0, what="scores")
+    rel_close(head.predict_probs_img(pred, props), p0, what="image probabilities")
+    loss = head.losses(pred, props, y.to(cuda))["loss_cls"]
+    rel_close(loss, l0, what="loss")
+    loss.backward()
+    for mine, ref, what in ((head.cls.weight, wc, "d cls.weight"), (head.cls.bias, bc, "d cls.bias"),
+                            (head.det.weight, wd, "d det.weight")):
+        rel_close(mine.grad, ref.grad, what=what)
+    probs = head.predict_probs(pred, props)
+    assert [tuple(t.shape) for t in probs] == [(n, OM.NUM_MIL + 1) for n in counts] and float(probs[0][:, -1].sum()) == 0
+    pb = head.predict_boxes(pred, props)
+    assert torch.allclose(pb[1][:, :4].cpu(), boxes.split(counts)[1], atol=1e-4)      # zero deltas: the boxes themselves
+    # the fused path gives the same loss
+    c, d = head.logits(x.to(cuda))
+    off = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32, device=cuda)
+    fused, _, _ = head.score_and_loss(c, d, off, y.to(cuda), max(counts))
+    rel_close(fused["loss_cls"], loss, what="fused == reference-shaped")
+
+
 @pytest.mark.parametrize("R", [4000, 77, 1])
 @pytest.mark.parametrize("with_box", [True, False])
 def test_oicr_forward_backward(cuda, R, with_box):
