@@ -139,6 +139,40 @@ int jtsm_moi_pool_forward_f32(const float* input, const float* rois, const int32
 int jtsm_moi_pool_backward_f32(const float* grad, const float* rois, const int32_t* argmax,
                                float* grad_input, int B, int C, int H, int W, int M,
                                int pooled_h, int pooled_w, int layout, void* stream);
+/* ---------------------------------------------------------------------------
+ * fp16 tensors at the pooling boundary.  The reference dispatches MOIPool on half too
+ * (AT_DISPATCH_FLOATING_TYPES_AND_HALF, projects/WSL/wsl/layers/csrc/MOIPool/MOIPool_cuda.cu:400,415,484) and its
+ * Python layers hand half tensors to the align operators (detectron2/layers/roi_align_rotated.py:79-85: up-cast,
+ * compute, cast back).  input / rois / output / grad are IEEE binary16 bit patterns; every call needs a caller
+ * workspace (16-byte aligned) in which the values are widened to fp32, pooled by the fp32 kernels above and rounded
+ * to fp16 once.  MOIPool is exact (a maximum of fp16 values; roi corners = round(Half(x) * Half(scale)), the product
+ * rounded to half as c10::Half arithmetic does); the align operators accumulate in fp32 and round once.
+ *   jtsm_pool_f16_workspace_bytes(in, rois, out, extra): elements of the tensor read, of the rois, of the tensor
+ *   written (+ extra bytes) — what the align calls need (extra = 0) and the MOIPool backward needs. */
+size_t jtsm_pool_f16_workspace_bytes(long in_elems, long roi_elems, long out_elems, size_t extra);
+size_t jtsm_moi_pool_f16_workspace_bytes(int B, int C, int H, int W, int M, int L, int pooled_h, int pooled_w);
+int jtsm_roi_align_forward_f16(const uint16_t* input, const uint16_t* rois, uint16_t* output, int B, int C, int H, int W,
+                               int M, float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                               int layout, void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_roi_align_backward_f16(const uint16_t* grad, const uint16_t* rois, uint16_t* grad_input, int B, int C, int H,
+                                int W, int M, float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                int aligned, int layout, void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_roi_align_rotated_forward_f16(const uint16_t* input, const uint16_t* rois, uint16_t* output, int B, int C,
+                                       int H, int W, int M, float spatial_scale, int pooled_h, int pooled_w,
+                                       int sampling_ratio, int layout, void* workspace, size_t workspace_bytes,
+                                       void* stream);
+int jtsm_roi_align_rotated_backward_f16(const uint16_t* grad, const uint16_t* rois, uint16_t* grad_input, int B, int C,
+                                        int H, int W, int M, float spatial_scale, int pooled_h, int pooled_w,
+                                        int sampling_ratio, int layout, void* workspace, size_t workspace_bytes,
+                                        void* stream);
+int jtsm_moi_pool_forward_f16(const uint16_t* input, const uint16_t* rois, const int32_t* oh_labels,
+                              const int32_t* superpixels, uint16_t* output, int32_t* argmax, void* workspace,
+                              size_t workspace_bytes, int B, int C, int H, int W, int M, int L, int Hs, int Ws,
+                              float spatial_scale, int pooled_h, int pooled_w, int layout, void* stream);
+int jtsm_moi_pool_backward_f16(const uint16_t* grad, const uint16_t* rois, const int32_t* argmax, uint16_t* grad_input,
+                               void* workspace, size_t workspace_bytes, int B, int C, int H, int W, int M, int pooled_h,
+                               int pooled_w, int layout, void* stream);
+
 /* All FPN levels in ONE launch — what detectron2/modeling/poolers.py:193-250 does level by level around
  * wsl/layers/moi_pool.py:10-33.  inputs[l] / grad_inputs[l]: (B,H[l],W[l],C) NHWC maps (host arrays of device
  * pointers, nlevels <= 8); roi_level[n] in [0,nlevels) picks roi n's map; output / argmax as above (NHWC).

@@ -119,13 +119,24 @@ __global__ __launch_bounds__(256) void channel_sum4_kernel(const float4* __restr
                                                      (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
   }
 }
+// out[c] = sum_s part[s][c], slabs in a fixed order: a workgroup folds 16 channels, 16 threads per channel each
+// taking every 16th slab, then the 16 partial sums are added in order.
 __global__ __launch_bounds__(256) void channel_sum_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                int C, int slabs) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float a = 0.f;
-  for (int s = 0; s < slabs; ++s) a += part[(size_t)s * C + c];
-  out[c] = a;
+  if (c < C)
+    for (int s = j; s < slabs; s += 16) a += part[(size_t)s * C + c];
+  red[j][cl] = a;
+  __syncthreads();
+  if (j == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    out[c] = t;
+  }
 }
 
 // ---- NHWC spatial helpers (C % 4 == 0: one float4 = 4 channels of one pixel) ---------------------
@@ -437,7 +448,7 @@ int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* str
   JTSM_REQUIRE(g, "channel_sum: null pointer");
   if (C % 4 == 0 && C >= 128 && ((uintptr_t)g & 15) == 0 && rows >= 256) {   // (narrow / short: the 4-byte kernel)
     const int cg = ceil_div(C / 4, 64);
-    long slabs = 1024 / cg;
+    long slabs = 1024 / cg;            // ~4 workgroups per CU in all
     if (slabs < 1) slabs = 1;
     if (slabs > (rows + 63) / 64) slabs = (rows + 63) / 64;
     const long rpb = (rows + slabs - 1) / slabs;
@@ -446,7 +457,7 @@ int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* str
     JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)nslab * C * sizeof(float), st));
     hipLaunchKernelGGL(channel_sum4_kernel, dim3(cg, (unsigned)nslab), dim3(256), 0, st,
                        reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(part), rows, C / 4, rpb);
-    hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, part, out, C, nslab);
+    hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
     JTSM_CHECK_LAUNCH("channel_sum");
     JTSM_CHECK_HIP(hipFreeAsync(part, st));
     return JTSM_OK;

@@ -19,6 +19,7 @@
 // Backward: same decomposition, scatter with float atomics (global_atomic_add_f32 /
 // _f64); in NHWC each wave instruction adds 256 contiguous bytes, the shape the memory-side
 // atomic units run at full rate on (MI355X_MICROARCH.md "Global float atomics").
+#include <cstdlib>
 #include <type_traits>
 
 #include "common.h"
@@ -195,7 +196,11 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
 // form above on spread-out rois; a tile under a pile of rois is walked by one workgroup, so a census of the boxes
 // (estimated bins per tile) sends such calls to the scatter form instead (as csrc/moi_pool.hip does).
 constexpr int kTile = 8, kPairCap = 1024;
-constexpr int kCensusLimit = 2000;   // bins on one tile: ~0.1 us each for the gather's four wavefronts
+// (estimated) bins on one tile above which the scatter form takes the call; overridable for sweeps
+static int census_limit() {
+  static const int v = [] { const char* e = getenv("JTSM_ALIGN_CENSUS_LIMIT"); return e ? atoi(e) : 20000; }();
+  return v;
+}
 
 __global__ __launch_bounds__(256) void align_census_kernel(const float* __restrict__ rois, int M, float scale, int PH,
                                                            int PW, int sr, int aligned, int H, int W,
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
                                                        float* __restrict__ gin, int C, int H, int W, int M, float scale,
                                                        int PH, int PW, int sr, int aligned,
                                                        const int* __restrict__ roi_level, int level, int tiles_x,
-                                                       int tiles_y, const int* __restrict__ census_max) {
+                                                       int tiles_y, const int* __restrict__ census_max, int census_lim) {
 #pragma clang fp contract(off)
   // One workgroup per 8 x 8-cell tile; wavefront w owns channels 64 (w + 4 blockIdx.y) .. + 63 (lane = channel) and
   // keeps the tile's 64 cells of those channels in REGISTERS.  Every wavefront walks the same list of rois that can
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
   const bool live = c < C;              // wave-uniform (C % 64 == 0)
   const int nbins = PH * PW;
   float* __restrict__ out = gin + (size_t)b * H * W * C;
-  if (*census_max > kCensusLimit) {   // piled-up rois somewhere: clear the map, the scatter form does the work
+  if (*census_max > census_lim) {   // piled-up rois somewhere: clear the map, the scatter form does the work
     if (live)
       for (int cell = 0; cell < kTile * kTile; ++cell) {
         const int y = y0 + cell / kTile, x = x0 + cell % kTile;
@@ -529,17 +534,17 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
     hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
     hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, ceil_div(C, 256)), dim3(256), 0, st, g32,
                        r32, reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
-                       tiles_x, tiles_y, census + ntile);
+                       tiles_x, tiles_y, census + ntile, census_limit());
     constexpr int V = WideVec<float>::value;
     const int blocks = ceil_div((long)M * PH * PW, 4);
     if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
       hipLaunchKernelGGL((align_bwd_nhwc<float, V, false>), dim3(blocks), dim3(256), 0, st, g32, r32,
                          reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
-                         census + ntile, kCensusLimit);
+                         census + ntile, census_limit());
     else
       hipLaunchKernelGGL((align_bwd_nhwc<float, 1, false>), dim3(blocks), dim3(256), 0, st, g32, r32,
                          reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
-                         census + ntile, kCensusLimit);
+                         census + ntile, census_limit());
     JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
     JTSM_CHECK_HIP(hipFreeAsync(census, st));
     return JTSM_OK;

@@ -12,8 +12,8 @@ from .roi_align import _as_layout, _empty_like_layout
 
 def moi_pool_forward(input, rois, spatial_scale, pooled_h, pooled_w, oh_labels, superpixels):
     L.require_gpu(input, rois, oh_labels, superpixels)
-    if input.dtype != torch.float32:
-        raise RuntimeError('"MOIPool_forward" is implemented for float32 only, got %s' % input.dtype)
+    if input.dtype not in (torch.float32, torch.float16):
+        raise RuntimeError('"MOIPool_forward" is implemented for float32 and float16, got %s' % input.dtype)
     if input.dtype != rois.dtype:
         raise RuntimeError("expected input and rois to have the same dtype")
     x, layout = _as_layout(input)
@@ -27,6 +27,17 @@ def moi_pool_forward(input, rois, spatial_scale, pooled_h, pooled_w, oh_labels, 
     arg = torch.empty((M, Cc, pooled_h, pooled_w), dtype=torch.int32, device=x.device,
                       memory_format=fmt)
     if out.numel() == 0:
+        return out, arg
+    if input.dtype == torch.float16:   # fp16 at the boundary (MOIPool_cuda.cu:400 dispatches on half too)
+        import ctypes as C
+        lib = L.lib()
+        lib.jtsm_moi_pool_f16_workspace_bytes.restype = C.c_size_t
+        nb = lib.jtsm_moi_pool_f16_workspace_bytes(B, Cc, H, W, M, Lw, pooled_h, pooled_w)
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        L.check(lib.jtsm_moi_pool_forward_f16(
+            L.ptr(x), L.ptr(rois), L.ptr(oh), L.ptr(sp), L.ptr(out), L.ptr(arg), L.ptr(ws), C.c_size_t(nb), B, Cc, H, W,
+            M, Lw, sp.shape[1], sp.shape[2], L.f32(spatial_scale), pooled_h, pooled_w, layout, L.stream()),
+            "moi_pool_forward_f16")
         return out, arg
     nbytes = L.lib().jtsm_moi_pool_workspace_bytes(B, H, W, M, Lw)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
@@ -46,6 +57,17 @@ def moi_pool_backward(grad, rois, argmax, spatial_scale, pooled_h, pooled_w, B, 
     a = argmax.contiguous(memory_format=fmt)
     gin = _empty_like_layout((B, Cc, H, W), g, layout)
     if gin.numel() == 0:
+        return gin
+    if g.dtype == torch.float16:
+        import ctypes as C
+        lib = L.lib()
+        lib.jtsm_pool_f16_workspace_bytes.restype = C.c_size_t
+        nb = lib.jtsm_pool_f16_workspace_bytes(C.c_long(g.numel()), C.c_long(rois.numel()), C.c_long(gin.numel()),
+                                               C.c_size_t(0))
+        ws = torch.empty(nb, dtype=torch.uint8, device=g.device)
+        L.check(lib.jtsm_moi_pool_backward_f16(
+            L.ptr(g), L.ptr(rois.contiguous()), L.ptr(a), L.ptr(gin), L.ptr(ws), C.c_size_t(nb), B, Cc, H, W,
+            rois.shape[0], pooled_h, pooled_w, layout, L.stream()), "moi_pool_backward_f16")
         return gin
     L.check(L.lib().jtsm_moi_pool_backward_f32(
         L.ptr(g), L.ptr(rois.contiguous()), L.ptr(a), L.ptr(gin), B, Cc, H, W, rois.shape[0],

@@ -13,14 +13,15 @@ from torch.nn.modules.utils import _pair
 
 from .. import _lib as L
 
-_SFX = {torch.float32: ("_f32", L.f32), torch.float64: ("_f64", L.f64)}
+_SFX = {torch.float32: ("_f32", L.f32), torch.float64: ("_f64", L.f64), torch.float16: ("_f16", L.f32)}
 
 
 def _dtype_entry(t, opname):
     try:
         return _SFX[t.dtype]
     except KeyError:
-        # reference CUDA dispatch is AT_DISPATCH_FLOATING_TYPES only (ROIAlign_cuda.cu:349)
+        # float32 / float64 as the reference's CUDA dispatch (ROIAlign_cuda.cu:349), plus float16 at the boundary
+        # (include/jtsm_hip.h "fp16 tensors at the pooling boundary")
         raise RuntimeError('"%s" not implemented for \'%s\'' % (opname, t.dtype)) from None
 
 
@@ -54,6 +55,14 @@ def pooled_forward(kind, input, rois, out_hw, spatial_scale, sampling_ratio, ali
             out_hw[1], int(sampling_ratio)]
     if kind == "roi_align":
         args.append(int(bool(aligned)))
+    if sfx == "_f16":
+        import ctypes as C
+        L.lib().jtsm_pool_f16_workspace_bytes.restype = C.c_size_t
+        nb = L.lib().jtsm_pool_f16_workspace_bytes(C.c_long(x.numel()), C.c_long(rois.numel()), C.c_long(out.numel()),
+                                                   C.c_size_t(0))
+        ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+        L.check(fn(*args, layout, L.ptr(ws), C.c_size_t(nb), L.stream()), kind + "_forward")
+        return out
     L.check(fn(*args, layout, L.stream()), kind + "_forward")
     return out
 
@@ -72,6 +81,14 @@ def pooled_backward(kind, grad, rois, out_hw, spatial_scale, sampling_ratio, ali
             out_hw[0], out_hw[1], int(sampling_ratio)]
     if kind == "roi_align":
         args.append(int(bool(aligned)))
+    if sfx == "_f16":
+        import ctypes as C
+        L.lib().jtsm_pool_f16_workspace_bytes.restype = C.c_size_t
+        nb = L.lib().jtsm_pool_f16_workspace_bytes(C.c_long(g.numel()), C.c_long(rois.numel()), C.c_long(gin.numel()),
+                                                   C.c_size_t(0))
+        ws = torch.empty(nb, dtype=torch.uint8, device=g.device)
+        L.check(fn(*args, layout, L.ptr(ws), C.c_size_t(nb), L.stream()), kind + "_backward")
+        return gin
     L.check(fn(*args, layout, L.stream()), kind + "_backward")
     return gin
 

@@ -421,3 +421,35 @@ def test_roi_align_backward_gather_reproducible_and_fallback(cuda):
     gx0 = P.roi_align_backward(g, r2, 0.125, 7, 7, B, Cc, H, W, 0, True)
     assert np.allclose(gx, gx0, rtol=1e-4, atol=1e-3 * max(1.0, float(np.abs(gx0).max()) / 10)), np.abs(gx - gx0).max()
     assert float(np.abs(gx[1]).max()) == 0.0            # nothing lands in the other image
+
+
+def test_fp16_boundary_moi_pool_exact_and_roi_align_rounded_once(cuda):
+    """fp16 tensors at the pooling boundary (MOIPool_cuda.cu:400 dispatches on half; roi_align_rotated.py:79-85
+    up-casts): MOIPool on fp16 features returns exactly the fp32 result on the same (fp16-representable) values, with
+    the roi corners computed in half arithmetic; ROIAlign returns the fp32 result rounded once to fp16; backward too."""
+    from jtsm_amd.layers.moi_pool import moi_pool
+    from jtsm_amd.layers.roi_align import roi_align
+
+    g = torch.Generator().manual_seed(5)
+    B, C, H, W, L = 2, 64, 20, 24, 30
+    x = torch.randn(B, C, H, W, generator=g).half()
+    sp = (torch.arange(H * 4)[:, None] // 16 * 6 + torch.arange(W * 4)[None, :] // 16).to(torch.int32)[None].repeat(B, 1, 1)
+    rois = torch.tensor([[0, 3.0, 2.0, 60.0, 50.0], [1, 10.5, 8.25, 70.0, 61.0], [0, 33.3, 20.7, 90.1, 77.9]])
+    oh = (torch.rand(3, L, generator=g) < 0.7).to(torch.int32)
+    xd = x.to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out, arg = moi_pool(xd, rois.half().to(cuda), (7, 7), 0.25, oh.to(cuda), sp.to(cuda))
+    assert out.dtype == torch.float16
+    # fp32 run on the same values, corners as the half kernel computes them: round(Half(x) * Half(0.25)) in half
+    pre = rois.clone()
+    pre[:, 1:] = (rois[:, 1:].half().float() * 0.25).half().float()
+    x32 = x.float().to(cuda).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out32, arg32 = moi_pool(x32, pre.to(cuda), (7, 7), 1.0, oh.to(cuda), sp.to(cuda))
+    assert torch.equal(arg.cpu(), arg32.cpu()) and torch.equal(out.float().cpu(), out32.cpu())
+    go = torch.randn(out.shape, generator=g).half()
+    out.backward(go.to(cuda))
+    out32.backward(go.float().to(cuda))
+    assert torch.equal(xd.grad.float().cpu(), x32.grad.half().float().cpu())
+    # ROIAlign: fp32 accumulate, one rounding
+    y = roi_align(xd.detach(), rois.half().to(cuda), (7, 7), 0.25, 0, True)
+    y32 = roi_align(x32.detach(), rois.half().float().to(cuda), (7, 7), 0.25, 0, True)
+    assert y.dtype == torch.float16 and torch.equal(y.cpu(), y32.half().cpu())
