@@ -236,39 +236,44 @@ __global__ __launch_bounds__(256) void align_census_max_kernel(const int* __rest
   if (threadIdx.x == 0) *out = max(max(part[0], part[1]), max(part[2], part[3]));
 }
 
+constexpr int kSub = 64;        // listed rois whose tile weights are staged in LDS at a time
+constexpr int kMaxBins = 16;    // PH, PW <= 16 (7 and 14 on the JTSM path); wider poolers use the scatter form
+
 __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__ grad, const float* __restrict__ rois,
                                                        float* __restrict__ gin, int C, int H, int W, int M, float scale,
                                                        int PH, int PW, int sr, int aligned,
                                                        const int* __restrict__ roi_level, int level, int tiles_x,
                                                        int tiles_y, const int* __restrict__ census_max, int census_lim) {
 #pragma clang fp contract(off)
-  // One workgroup per 8 x 8-cell tile; wavefront w owns channels 64 (w + 4 blockIdx.y) .. + 63 (lane = channel) and
-  // keeps the tile's 64 cells of those channels in REGISTERS.  Every wavefront walks the same list of rois that can
-  // reach the tile; per roi the bins that reach it are a small (ph, pw) rectangle found from the geometry (no scan
-  // over all PH x PW bins), and a bin's contribution g * wy[r] * wx[q] is applied as  v[q] = sum_pw g wx_pw[q]  then
-  // acc[r][q] += wy_ph[r] v[q]  (the column weights of the rectangle are staged once per roi in LDS).
-  constexpr int kMaxBins = 16;          // PW <= 16 (7 and 14 on the JTSM path); wider poolers use the scatter form
+  // One workgroup per (8 x 8-cell tile, 64 channels): lane = channel, and each of the four wavefronts keeps its own
+  // copy of the tile's 64 cells in REGISTERS.  The rois that can reach the tile are listed (256 at a time); for 64 of
+  // them at a time the 256 threads compute, one (roi, axis, bin) each, the bilinear weights of every bin that reaches
+  // the tile on the tile's eight lines (the sample loops run once per workgroup, spread over the lanes) into LDS.  The
+  // wavefronts then share the staged rois round-robin: a bin's contribution g * wy[r] * wx[q] is applied as
+  // v[q] = sum_pw g wx_pw[q], acc[r][q] += wy_ph[r] v[q], weights coming from LDS as broadcast reads, the gradients
+  // of the next bin row already in flight.  The four copies are added in a fixed order at the end: no atomics,
+  // reproducible bit for bit, every map cell written exactly once (no zero fill).
   __shared__ int roi_list[256];
   __shared__ float roi_row[256][5];
   __shared__ int wave_count[4];
-  __shared__ float wxs[4][kMaxBins][kTile];
-  __shared__ int wpw[4][kMaxBins];
+  __shared__ __attribute__((aligned(16))) float pool[kSub * 2 * kMaxBins * kTile];   // 64 KiB: weights, then the 4 copies
+  float (*wts)[2][kMaxBins][kTile] = reinterpret_cast<float (*)[2][kMaxBins][kTile]>(pool);   // [roi][axis y|x][slot][line]
+  __shared__ int first_bin[kSub][2], nbin[kSub][2];
+  __shared__ float inv_cnt[kSub];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   int rel = blockIdx.x;
   const int tx = rel % tiles_x; rel /= tiles_x;
   const int ty = rel % tiles_y;
   const int b = rel / tiles_y;
   const int x0 = tx * kTile, y0 = ty * kTile, x1 = min(x0 + kTile, W) - 1, y1 = min(y0 + kTile, H) - 1;
-  const int c = (blockIdx.y * 4 + wv) * 64 + lane;
-  const bool live = c < C;              // wave-uniform (C % 64 == 0)
+  const int c = blockIdx.y * 64 + lane;
   const int nbins = PH * PW;
   float* __restrict__ out = gin + (size_t)b * H * W * C;
   if (*census_max > census_lim) {   // piled-up rois somewhere: clear the map, the scatter form does the work
-    if (live)
-      for (int cell = 0; cell < kTile * kTile; ++cell) {
-        const int y = y0 + cell / kTile, x = x0 + cell % kTile;
-        if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
-      }
+    for (int cell = wv; cell < kTile * kTile; cell += 4) {
+      const int y = y0 + cell / kTile, x = x0 + cell % kTile;
+      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
+    }
     return;
   }
   float acc[kTile][kTile];
@@ -281,21 +286,6 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
   auto reach = [](float lo, float hi, int n, int& a, int& z) {
     a = max((int)floorf(lo), 0);
     z = min((int)floorf(hi) + 1, n - 1);
-  };
-  // bilinear row (or column) weights of bin `p` of an axis on the tile's eight lines starting at `t0`
-  auto axis_weights = [](float origin, float bin, int grid, int p, int n, int t0, float (&w)[kTile]) {
-#pragma unroll
-    for (int r = 0; r < kTile; ++r) w[r] = 0.f;
-    for (int i = 0; i < grid; ++i) {
-      float y = origin + (float)p * bin + (float)((float)i + .5f) * bin / (float)grid;
-      if (y < -1.0f || y > (float)n) continue;
-      if (y <= 0.f) y = 0.f;
-      int yl = (int)y, yh;
-      if (yl >= n - 1) { yh = yl = n - 1; y = (float)yl; } else { yh = yl + 1; }
-      const float ly = y - (float)yl, hy = 1.f - ly;
-#pragma unroll
-      for (int r = 0; r < kTile; ++r) w[r] += (yl == t0 + r ? hy : 0.f) + (yh == t0 + r ? ly : 0.f);
-    }
   };
 
   for (int base = 0; base < M; base += 256) {
@@ -318,73 +308,108 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
       for (int q = 0; q < 5; ++q) roi_row[slot][q] = rois[(size_t)n * 5 + q];
     }
     __syncthreads();
-    if (live) {
-      for (int i = 0; i < nroi; ++i) {     // every wavefront walks the whole list (its own channels)
-        const RoiGeom<float> g = geom_box<float>(roi_row[i], scale, PH, PW, sr, aligned != 0);
-        const float* __restrict__ gro = grad + (size_t)roi_list[i] * nbins * C + c;
-        // the (pw) bins whose taps reach the tile's columns, and their column weights -> LDS (this wavefront's rows)
-        int npw = 0;
-        {
-          const int lo = max(0, (int)floorf(((float)x0 - 1.f - g.x0) / fmaxf(g.bw, 1e-6f)) - 1);
-          const int hi = min(PW - 1, (int)floorf(((float)x1 + 1.f - g.x0) / fmaxf(g.bw, 1e-6f)) + 1);
-          for (int pw = lo; pw <= hi && npw < kMaxBins; ++pw) {
-            int xa, xz;
-            reach(g.x0 + (float)pw * g.bw, g.x0 + (float)(pw + 1) * g.bw, W, xa, xz);
-            if (xa > x1 || xz < x0) continue;
-            float wx[kTile];
-            axis_weights(g.x0, g.bw, g.gw, pw, W, x0, wx);
-            if (lane < kTile) {
-              float v = 0.f;
+    for (int sub = 0; sub < nroi; sub += kSub) {
+      const int ns = min(kSub, nroi - sub);
+      // ---- stage: bins of each axis that reach the tile, and their weights on the tile's eight lines
+      if (t < ns * 2) {   // one thread per (roi, axis): the contiguous range of reaching bins
+        const int i = t >> 1, axis = t & 1;
+        const RoiGeom<float> g = geom_box<float>(roi_row[sub + i], scale, PH, PW, sr, aligned != 0);
+        const float origin = axis ? g.x0 : g.y0, bin = axis ? g.bw : g.bh;
+        const int P = axis ? PW : PH, n_lines = axis ? W : H, t0 = axis ? x0 : y0, t1 = axis ? x1 : y1;
+        int lo = max(0, (int)floorf(((float)t0 - 1.f - origin) / fmaxf(bin, 1e-6f)) - 1);
+        int hi = min(P - 1, (int)floorf(((float)t1 + 1.f - origin) / fmaxf(bin, 1e-6f)) + 1);
+        auto reaches = [&](int p) {
+          int a, z;
+          reach(origin + (float)p * bin, origin + (float)(p + 1) * bin, n_lines, a, z);
+          return a <= t1 && z >= t0;
+        };
+        while (lo <= hi && !reaches(lo)) ++lo;
+        while (hi >= lo && !reaches(hi)) --hi;
+        first_bin[i][axis] = lo;
+        nbin[i][axis] = max(hi - lo + 1, 0);
+        if (axis == 0) inv_cnt[i] = 1.f / (float)(g.gh * g.gw);
+      }
+      __syncthreads();
+      for (int task = t; task < ns * 2 * kMaxBins; task += 256) {   // one (roi, axis, bin slot) per thread
+        const int i = task / (2 * kMaxBins), axis = (task / kMaxBins) & 1, sl = task % kMaxBins;
+        if (sl >= nbin[i][axis]) continue;
+        const RoiGeom<float> g = geom_box<float>(roi_row[sub + i], scale, PH, PW, sr, aligned != 0);
+        const float origin = axis ? g.x0 : g.y0, bin = axis ? g.bw : g.bh;
+        const int grid = axis ? g.gw : g.gh, n_lines = axis ? W : H, t0 = axis ? x0 : y0;
+        const int p = first_bin[i][axis] + sl;
+        float w[kTile];
 #pragma unroll
-              for (int q = 0; q < kTile; ++q) v = lane == q ? wx[q] : v;
-              wxs[wv][npw][lane] = v;
-            }
-            if (lane == 0) wpw[wv][npw] = pw;
-            ++npw;
-          }
+        for (int r = 0; r < kTile; ++r) w[r] = 0.f;
+        for (int k = 0; k < grid; ++k) {
+          float y = origin + (float)p * bin + (float)((float)k + .5f) * bin / (float)grid;
+          if (y < -1.0f || y > (float)n_lines) continue;
+          if (y <= 0.f) y = 0.f;
+          int yl = (int)y, yh;
+          if (yl >= n_lines - 1) { yh = yl = n_lines - 1; y = (float)yl; } else { yh = yl + 1; }
+          const float ly = y - (float)yl, hy = 1.f - ly;
+#pragma unroll
+          for (int r = 0; r < kTile; ++r) w[r] += (yl == t0 + r ? hy : 0.f) + (yh == t0 + r ? ly : 0.f);
         }
-        if (npw == 0) continue;
-        const int lo = max(0, (int)floorf(((float)y0 - 1.f - g.y0) / fmaxf(g.bh, 1e-6f)) - 1);
-        const int hi = min(PH - 1, (int)floorf(((float)y1 + 1.f - g.y0) / fmaxf(g.bh, 1e-6f)) + 1);
-        const float inv = 1.f / (float)(g.gh * g.gw);
-        for (int ph = lo; ph <= hi; ++ph) {
-          int ya, yz;
-          reach(g.y0 + (float)ph * g.bh, g.y0 + (float)(ph + 1) * g.bh, H, ya, yz);
-          if (ya > y1 || yz < y0) continue;
-          float gk[kMaxBins];
 #pragma unroll
-          for (int k = 0; k < kMaxBins; ++k) gk[k] = k < npw ? gro[(size_t)(ph * PW + wpw[wv][k]) * C] : 0.f;
-          float wy[kTile];
-          axis_weights(g.y0, g.bh, g.gh, ph, H, y0, wy);
-          float v[kTile];
+        for (int r = 0; r < kTile; ++r) wts[i][axis][sl][r] = w[r];
+      }
+      __syncthreads();
+      // ---- walk: wavefront wv takes staged rois wv, wv + 4, ...
+      {
+        for (int i = wv; i < ns; i += 4) {
+          const int npw = nbin[i][1], nph = nbin[i][0];
+          if (npw == 0 || nph == 0) continue;
+          const int pw0 = first_bin[i][1], ph0 = first_bin[i][0];
+          const float inv = inv_cnt[i];
+          const float* __restrict__ gro = grad + ((size_t)roi_list[sub + i] * nbins + (size_t)ph0 * PW + pw0) * C + c;
+          float gk[kMaxBins], gnext[kMaxBins];
 #pragma unroll
-          for (int q = 0; q < kTile; ++q) v[q] = 0.f;
+          for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? gro[(size_t)k * C] : 0.f;
+          for (int a = 0; a < nph; ++a) {
 #pragma unroll
-          for (int k = 0; k < kMaxBins; ++k) {
-            if (k >= npw) break;
-            const float gs = gk[k] * inv;
+            for (int k = 0; k < kMaxBins; ++k) gk[k] = gnext[k];
+            if (a + 1 < nph) {   // the next bin row's gradients are on their way while this one is applied
+              const float* __restrict__ grow = gro + (size_t)(a + 1) * PW * C;
 #pragma unroll
-            for (int q = 0; q < kTile; ++q) v[q] += gs * wxs[wv][k][q];
-          }
+              for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? grow[(size_t)k * C] : 0.f;
+            }
+            float v[kTile];
 #pragma unroll
-          for (int r = 0; r < kTile; ++r) {
-            if (wy[r] == 0.f) continue;
+            for (int q = 0; q < kTile; ++q) v[q] = 0.f;
 #pragma unroll
-            for (int q = 0; q < kTile; ++q) acc[r][q] += wy[r] * v[q];
+            for (int k = 0; k < kMaxBins; ++k) {
+              if (k >= npw) break;
+              const float gs = gk[k] * inv;
+#pragma unroll
+              for (int q = 0; q < kTile; ++q) v[q] += gs * wts[i][1][k][q];
+            }
+#pragma unroll
+            for (int r = 0; r < kTile; ++r) {
+              const float wy = wts[i][0][a][r];
+              if (wy == 0.f) continue;
+#pragma unroll
+              for (int q = 0; q < kTile; ++q) acc[r][q] += wy * v[q];
+            }
           }
         }
       }
+      __syncthreads();                  // before the next batch overwrites the staged weights
     }
     __syncthreads();                    // before the next chunk overwrites roi_list / roi_row
   }
-  if (!live) return;
+  // the four wavefronts' copies -> LDS (the weight pool is free now), added in a fixed order
+  constexpr int SLAB = kTile * kTile * 64;
 #pragma unroll
   for (int r = 0; r < kTile; ++r)
 #pragma unroll
-    for (int q = 0; q < kTile; ++q) {
-      const int y = y0 + r, x = x0 + q;
-      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = acc[r][q];
-    }
+    for (int q = 0; q < kTile; ++q) pool[wv * SLAB + (r * kTile + q) * 64 + lane] = acc[r][q];
+  __syncthreads();
+  for (int cell = wv; cell < kTile * kTile; cell += 4) {
+    const int y = y0 + cell / kTile, x = x0 + cell % kTile;
+    if (y > y1 || x > x1) continue;
+    const int o = cell * 64 + lane;
+    out[((size_t)y * W + x) * C + c] = ((pool[o] + pool[SLAB + o]) + pool[2 * SLAB + o]) + pool[3 * SLAB + o];
+  }
 }
 
 // ---------------------------------------------------------------- NCHW (reference layout)
@@ -520,7 +545,7 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
   JTSM_REQUIRE(gin, "roi_align backward: null grad_input");
   // (a handful of rois — the mask branch's foreground set — is cheaper as memset + scatter than as one workgroup per
   // tile of the whole map: the gather starts at 8192 bins)
-  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && grad && rois && PW <= 16 &&
+  if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && grad && rois && PW <= kMaxBins && PH <= kMaxBins &&
       (long)M * PH * PW >= 8192 && (long)M * PH * PW < (1L << 30)) {
     // gather form with the census guard: both forms are launched, the device-side census lets one of them return
     const int tiles_x = ceil_div(W, kTile), tiles_y = ceil_div(H, kTile), ntile = B * tiles_x * tiles_y;
@@ -532,7 +557,7 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
     hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, r32, M, (float)scale, PH, PW, sr,
                        aligned, H, W, roi_level, level, tiles_x, tiles_y, census);
     hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
-    hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, ceil_div(C, 256)), dim3(256), 0, st, g32,
+    hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 0, st, g32,
                        r32, reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
                        tiles_x, tiles_y, census + ntile, census_limit());
     constexpr int V = WideVec<float>::value;
