@@ -349,6 +349,12 @@ int jtsm_relu_backward_split_f32(const float* dy, const float* y, float* g, uint
 int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, void* stream);
 /* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);
+/* The same without atomics (bitwise reproducible) and ~4x faster on large inputs: row slabs are summed into
+ * `workspace` (jtsm_channel_sum_workspace_bytes, 16-byte aligned) and folded in slab order.  Falls back to the form
+ * above for narrow matrices (C < 128 or C % 4 != 0), short ones, or a workspace that is too small. */
+size_t jtsm_channel_sum_workspace_bytes(long rows, int C);
+int jtsm_channel_sum_ws_f32(const float* g, float* out, long rows, int C, void* workspace, size_t workspace_bytes,
+                            void* stream);
 /* SGD with momentum over many tensors in ONE launch — torch.optim.SGD as detectron2/solver/build.py:110-195
  * configures it (dampening 0, no nesterov): d = g + wd*p; buf = first_step ? d : mu*buf + d; p -= lr*buf.
  * table: device array of `entries` records of eight 64-bit words {param, grad, momentum_buffer, n, first_block,

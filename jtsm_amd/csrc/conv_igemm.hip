@@ -1265,7 +1265,7 @@ static bool x3_wgrad_halo(const Params& p) {
 static int x3_wgrad_splits(const Params& p) {
   if (x3_wgrad_halo(p)) {
     const int ntiles = ceil_div(p.M, 128) * (p.s.Cin / 32), segs = p.K / 32;
-    int splits = ntiles >= 512 ? 1 : ceil_div(512, ntiles);
+    int splits = ntiles >= 512 ? 1 : 512 / ntiles;
     if (splits > segs / 8) splits = segs / 8;   // at least 8 segments per workgroup
     if (splits > 64) splits = 64;
     if (splits < 1) splits = 1;
@@ -1278,8 +1278,10 @@ static int x3_wgrad_splits(const Params& p) {
   // Pixel-axis split (measured on MI355X, tools/sweeps/wsplit.py): the kernels are bound by memory latency x bytes in
   // flight, so two workgroups per CU (512) beat one as long as each keeps >= 8 stages; 256 x 256 tiles hold one
   // workgroup per CU.
-  int splits = ceil_div(big ? 256 : 512, ntiles);
-  if (!big && ceil_div(ktiles, splits) > 64) splits = ceil_div(768, ntiles);
+  // one resident round: 256 workgroups of 256 x 256 (one per CU), 512 of 128 x 128 (two per CU) — rounded DOWN, so the
+  // launch never spills a handful of workgroups into a second round (9 tiles x 29 slices = 261 did: half the time idle)
+  int splits = max(1, (big ? 256 : 512) / ntiles);
+  if (!big && ceil_div(ktiles, splits) > 64) splits = max(1, 768 / ntiles);
   const int min_stages = big ? 16 : 8;
   if (splits > ceil_div(ktiles, min_stages)) splits = ceil_div(ktiles, min_stages);
   if (splits > 64) splits = 64;   // slab traffic: the finishing pass reads splits x dW

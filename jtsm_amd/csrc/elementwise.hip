@@ -439,6 +439,42 @@ int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint
   return JTSM_OK;
 }
 
+static void csum_plan(long rows, int C, long* rpb, int* nslab) {
+  const int cg = ceil_div(C / 4, 64);
+  long slabs = 1024 / cg;            // ~4 workgroups per CU in all
+  if (slabs < 1) slabs = 1;
+  if (slabs > (rows + 63) / 64) slabs = (rows + 63) / 64;
+  if (slabs < 1) slabs = 1;
+  *rpb = (rows + slabs - 1) / slabs;
+  *nslab = (int)((rows + *rpb - 1) / *rpb);
+}
+
+size_t jtsm_channel_sum_workspace_bytes(long rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 4) return 0;
+  long rpb; int nslab;
+  csum_plan(rows, C, &rpb, &nslab);
+  return (size_t)nslab * C * sizeof(float) + 16;
+}
+
+int jtsm_channel_sum_ws_f32(const float* g, float* out, long rows, int C, void* workspace, size_t workspace_bytes,
+                            void* stream) {
+  JTSM_REQUIRE(rows >= 0 && C > 0, "channel_sum: bad sizes");
+  JTSM_REQUIRE(out, "channel_sum: null out");
+  hipStream_t st = as_stream(stream);
+  const bool wide = C % 4 == 0 && C >= 128 && ((uintptr_t)g & 15) == 0 && rows >= 256 && workspace &&
+                    ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= jtsm_channel_sum_workspace_bytes(rows, C);
+  if (!wide) return jtsm_channel_sum_f32(g, out, rows, C, stream);
+  JTSM_REQUIRE(g, "channel_sum: null pointer");
+  long rpb; int nslab;
+  csum_plan(rows, C, &rpb, &nslab);
+  float* part = reinterpret_cast<float*>(workspace);
+  hipLaunchKernelGGL(channel_sum4_kernel, dim3(ceil_div(C / 4, 64), (unsigned)nslab), dim3(256), 0, st,
+                     reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(part), rows, C / 4, rpb);
+  hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
+  JTSM_CHECK_LAUNCH("channel_sum");
+  return JTSM_OK;
+}
+
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream) {
   JTSM_REQUIRE(rows >= 0 && C > 0, "channel_sum: bad sizes");
   JTSM_REQUIRE(out, "channel_sum: null out");
@@ -446,22 +482,6 @@ int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* str
   JTSM_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
   if (rows == 0) return JTSM_OK;
   JTSM_REQUIRE(g, "channel_sum: null pointer");
-  if (C % 4 == 0 && C >= 128 && ((uintptr_t)g & 15) == 0 && rows >= 256) {   // (narrow / short: the 4-byte kernel)
-    const int cg = ceil_div(C / 4, 64);
-    long slabs = 1024 / cg;            // ~4 workgroups per CU in all
-    if (slabs < 1) slabs = 1;
-    if (slabs > (rows + 63) / 64) slabs = (rows + 63) / 64;
-    const long rpb = (rows + slabs - 1) / slabs;
-    const int nslab = (int)((rows + rpb - 1) / rpb);
-    float* part = nullptr;
-    JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&part), (size_t)nslab * C * sizeof(float), st));
-    hipLaunchKernelGGL(channel_sum4_kernel, dim3(cg, (unsigned)nslab), dim3(256), 0, st,
-                       reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(part), rows, C / 4, rpb);
-    hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
-    JTSM_CHECK_LAUNCH("channel_sum");
-    JTSM_CHECK_HIP(hipFreeAsync(part, st));
-    return JTSM_OK;
-  }
   const int cgroups = ceil_div(C, 64);
   long slabs = 2048 / cgroups;
   if (slabs < 1) slabs = 1;

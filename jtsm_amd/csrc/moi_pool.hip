@@ -144,26 +144,51 @@ __device__ __forceinline__ void moi_pool_wave(
     int at[VEC];
 #pragma unroll
     for (int v = 0; v < VEC; ++v) { best[v] = -FLT_MAX; at[v] = -1; }
-    for (int h = q.hs; h < q.he; ++h)
-      for (int w = q.ws; w < q.we; ++w) {
-        // inside the rounded (inclusive) box?  wave-uniform
-        if (!(w >= r.x0 && w <= r.x1 && h >= r.y0 && h <= r.y1)) continue;
-        const int cell = h * W + w;
-        if (!cell_hit(cplane + (size_t)cell * words, rrow, mine, words, lane)) continue;
-        if (live) {
-          const float* p = plane + (size_t)cell * C + c;
-          float x[VEC];
-          if (VEC == 4) {
-            const float4 t = *reinterpret_cast<const float4*>(p);
-            x[0] = t.x; x[1 % VEC] = t.y; x[2 % VEC] = t.z; x[3 % VEC] = t.w;
-          } else {
-            x[0] = p[0];
-          }
+    // The bin's cells in (h, w) order, FOUR at a time: their mask words are requested together, then the features
+    // of those that hit, so a round trip to memory serves four cells instead of one (the walk is latency-bound:
+    // mask word -> ballot -> feature row -> compare).  Comparison order = cell order (first maximum wins).
+    constexpr int kAhead = 4;
+    const int bwid = q.we - q.ws, ncell = (q.he - q.hs) * bwid;
+    for (int i0 = 0; i0 < ncell; i0 += kAhead) {
+      int cell[kAhead];
+      unsigned hb[kAhead];
 #pragma unroll
-          for (int v = 0; v < VEC; ++v)
-            if (x[v] > best[v]) { best[v] = x[v]; at[v] = cell; }
+      for (int u = 0; u < kAhead; ++u) {
+        const int idx = i0 + u;
+        const int h = q.hs + idx / max(bwid, 1), w = q.ws + idx % max(bwid, 1);
+        // inside the bin and the rounded (inclusive) box?  wave-uniform
+        const bool in = idx < ncell && w >= r.x0 && w <= r.x1 && h >= r.y0 && h <= r.y1;
+        cell[u] = in ? h * W + w : -1;
+        hb[u] = 0u;
+        if (in) {
+          const unsigned* __restrict__ crow = cplane + (size_t)cell[u] * words;
+          if (lane < words) hb[u] = crow[lane] & mine;
+          for (int i = 64 + lane; i < words; i += 64) hb[u] |= crow[i] & rrow[i];
         }
       }
+      bool hit[kAhead];
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) hit[u] = cell[u] >= 0 && __ballot(hb[u] != 0u) != 0ull;
+      float x[kAhead][VEC];
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        if (!(hit[u] && live)) continue;
+        const float* p = plane + (size_t)cell[u] * C + c;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(p);
+          x[u][0] = t.x; x[u][1 % VEC] = t.y; x[u][2 % VEC] = t.z; x[u][3 % VEC] = t.w;
+        } else {
+          x[u][0] = p[0];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        if (!(hit[u] && live)) continue;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v)
+          if (x[u][v] > best[v]) { best[v] = x[u][v]; at[v] = cell[u]; }
+      }
+    }
     if (live) {
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {

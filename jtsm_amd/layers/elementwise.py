@@ -50,8 +50,13 @@ def channel_sum(g):
         g = g.contiguous()
         rows, ch = g.shape
     out = torch.empty(ch, dtype=g.dtype, device=g.device)
+    from . import conv
+    lib = L.lib()
+    nbytes = lib.jtsm_channel_sum_workspace_bytes(C.c_long(rows), ch)
+    ws = conv._scratch(nbytes, g.device)      # the contractions' scratch: same stream, in order
     L.note_bytes(4.0 * g.numel())
-    L.check(L.lib().jtsm_channel_sum_f32(L.ptr(g), L.ptr(out), C.c_long(rows), ch, L.stream()), "channel_sum")
+    L.check(lib.jtsm_channel_sum_ws_f32(L.ptr(g), L.ptr(out), C.c_long(rows), ch, L.ptr(ws), C.c_size_t(nbytes),
+                                        L.stream()), "channel_sum")
     return out
 
 
