@@ -16,6 +16,9 @@ from . import conv as K
 from .elementwise import relu_backward
 
 CL = torch.channels_last
+# False: residual blocks run layer by layer (the same kernels, one autograd node per convolution) — used by the
+# frozen-gates parity test, whose forward hooks need every convolution's output
+ENABLED = True
 
 
 def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=None, emit_planes=False):

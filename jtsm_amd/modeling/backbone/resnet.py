@@ -15,6 +15,7 @@ from torch import nn
 from ...layers.batch_norm import FrozenBatchNorm2d, get_norm
 from ...layers.blocks import CNNBlockBase
 from ...layers.elementwise import max_pool_3x3_s2
+from ...layers import fused_blocks
 from ...layers.fused_blocks import bottleneck_fused
 from ...layers.wrappers import Conv2d
 from .backbone import Backbone
@@ -81,7 +82,8 @@ class BottleneckBlock(CNNBlockBase):
         return [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
 
     def forward(self, x):
-        if x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and _all_frozen(self._members()):
+        if fused_blocks.ENABLED and x.is_cuda and x.dtype == torch.float32 and x.shape[1] % 8 == 0 and \
+                _all_frozen(self._members()):
             # one autograd node for the block: ReLU gates and the two-path sum ride in the data-gradient epilogues
             sc = self.shortcut
             return bottleneck_fused(

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 
 from ...layers.blocks import CNNBlockBase
 from ...layers.elementwise import max_pool_2x2
+from ...layers import fused_blocks
 from ...layers.fused_blocks import bottleneck_fused
 from .build import BACKBONE_REGISTRY
 from .resnet import ResNet, _all_frozen, conv_norm, resnet_cfg
@@ -76,7 +77,7 @@ class PooledBottleneckBlock(_PooledBlock):
     def forward(self, x):
         x = self.pooled(x)
         convs = [c for c in (self.conv1, self.conv2, self.conv3, self.shortcut) if c is not None]
-        if x.is_cuda and x.shape[1] % 8 == 0 and _all_frozen(convs):
+        if fused_blocks.ENABLED and x.is_cuda and x.shape[1] % 8 == 0 and _all_frozen(convs):
             sc = self.shortcut
             return self.pooled_out(bottleneck_fused(
                 x, self.conv1.weight, self.conv1.norm.scale_bias(), self.conv2.weight, self.conv2.norm.scale_bias(),

@@ -79,8 +79,7 @@ class DiscriminativeAdaptionNeck(nn.Module):
                 x = x.permute(0, 2, 3, 1)               # (h,w,c) order: a view of a channels_last tensor
             x = x.reshape(x.shape[0], -1)
         for k, fc in enumerate(self.fcs):
-            from ...layers.conv import linear_fused
-            x = linear_fused(x, fc.weight, fc.bias, True, True)
+            x = fc(x, relu=True)                       # Linear + bias + ReLU: one MFMA GEMM launch
             if self.training and self.dropout_p > 0:
                 x = torch.nn.functional.dropout(x, self.dropout_p, True)
         return x

@@ -170,9 +170,21 @@ def frozen_bn(p, name, x, eps=1e-5):
     return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
 
 
+# Forced discrete choices (tests/test_hip_model.py: whole-step gradients at 1e-4): when set, ReLU gates named here,
+# the MOIPool winners and the refinery's mask targets are TAKEN from this dict instead of being decided by this
+# run's own (rounding-dependent) values, so that two implementations differentiate the same piecewise-linear map.
+_FORCED = None
+
+
+def gated_relu(y, name):
+    if _FORCED is not None and name in _FORCED.get("gates", {}):
+        return y * _FORCED["gates"][name].to(y.dtype)
+    return F.relu(y)
+
+
 def conv_bn(p, name, x, stride=1, pad=0, relu=False, dil=1):
     y = frozen_bn(p, name + ".norm", F.conv2d(x, p[name + ".weight"], None, stride, pad, dil))
-    return F.relu(y) if relu else y
+    return gated_relu(y, name) if relu else y
 
 
 def bottleneck(p, pre, x, stride):
@@ -181,7 +193,7 @@ def bottleneck(p, pre, x, stride):
     out = conv_bn(p, pre + "conv2", out, 1, 1, True)
     out = conv_bn(p, pre + "conv3", out)
     sc = conv_bn(p, pre + "shortcut", x, stride) if (pre + "shortcut.weight") in p else x
-    return F.relu(out + sc)
+    return gated_relu(out + sc, pre + "conv3")
 
 
 def resnet_fpn(p, x, depth=50):
@@ -410,7 +422,14 @@ def moi_pool_levels(feats, boxes_list, oh_list, superpixels, res=7, single=False
         scale = f.shape[2] / superpixels.shape[1]
         y, a = P.moi_pool_forward(f.detach().numpy(), rois[sel].numpy(), scale, res, res, oh[sel].numpy(),
                                   superpixels.numpy())
-        out[sel], arg[sel] = torch.from_numpy(y), torch.from_numpy(a)
+        y, a = torch.from_numpy(y), torch.from_numpy(a)
+        if _FORCED is not None and "argmax" in _FORCED:      # winners decided elsewhere: read the features there
+            a = _FORCED["argmax"][sel].to(torch.int32)
+            b_idx = rois[sel, 0].to(torch.int64)
+            flat = f.detach().flatten(2)                                                 # (B, C, H*W)
+            picked = torch.gather(flat[b_idx], 2, a.clamp(min=0).to(torch.int64).flatten(2)).view(a.shape)
+            y = torch.where(a >= 0, picked, torch.zeros(()))
+        out[sel], arg[sel] = y, a
         grads.append((l, sel, scale))
     return _MoiLevels.apply(out, arg, rois, grads, res, *feats), arg
 
@@ -489,7 +508,7 @@ def oicr_losses(logits, deltas, prop_boxes, lab, nt=NUM_THINGS):
 
 # ----------------------------------------------------------------------------- heads
 def linear_relu_drop(p, name, x, drop):
-    x = F.relu(F.linear(x, p[name + ".weight"], p[name + ".bias"]))
+    x = gated_relu(F.linear(x, p[name + ".weight"], p[name + ".bias"]), name)
     return x if drop is None else x * drop
 
 
@@ -531,8 +550,9 @@ def pgt_sem_seg(tgt_list, H, W, nt=NUM_THINGS):
 
 def mask_head_layers(p, pre, x):
     for k in range(4):
-        x = F.relu(F.conv2d(x, p["%smask_fcn%d.weight" % (pre, k + 1)], p["%smask_fcn%d.bias" % (pre, k + 1)], 1, 1))
-    x = F.relu(F.conv_transpose2d(x, p[pre + "deconv.weight"], p[pre + "deconv.bias"], 2))
+        x = gated_relu(F.conv2d(x, p["%smask_fcn%d.weight" % (pre, k + 1)], p["%smask_fcn%d.bias" % (pre, k + 1)], 1, 1),
+                       "%smask_fcn%d" % (pre, k + 1))
+    x = gated_relu(F.conv_transpose2d(x, p[pre + "deconv.weight"], p[pre + "deconv.bias"], 2), pre + "deconv")
     return F.conv2d(x, p[pre + "predictor.weight"], p[pre + "predictor.bias"])
 
 
@@ -544,8 +564,8 @@ def semseg_head(p, feats):
         for j in range(nconv):
             idx = j * (1 if lvl == 2 else 2)
             n = "sem_seg_head.p%d.%d" % (lvl, idx)
-            x = F.relu(F.group_norm(F.conv2d(x, p[n + ".weight"], None, 1, 1), 32, p[n + ".norm.weight"],
-                                    p[n + ".norm.bias"]))
+            x = gated_relu(F.group_norm(F.conv2d(x, p[n + ".weight"], None, 1, 1), 32, p[n + ".norm.weight"],
+                                        p[n + ".norm.bias"]), n)
             if lvl != 2:
                 x = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
         total = x if total is None else total + x
@@ -571,12 +591,21 @@ def near_targets_and_masks(boxes, sel, tgt, oh, sp, top_k=10):
 
 
 def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_aux=False, arch="fpn",
-                   nt=NUM_THINGS, ns=NUM_STUFF, mask_targets="evidence"):
+                   nt=NUM_THINGS, ns=NUM_STUFF, mask_targets="evidence", forced=None):
     """batch: dict(images=[(3,H,W)], boxes=[(R_i,4)], objectness=[(R_i,)], oh_labels=[(R_i,L) int],
     superpixels=(B,H,W) int32, gt_classes=[(n_i,) int64], sem_seg=(B,H,W) int64).
     arch "fpn": the R50/R101-FPN composite with SemSegFPNHead; arch "dc5": the shipped single-level composite
     (ResNet-WS v2 dilated C5, one feature map at stride 8, TwoClassHead = no semantic loss), nt thing / ns semantic
     classes.  Returns the loss dict (keys as in SURVEY §5 'Metrics / logging')."""
+    global _FORCED
+    _FORCED = forced
+    try:
+        return _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, nt, ns, mask_targets)
+    finally:
+        _FORCED = None
+
+
+def _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, nt, ns, mask_targets):
     single = arch == "dc5"
     NUM_THINGS, NUM_MIL = nt, nt + ns - 1   # (shadow the module constants: the body below is written with them)
     x = preprocess(p, batch["images"], 8 if single else 32)
@@ -677,6 +706,8 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
                                                              True))[:, 0] >= 0.5
     else:
         tgt2 = logits.detach()[ar, fg_cls] > 0.0      # sigmoid > 0.5 of the first head's own prediction
+    if _FORCED is not None and "mask_targets_r0" in _FORCED:
+        tgt2 = _FORCED["mask_targets_r0"]
     aux["mask_targets_r0"] = tgt2
     logits2 = mask_head_layers(p, "roi_heads.mask_refinery_0.", mfeat)
     losses["loss_mask_r0"] = mask_loss(logits2, tgt2)

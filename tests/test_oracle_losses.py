@@ -114,3 +114,75 @@ def test_oracle_dc5_architecture_runs_and_trains_heads_only():
     assert bool(torch.isfinite(total))
     total.backward()
     assert all(p[n].grad is not None for n in names if "mask_refinery" not in n or float(losses["loss_mask"]) > 0)
+
+
+def _mil_literal(C, D, counts, y, mean_loss=True):
+    """A second, independently written reading of the MIL path — scalar Python floats (fp64), one line of the
+    reference per step, no tensor operations:
+      fast_rcnn_tsm.py:572-586   scores[r][c] = softmax over CLASSES of C[r] (dim=1)  x  softmax over the image's
+                                 PROPOSALS of D[:, c] (dim=0), image by image
+      :840-854 / :364-378        p_img[i][c] = clamp(sum_r scores, 1e-6, 1 - 1e-6)
+      :346-362                   BCE(p_img, y): mean over all (image, class) entries, or sum / number of images
+    Returns (scores, p_img, loss) as nested lists / float."""
+    import math
+    R, nc = len(C), len(C[0])
+    scores = [[0.0] * nc for _ in range(R)]
+    p_img, r0 = [], 0
+    for n in counts:
+        rows = range(r0, r0 + n)
+        cls_soft = {}
+        for r in rows:                                     # F.softmax(c, dim=1)
+            m = max(C[r])
+            e = [math.exp(v - m) for v in C[r]]
+            z = sum(e)
+            cls_soft[r] = [v / z for v in e]
+        for c in range(nc):                                # F.softmax(d, dim=0)
+            col = [D[r][c] for r in rows]
+            if not col:
+                continue
+            m = max(col)
+            e = [math.exp(v - m) for v in col]
+            z = sum(e)
+            for k, r in enumerate(rows):
+                scores[r][c] = cls_soft[r][c] * (e[k] / z)
+        p_img.append([min(max(sum(scores[r][c] for r in rows), 1e-6), 1.0 - 1e-6) for c in range(nc)])
+        r0 += n
+    total = 0.0
+    for i in range(len(counts)):
+        for c in range(nc):
+            total += -(y[i][c] * math.log(p_img[i][c]) + (1.0 - y[i][c]) * math.log(1.0 - p_img[i][c]))
+    loss = total / (len(counts) * nc) if mean_loss else total / len(counts)
+    return scores, p_img, loss
+
+
+def test_mil_second_literal_reading_agrees_incl_gradient():
+    """The scalar reading above against oracle/model.py (values), and its central finite differences (fp64) against
+    the oracle's autograd gradient: two independent readings of the unpinned MIL arithmetic that agree."""
+    g = torch.Generator().manual_seed(3)
+    counts = [7, 0, 12]                                   # ragged, incl. an empty bag
+    R, nc = sum(counts), 9
+    C = (torch.randn(R, nc, generator=g, dtype=torch.float64) * 2).requires_grad_()
+    D = (torch.randn(R, nc, generator=g, dtype=torch.float64) * 2).requires_grad_()
+    y = (torch.rand(len(counts), nc, generator=g) < 0.3).double()
+    for mean_loss in (True, False):
+        s = OM.mil_scores(C, D, counts)
+        p = OM.mil_image_probs(s, counts)
+        loss = F.binary_cross_entropy(p, y, reduction="mean" if mean_loss else "sum") / (1 if mean_loss else len(counts))
+        s2, p2, l2 = _mil_literal(C.tolist(), D.tolist(), counts, y.tolist(), mean_loss)
+        assert torch.allclose(s.detach(), torch.tensor(s2, dtype=torch.float64), atol=1e-12)
+        assert torch.allclose(p.detach(), torch.tensor(p2, dtype=torch.float64), atol=1e-12)
+        assert abs(float(loss) - l2) < 1e-12
+        C.grad = D.grad = None
+        loss.backward()
+        eps = 1e-6
+        for (name, T) in (("C", C), ("D", D)):
+            for (r, c) in ((0, 0), (3, 4), (8, 8), (R - 1, 2)):
+                base = T.detach().clone()
+                vals = []
+                for sgn in (+1, -1):
+                    t = base.clone()
+                    t[r, c] += sgn * eps
+                    args = (t.tolist(), D.tolist()) if name == "C" else (C.tolist(), t.tolist())
+                    vals.append(_mil_literal(args[0], args[1], counts, y.tolist(), mean_loss)[2])
+                fd = (vals[0] - vals[1]) / (2 * eps)
+                assert abs(fd - float(T.grad[r, c])) <= 1e-6 * max(1.0, abs(fd)), (name, r, c, fd, float(T.grad[r, c]))
