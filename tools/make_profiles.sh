@@ -1,21 +1,27 @@
 #!/bin/bash
 # Produce the round's measurement artefacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/art/bench.json, kernel_stats.csv, pmc/{fetch,write,mfma}, pmc_traffic.json, pmc_mfma.json, stock.json,
-#   inference.json, inference_kernel_stats.csv, input_pipeline.json
-# Copy what should be judged into profiles/ afterwards (gpurun_out/ is scratch).
+#   gpurun_out/art/{bench.json, kernel_stats.csv (headline workload), kernel_stats_uniform.csv (round-1 workload),
+#   pmc/{fetch,write,mfma}, pmc_traffic.json, pmc_mfma.json, stock.json, inference.json, inference_kernel_stats.csv,
+#   input_pipeline.json}
+# Copy what should be judged into profiles/ (named per round) afterwards: gpurun_out/ is scratch.
+# Counter passes are separate runs with --kernel-trace only (no other trace domain), as the pool requires.
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/art
 mkdir -p $A
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-config4 > $A/pmc_fetch.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-config4 > $A/pmc_write.log 2>&1 &&
+FAST="--no-cpu-baseline --no-roofline --no-exact --no-config4"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_write.log 2>&1 &&
 python tools/pmc_traffic.py $A/pmc profiles/pmc_traffic.json && cp profiles/pmc_traffic.json $A/pmc_traffic.json &&
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $A/pmc/mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact --no-config4 > $A/pmc_mfma.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $A/pmc/mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_mfma.log 2>&1 &&
 (cd tools && python pmc_mfma.py ../$A/pmc/mfma ../profiles/pmc_mfma.json) && cp profiles/pmc_mfma.json $A/pmc_mfma.json &&
 rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 > $A/prof_bench.json 2> $A/prof.log &&
 cp $A/prof/r_kernel_stats.csv $A/kernel_stats.csv &&
+rocprofv3 --kernel-trace --stats -d $A/prof_u -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 --no-roofline --cluster 0 > $A/prof_u_bench.json 2> $A/prof_u.log &&
+cp $A/prof_u/r_kernel_stats.csv $A/kernel_stats_uniform.csv &&
 python bench.py --steps 20 --warmup 5 > $A/bench.json 2> $A/bench.err &&
 python tools/stock_baseline.py > $A/stock.json 2> $A/stock.err &&
+python tools/stock_baseline.py --cluster 0 > $A/stock_uniform.json 2> $A/stock_uniform.err &&
 rocprofv3 --kernel-trace --stats -d $A/infprof -o r --output-format csv -- python tools/bench_inference.py --steps 10 --warmup 3 > $A/infprof_bench.json 2> $A/infprof.log &&
 cp $A/infprof/r_kernel_stats.csv $A/inference_kernel_stats.csv &&
 python tools/bench_inference.py --steps 20 --warmup 5 --cpu-baseline > $A/inference.json 2> $A/inference.err &&

@@ -33,7 +33,7 @@ def main():
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     for i, v in disp.items():
         k = label(v["name"])
-        if k:
+        if k and k.startswith("igemm"):
             a = agg[k]
             a[0] += 1
             a[1] += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)

@@ -100,6 +100,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cluster", type=float, default=1.0, help="as bench.py (0 = the uniform recipe of round 1)")
+    ap.add_argument("--objects", type=int, default=40)
     args = ap.parse_args()
     patch_to_stock()
     import bench
@@ -107,7 +109,8 @@ def main():
 
     dev = torch.device("cuda", 0)
     model = bench.build(dev)
-    inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev)
+    inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev, cluster=args.cluster,
+                              objects=args.objects)
     opt = bench.make_optimizer(model, fused=False)
 
     def step():
@@ -128,7 +131,8 @@ def main():
     dt = time.perf_counter() - t0
     print(json.dumps({"what": "stock PyTorch-ROCm operators, same model/step as bench.py (pooling ops: HIP kernels)",
                       "value": round(2 * args.steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / args.steps, 3),
-                      "steps": args.steps, "final_loss": round(float(last.detach()), 5),
+                      "steps": args.steps, "final_loss": round(float(last.detach()), 5), "cluster": args.cluster,
+                      "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
                       "torch": torch.__version__}))
 
 
