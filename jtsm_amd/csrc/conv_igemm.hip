@@ -32,6 +32,7 @@
 // "sum the two gradient paths, then gate by the ReLU mask" in DGRAD.  WGRAD accumulates with
 // float atomics into a zero-filled dW (optionally scaled per output row).
 #include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -74,6 +75,10 @@ struct Params {
   // fp16 path: gradient planes are stored times 2^k so that small gradients stay above fp16's subnormal range.
   int in_shift;             // the accumulator is multiplied by 2^-in_shift first (an operand plane carried 2^in_shift)
   int out_shift;            // emitted planes are multiplied by 2^out_shift
+  // Split-K finishing INSIDE the contraction kernel (null: the separate splitk_finish pass).  One zero-initialised
+  // counter per output tile (blockIdx.x): a workgroup publishes its slab with write-through stores and takes a ticket;
+  // the last of a tile's gridDim.y slices adds all slabs in slice order and runs the epilogue.
+  int* tickets;
   ConvShape s;
   Epilogue e;
 };
@@ -304,6 +309,71 @@ struct PatchRows {
   }
 };
 
+// ---- device-scope message passing without device-scope FENCES --------------------------------------------------
+// A fence at agent scope (__threadfence) writes back / invalidates the XCD's whole L2: tried for split-K finishing in
+// round 1, it doubled the step.  Here only the slab traffic itself is made coherent, instruction by instruction: slabs
+// are written with sc1 stores (agent scope: written through the XCD's L2) and read back with sc1 loads (agent scope:
+// served from the coherent level, not from this XCD's possibly stale L2 / L1) — the encodings the LLVM AMDGPU memory
+// model prescribes for monotonic agent-scope atomics on gfx942 / gfx950 — and the ticket is an agent-scope atomic.
+// Ordering: a workgroup waits for its stores' acknowledgements (s_waitcnt vmcnt(0) in every thread, then the
+// workgroup barrier) before thread 0 takes the ticket; the reader's loads are issued after it has seen the ticket.
+typedef float fx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void st_sc1_x4(float* ptr, const float4& v) {
+  const fx4 t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st_sc1(float* ptr, float v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(ptr), "v"(v) : "memory");
+}
+// eight 16-byte loads in flight, then wait for all of them (one asm block: the compiler cannot see that the
+// destinations are written asynchronously)
+__device__ __forceinline__ void ld_sc1_x4_8(const float* const (&q)[8], fx4 (&o)[8]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %9, off sc1\n\t"
+      "global_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\t"
+      "global_load_dwordx4 %4, %12, off sc1\n\t"
+      "global_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\t"
+      "global_load_dwordx4 %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+      : "memory");
+}
+__device__ __forceinline__ void ld_sc1_8(const float* const (&q)[8], float (&o)[8]) {
+  asm volatile(
+      "global_load_dword %0, %8, off sc1\n\t"
+      "global_load_dword %1, %9, off sc1\n\t"
+      "global_load_dword %2, %10, off sc1\n\t"
+      "global_load_dword %3, %11, off sc1\n\t"
+      "global_load_dword %4, %12, off sc1\n\t"
+      "global_load_dword %5, %13, off sc1\n\t"
+      "global_load_dword %6, %14, off sc1\n\t"
+      "global_load_dword %7, %15, off sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7])
+      : "memory");
+}
+
+// After a workgroup's slab is written: true in exactly one workgroup of each tile — the last of its gridDim.y slices
+// (which also re-arms the counter for the next launch).  `flag` is one int of LDS.
+__device__ __forceinline__ bool splitk_last_arrival(const Params& p, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's slab stores are acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(p.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = old == (int)gridDim.y - 1;
+    if (last) __hip_atomic_store(p.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
 template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256, class MAP = LinearRows>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                 int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */,
@@ -315,6 +385,37 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
   constexpr int CPR = BN / 4;                 // float4 pieces per tile row
   constexpr int PIECES = ROWS * CPR / NT;     // per thread per band
   const bool raw = gridDim.y > 1;             // split-K: raw partial into this slice's slab
+  // the fused epilogue of one finished float4 piece at output row m, column n
+  auto finish_piece = [&](int m, int n, float4 v) {
+    size_t o = (size_t)m * p.ldc + n;
+    if (ROLE == DGRAD && p.scatter) {
+      const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
+      const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
+      o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
+    }
+    if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
+    if (ROLE == WGRAD) {
+      if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+    } else if (e.scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
+      v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+    }
+    if (e.bias) {
+      const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
+      v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+    }
+    if (e.residual) {
+      const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (e.mask) {
+      const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
+      v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+    *reinterpret_cast<float4*>(p.C + o) = v;
+    if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
+  };
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
     __syncthreads();   // every wave is done reading the last K stage / streaming the previous band
@@ -340,39 +441,67 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
       if (m < 0 || m >= p.M || n >= p.N) continue;
       float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
       if (raw) {
-        *reinterpret_cast<float4*>(p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n) = v;
+        float* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n;
+        if (p.tickets) st_sc1_x4(dst, v);
+        else *reinterpret_cast<float4*>(dst) = v;
         continue;
       }
-      size_t o = (size_t)m * p.ldc + n;
-      if (ROLE == DGRAD && p.scatter) {
-        const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
-        const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
-        o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
-      }
-      if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
-      if (ROLE == WGRAD) {
-        if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
-      } else if (e.scale) {
-        const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
-        v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
-      }
-      if (e.bias) {
-        const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
-        v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
-      }
-      if (e.residual) {
-        const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
-        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-      }
-      if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-      if (e.mask) {
-        const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
-        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-      }
-      *reinterpret_cast<float4*>(p.C + o) = v;
-      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
+      finish_piece(m, n, v);
     }
   }
+  if (!(raw && p.tickets)) return;
+  // ---- split-K finishing by the tile's last-arriving slice: every slab in slice order, then the epilogue
+  __syncthreads();                                   // (the LDS window is free again)
+  if (!splitk_last_arrival(p, reinterpret_cast<int*>(tile))) return;
+  const int S = (int)gridDim.y;
+  constexpr int NPIECE = BM * CPR / NT;              // float4 pieces of the whole tile per thread
+  const size_t slice = (size_t)p.M * p.ldc;
+  // SPAD slices of PP = 8 / SPAD pieces travel in one block of eight loads (S <= 8); beyond that one piece per block
+  auto run = [&](auto spad_c) {
+    constexpr int SPAD = decltype(spad_c)::value, PP = 8 / SPAD;
+    for (int it0 = 0; it0 < NPIECE; it0 += PP) {
+      float4 sum[PP];
+      int pm[PP], pn[PP];
+#pragma unroll
+      for (int u = 0; u < PP; ++u) {
+        sum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pm[u] = -1;
+        pn[u] = 0;
+        if (it0 + u < NPIECE) {
+          const int c = tid + NT * (it0 + u);
+          const int row = c / CPR, col = (c % CPR) * 4;
+          const int m = map ? (*map)(row) : m0 + row;
+          const int n = n0 + col;
+          if (m >= 0 && m < p.M && n < p.N) { pm[u] = m; pn[u] = n; }
+        }
+      }
+      for (int s0 = 0; s0 < S; s0 += SPAD) {            // (more than one round only when S > 8, where PP == 1)
+        const float* q[8];
+        bool ok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int u = j / SPAD, sl = s0 + j % SPAD;
+          ok[j] = pm[u] >= 0 && sl < S;
+          q[j] = ok[j] ? p.slab + (size_t)sl * slice + (size_t)pm[u] * p.ldc + pn[u] : p.slab;
+        }
+        fx4 o[8];
+        ld_sc1_x4_8(q, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (!ok[j]) continue;
+          float4& a = sum[j / SPAD];                    // ascending j = ascending slice: a fixed order
+          a.x += o[j][0]; a.y += o[j][1]; a.z += o[j][2]; a.w += o[j][3];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PP; ++u)
+        if (pm[u] >= 0) finish_piece(pm[u], pn[u], sum[u]);
+    }
+  };
+  if (S <= 1) run(std::integral_constant<int, 1>{});
+  else if (S <= 2) run(std::integral_constant<int, 2>{});
+  else if (S <= 4) run(std::integral_constant<int, 4>{});
+  else run(std::integral_constant<int, 8>{});
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
