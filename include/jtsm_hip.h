@@ -53,6 +53,11 @@ int jtsm_event_record(void* event, void* stream);
 int jtsm_event_elapsed_ms(void* start, void* stop, float* ms);
 void jtsm_event_destroy(void* event);
 void jtsm_conv_set_mid_event(void* event);
+/* Split-K finishing of the bf16x3 / fp16 contractions: 1 = inside the contraction kernel (the tile's last-arriving K
+ * slice folds the slabs in slice order and runs the epilogue: sc1 write-through slab stores, sc1 loads, an agent-scope
+ * ticket, no device-scope fence), 0 = the separate splitk_finish pass, -1 = follow JTSM_SPLITK_FUSED (default: 1).
+ * Both give bit-identical results (same slice order, same epilogue arithmetic); the switch exists for tests / sweeps. */
+void jtsm_conv_set_splitk_fused(int mode);
 
 /* ---------------------------------------------------------------------------
  * ROIAlign — replaces detectron2/layers/csrc/ROIAlign/ROIAlign.h:7-27

@@ -31,6 +31,7 @@ def lib():
         _lib.jtsm_event_create.restype = C.c_void_p
         _lib.jtsm_event_destroy.restype = None
         _lib.jtsm_conv_set_mid_event.restype = None
+        _lib.jtsm_conv_set_splitk_fused.restype = None
         _lib.jtsm_moi_pool_workspace_bytes.restype = C.c_size_t
         for name in ("jtsm_mil_workspace_bytes", "jtsm_oicr_workspace_bytes", "jtsm_conv_workspace_bytes",
                      "jtsm_group_norm_workspace_bytes", "jtsm_semseg_ce_workspace_bytes",
@@ -52,7 +53,7 @@ def lib():
 TIMING = None
 _pending_bytes = None
 _UNTIMED = ("jtsm_event_", "jtsm_last_error", "jtsm_version", "jtsm_device_count", "jtsm_conv_set_mid_event",
-            "jtsm_conv_plan", "jtsm_conv_bf16x3_plan", "jtsm_conv_bf16x3_eligible", "jtsm_conv_out_size",
+            "jtsm_conv_set_splitk_fused", "jtsm_conv_plan", "jtsm_conv_bf16x3_plan", "jtsm_conv_bf16x3_eligible", "jtsm_conv_out_size",
             "jtsm_conv2d_")   # (the contractions carry their own, finer instrumentation: layers/conv.py LAUNCH_LOG)
 
 

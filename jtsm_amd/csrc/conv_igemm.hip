@@ -31,7 +31,9 @@
 // resnet.py:195-211, layers/batch_norm.py:45-66, layers/wrappers.py:62-83) in FWD, and
 // "sum the two gradient paths, then gate by the ReLU mask" in DGRAD.  WGRAD accumulates with
 // float atomics into a zero-filled dW (optionally scaled per output row).
+#include <atomic>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -374,6 +376,55 @@ __device__ __forceinline__ bool splitk_last_arrival(const Params& p, int* flag) 
   return *flag != 0;
 }
 
+// The last-arriving slice's work: thread-private float4 pieces k = 0 .. npiece-1 (piece_of(k, m, n) -> valid?), each
+// the sum of all gridDim.y slabs in slice order, handed to finish(m, n, sum).  Eight 16-byte loads travel together:
+// SPAD slices of 8 / SPAD pieces when there are at most eight slices, otherwise eight slices of one piece per round.
+template <class PIECE, class FIN>
+__device__ __forceinline__ void splitk_fold(const Params& p, int npiece, PIECE piece_of, FIN finish) {
+  const int S = (int)gridDim.y;
+  const size_t slice = (size_t)p.M * p.ldc;
+  auto run = [&](auto spad_c) {
+    constexpr int SPAD = decltype(spad_c)::value, PP = 8 / SPAD;
+    for (int it0 = 0; it0 < npiece; it0 += PP) {
+      float4 sum[PP];
+      int pm[PP], pn[PP];
+#pragma unroll
+      for (int u = 0; u < PP; ++u) {
+        sum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pm[u] = -1;
+        pn[u] = 0;
+        int m, n;
+        if (it0 + u < npiece && piece_of(it0 + u, m, n)) { pm[u] = m; pn[u] = n; }
+      }
+      for (int s0 = 0; s0 < S; s0 += SPAD) {            // (more than one round only when S > 8, where PP == 1)
+        const float* q[8];
+        bool ok[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int u = j / SPAD, sl = s0 + j % SPAD;
+          ok[j] = pm[u] >= 0 && sl < S;
+          q[j] = ok[j] ? p.slab + (size_t)sl * slice + (size_t)pm[u] * p.ldc + pn[u] : p.slab;
+        }
+        fx4 o[8];
+        ld_sc1_x4_8(q, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (!ok[j]) continue;
+          float4& acc4 = sum[j / SPAD];                 // ascending j = ascending slice: a fixed order
+          acc4.x += o[j][0]; acc4.y += o[j][1]; acc4.z += o[j][2]; acc4.w += o[j][3];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PP; ++u)
+        if (pm[u] >= 0) finish(pm[u], pn[u], sum[u]);
+    }
+  };
+  if (S <= 1) run(std::integral_constant<int, 1>{});
+  else if (S <= 2) run(std::integral_constant<int, 2>{});
+  else if (S <= 4) run(std::integral_constant<int, 4>{});
+  else run(std::integral_constant<int, 8>{});
+}
+
 template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256, class MAP = LinearRows>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                 int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */,
@@ -453,55 +504,14 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
   // ---- split-K finishing by the tile's last-arriving slice: every slab in slice order, then the epilogue
   __syncthreads();                                   // (the LDS window is free again)
   if (!splitk_last_arrival(p, reinterpret_cast<int*>(tile))) return;
-  const int S = (int)gridDim.y;
   constexpr int NPIECE = BM * CPR / NT;              // float4 pieces of the whole tile per thread
-  const size_t slice = (size_t)p.M * p.ldc;
-  // SPAD slices of PP = 8 / SPAD pieces travel in one block of eight loads (S <= 8); beyond that one piece per block
-  auto run = [&](auto spad_c) {
-    constexpr int SPAD = decltype(spad_c)::value, PP = 8 / SPAD;
-    for (int it0 = 0; it0 < NPIECE; it0 += PP) {
-      float4 sum[PP];
-      int pm[PP], pn[PP];
-#pragma unroll
-      for (int u = 0; u < PP; ++u) {
-        sum[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-        pm[u] = -1;
-        pn[u] = 0;
-        if (it0 + u < NPIECE) {
-          const int c = tid + NT * (it0 + u);
-          const int row = c / CPR, col = (c % CPR) * 4;
-          const int m = map ? (*map)(row) : m0 + row;
-          const int n = n0 + col;
-          if (m >= 0 && m < p.M && n < p.N) { pm[u] = m; pn[u] = n; }
-        }
-      }
-      for (int s0 = 0; s0 < S; s0 += SPAD) {            // (more than one round only when S > 8, where PP == 1)
-        const float* q[8];
-        bool ok[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int u = j / SPAD, sl = s0 + j % SPAD;
-          ok[j] = pm[u] >= 0 && sl < S;
-          q[j] = ok[j] ? p.slab + (size_t)sl * slice + (size_t)pm[u] * p.ldc + pn[u] : p.slab;
-        }
-        fx4 o[8];
-        ld_sc1_x4_8(q, o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (!ok[j]) continue;
-          float4& a = sum[j / SPAD];                    // ascending j = ascending slice: a fixed order
-          a.x += o[j][0]; a.y += o[j][1]; a.z += o[j][2]; a.w += o[j][3];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < PP; ++u)
-        if (pm[u] >= 0) finish_piece(pm[u], pn[u], sum[u]);
-    }
-  };
-  if (S <= 1) run(std::integral_constant<int, 1>{});
-  else if (S <= 2) run(std::integral_constant<int, 2>{});
-  else if (S <= 4) run(std::integral_constant<int, 4>{});
-  else run(std::integral_constant<int, 8>{});
+  splitk_fold(p, NPIECE, [&](int k, int& m, int& n) {
+    const int c = tid + NT * k;
+    const int row = c / CPR, col = (c % CPR) * 4;
+    m = map ? (*map)(row) : m0 + row;
+    n = n0 + col;
+    return m >= 0 && m < p.M && n < p.N;
+  }, finish_piece);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
@@ -1027,6 +1037,41 @@ inline void record_mid(hipStream_t st) {
   }
 }
 
+// Ticket counters of the in-kernel split-K finishing (Params::tickets): kTicketCap zero-initialised ints per
+// (device, stream) that has launched a split contraction — the finishing workgroup re-arms its counter, so the buffer
+// is cleared once, when it is created.  Two launches on the SAME stream run in order; different streams get their own.
+constexpr int kTicketCap = 4096;
+static std::atomic<int> g_splitk_fused_override{-1};   // jtsm_conv_set_splitk_fused: -1 = follow the environment
+inline bool splitk_fused_enabled() {
+  static const bool on = [] { const char* e = getenv("JTSM_SPLITK_FUSED"); return !e || atoi(e) != 0; }();
+  const int o = g_splitk_fused_override.load();
+  return o < 0 ? on : o != 0;
+}
+inline int* tickets_for(hipStream_t st) {
+  struct Slot { int dev; hipStream_t st; int* buf; };
+  static Slot slots[64];
+  static int nslots = 0;
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < nslots; ++i)
+    if (slots[i].dev == dev && slots[i].st == st) return slots[i].buf;
+  if (nslots == 64) return nullptr;
+  int* buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&buf), kTicketCap * sizeof(int)) != hipSuccess) return nullptr;
+  if (hipMemset(buf, 0, kTicketCap * sizeof(int)) != hipSuccess) { (void)hipFree(buf); return nullptr; }
+  slots[nslots++] = {dev, st, buf};
+  return buf;
+}
+// Decide how a split launch is finished: sets p.tickets (and returns true) when the kernel itself will do it.
+inline bool use_fused_finish(Params& p, int ntiles, int splits, hipStream_t st) {
+  p.tickets = nullptr;
+  if (splits <= 1 || !p.wide || ntiles > kTicketCap || !splitk_fused_enabled()) return false;
+  p.tickets = tickets_for(st);
+  return p.tickets != nullptr;
+}
+
 inline int finish_split(const Params& p, int splits, hipStream_t st, int scale_by_row = 0) {
   const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
                    (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
@@ -1472,14 +1517,16 @@ static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, cons
   p.ktiles_per_split = ceil_div(ceil_div(p.K, XBK), splits);
   p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   p.wide = 1;   // N = taps * in_c is a multiple of 8, dw / slab 16-byte aligned
-  if (x3_wgrad_halo(p)) {
+  const bool halo = x3_wgrad_halo(p);
+  const bool fused = use_fused_finish(p, halo ? ceil_div(p.M, 128) * (p.s.Cin / 32) : ntiles, splits, st);
+  if (halo) {
     const int halo_tiles = ceil_div(p.M, 128) * (p.s.Cin / 32);
     hipLaunchKernelGGL(igemm_x3_wgrad_halo_kernel<NP>, dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
   } else if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2, NP>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
   else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2, NP>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
   record_mid(st);
-  if (splits > 1) return finish_split(p, splits, st, 1);
+  if (splits > 1 && !fused) return finish_split(p, splits, st, 1);
   return JTSM_OK;
 }
 
@@ -1623,5 +1670,7 @@ int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, 
 }
 
 void jtsm_conv_set_mid_event(void* event) { g_mid_event = reinterpret_cast<hipEvent_t>(event); }
+
+void jtsm_conv_set_splitk_fused(int mode) { g_splitk_fused_override.store(mode < 0 ? -1 : (mode ? 1 : 0)); }
 
 }  // extern "C"

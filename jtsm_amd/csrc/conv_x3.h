@@ -802,7 +802,11 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m >= p.M) continue;
       float v = acc[t][r];
-      if (gridDim.y > 1) { p.slab[((size_t)blockIdx.y * p.M + m) * p.ldc + n] = v; continue; }
+      if (gridDim.y > 1) {
+        float* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n;
+        if (p.tickets) st_sc1(dst, v); else *dst = v;
+        continue;
+      }
       const size_t o = (size_t)m * p.ldc + n;
       v *= pow2i(-p.in_shift);
       if (e.scale) v *= e.scale[m];
@@ -810,6 +814,27 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       p.C[o] = v;
     }
   }
+  if (!(gridDim.y > 1 && p.tickets)) return;
+  // split-K finishing by the tile's last-arriving slice (conv_igemm.hip: splitk_fold): 128 rows x nine 32-column runs
+  __syncthreads();
+  if (!splitk_last_arrival(p, reinterpret_cast<int*>(lds))) return;
+  constexpr int NPIECE = 128 * TAPS * 8 / 256;          // float4 pieces per thread
+  splitk_fold(p, NPIECE, [&](int k, int& m, int& n) {
+    const int c = tid + 256 * k;                        // (row, tap, 4-column group): the group is fastest
+    const int grp = c & 7, tp = (c >> 3) % TAPS, row = c / (8 * TAPS);
+    m = m0 + row;
+    n = tp * s.Cin + ci0 + 4 * grp;
+    return m < p.M;
+  }, [&](int m, int n, float4 v) {
+    const size_t o = (size_t)m * p.ldc + n;
+    const float a = pow2i(-p.in_shift) * (e.scale ? e.scale[m] : 1.f);
+    v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+    if (e.residual) {
+      const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
+      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+    }
+    *reinterpret_cast<float4*>(p.C + o) = v;
+  });
 }
 
 // ---- the splitting pre-passes ---------------------------------------------------------------------
@@ -1000,6 +1025,7 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
+  const bool fused = use_fused_finish(p, ntiles, splits, st);
   if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
     // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
     // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
@@ -1008,7 +1034,7 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2, NP>), grid, dim3(NT), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3");
   record_mid(st);
-  if (splits > 1) return finish_split(p, splits, st);
+  if (splits > 1 && !fused) return finish_split(p, splits, st);
   return JTSM_OK;
 }
 
@@ -1066,11 +1092,12 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
+  const bool fused = use_fused_finish(p, ntiles, splits, st);
   if (BIG) hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 16, 4, 2, 4, 21, NP>), grid, dim3(512), 0, st, p, q);
   else hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 8, 2, 2, 2, 12, NP>), grid, dim3(256), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3 halo");
   record_mid(st);
-  if (splits > 1) return finish_split(p, splits, st);
+  if (splits > 1 && !fused) return finish_split(p, splits, st);
   return JTSM_OK;
 }
 

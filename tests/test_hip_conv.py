@@ -352,3 +352,41 @@ def test_full_size_adjointness(cuda, shape):
     # and the forward is linear in x
     y2 = K.conv2d_forward(x * 0.5, w, s, p, 1)
     assert float((y2 - 0.5 * y).abs().max()) <= REL * float(y.abs().max())
+
+
+def test_splitk_finishing_inside_the_kernel_is_bit_identical_to_the_separate_pass(cuda, conv_math):
+    """Split-K layers (few output tiles, long K) finished by the tile's last-arriving slice — slabs published with sc1
+    stores, read back with sc1 loads, an agent-scope ticket, no device-scope fence — must give the very bits of the
+    separate splitk_finish pass (same slice order, same epilogue).  Forward / data gradient / weight gradient (generic,
+    LDS-halo and 256x256-tile forms), repeated: a lost or stale slab would show up as a differing element."""
+    if conv_math == "f32":
+        pytest.skip("the exact-fp32 kernels keep the separate finishing pass")
+    from jtsm_amd import _lib as L
+    gen = torch.Generator(device=cuda).manual_seed(12)
+    cases = [(2, 256, 32, 32, 256, 3, 1, 1),     # 3x3 halo forms (few tiles at 32x32, split over channel blocks)
+             (2, 1024, 16, 16, 256, 1, 1, 0),    # 1x1, K = 1024: 128x128 tiles, split
+             (2, 512, 16, 16, 2048, 1, 1, 0),    # wide output
+             (1, 256, 64, 64, 256, 3, 1, 1),     # wgrad halo with many pixel slices
+             (2, 2048, 8, 8, 512, 1, 1, 0)]
+    lib = L.lib()
+    try:
+        for (n, c, h, w, o, k, s, p) in cases:
+            x = torch.randn(n, c, h, w, device=cuda, generator=gen).contiguous(memory_format=CL)
+            wt = (torch.randn(o, c, k, k, device=cuda, generator=gen) * 0.05).contiguous(memory_format=CL)
+            sc, bi = torch.rand(o, device=cuda, generator=gen) + 0.5, torch.randn(o, device=cuda, generator=gen)
+            outs = {}
+            for mode in (0, 1, 1, 1):
+                lib.jtsm_conv_set_splitk_fused(mode)
+                K.planes_clear()
+                y = K.conv2d_forward(x, wt, s, p, 1, sc, bi, None, True, emit_planes=True)
+                dy = torch.randn(y.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3)).contiguous(memory_format=CL)
+                dx = K.conv2d_backward_data(dy, wt, tuple(x.shape), s, p, 1, kscale=sc, relu_mask=x)
+                dw = K.conv2d_backward_weight(dy, x, tuple(wt.shape), s, p, 1, row_scale=sc)
+                got = (y, dx, dw, K.planes_of(y).clone())
+                if mode == 0:
+                    outs = got
+                else:
+                    for a, b, what in zip(got, outs, ("y", "dx", "dw", "planes of y")):
+                        assert torch.equal(a, b), ((n, c, h, w, o, k), what, float((a.float() - b.float()).abs().max()))
+    finally:
+        lib.jtsm_conv_set_splitk_fused(-1)
