@@ -411,7 +411,8 @@ __device__ __forceinline__ void splitk_fold(const Params& p, int npiece, PIECE p
         for (int j = 0; j < 8; ++j) {
           if (!ok[j]) continue;
           float4& acc4 = sum[j / SPAD];                 // ascending j = ascending slice: a fixed order
-          acc4.x += o[j][0]; acc4.y += o[j][1]; acc4.z += o[j][2]; acc4.w += o[j][3];
+          acc4.x = __fadd_rn(acc4.x, o[j][0]); acc4.y = __fadd_rn(acc4.y, o[j][1]);
+          acc4.z = __fadd_rn(acc4.z, o[j][2]); acc4.w = __fadd_rn(acc4.w, o[j][3]);
         }
       }
 #pragma unroll
@@ -446,18 +447,23 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
     }
     if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
     if (ROLE == WGRAD) {
-      if (e.scale) { const float sc = e.scale[m]; v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; }
+      if (e.scale) {
+        const float sc = e.scale[m];
+        v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
+      }
     } else if (e.scale) {
       const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
-      v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+      v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
     }
+    // (every step individually rounded — no FMA contraction — so that the direct epilogue, the in-kernel split-K
+    // finishing and the separate splitk_finish pass produce the same bits)
     if (e.bias) {
       const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
-      v.x += bi.x; v.y += bi.y; v.z += bi.z; v.w += bi.w;
+      v.x = __fadd_rn(v.x, bi.x); v.y = __fadd_rn(v.y, bi.y); v.z = __fadd_rn(v.z, bi.z); v.w = __fadd_rn(v.w, bi.w);
     }
     if (e.residual) {
       const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
-      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      v.x = __fadd_rn(v.x, rr.x); v.y = __fadd_rn(v.y, rr.y); v.z = __fadd_rn(v.z, rr.z); v.w = __fadd_rn(v.w, rr.w);
     }
     if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (e.mask) {
@@ -986,7 +992,8 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
       const float* src = p.slab + ((size_t)s * p.M + m) * p.ldc + n;
       if (VEC == 4) {
         const float4 t = *reinterpret_cast<const float4*>(src);
-        v[0] += t.x; v[1 % VEC] += t.y; v[2 % VEC] += t.z; v[3 % VEC] += t.w;
+        v[0] = __fadd_rn(v[0], t.x); v[1 % VEC] = __fadd_rn(v[1 % VEC], t.y);
+        v[2 % VEC] = __fadd_rn(v[2 % VEC], t.z); v[3 % VEC] = __fadd_rn(v[3 % VEC], t.w);
       } else {
         v[0] += src[0];
       }
@@ -1000,8 +1007,10 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
-      float x = v[j] * alpha * (e.scale ? e.scale[scale_by_row ? m : n + j] : 1.f) + (e.bias ? e.bias[n + j] : 0.f);
-      if (e.residual) x += e.residual[o + j];
+      float x = v[j] * alpha;                                   // (a power of two: exact)
+      if (e.scale) x = __fmul_rn(x, e.scale[scale_by_row ? m : n + j]);
+      if (e.bias) x = __fadd_rn(x, e.bias[n + j]);
+      if (e.residual) x = __fadd_rn(x, e.residual[o + j]);
       if (e.relu) x = fmaxf(x, 0.f);
       if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
       v[j] = x;

@@ -827,11 +827,15 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
     return m < p.M;
   }, [&](int m, int n, float4 v) {
     const size_t o = (size_t)m * p.ldc + n;
-    const float a = pow2i(-p.in_shift) * (e.scale ? e.scale[m] : 1.f);
+    const float a = pow2i(-p.in_shift);                 // exact
     v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+    if (e.scale) {
+      const float sc = e.scale[m];
+      v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
+    }
     if (e.residual) {
       const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
-      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      v.x = __fadd_rn(v.x, rr.x); v.y = __fadd_rn(v.y, rr.y); v.z = __fadd_rn(v.z, rr.z); v.w = __fadd_rn(v.w, rr.w);
     }
     *reinterpret_cast<float4*>(p.C + o) = v;
   });
