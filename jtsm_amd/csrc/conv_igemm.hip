@@ -1052,7 +1052,10 @@ inline void record_mid(hipStream_t st) {
 constexpr int kTicketCap = 4096;
 static std::atomic<int> g_splitk_fused_override{-1};   // jtsm_conv_set_splitk_fused: -1 = follow the environment
 inline bool splitk_fused_enabled() {
-  static const bool on = [] { const char* e = getenv("JTSM_SPLITK_FUSED"); return !e || atoi(e) != 0; }();
+  // default OFF: measured on MI355X (round 2, bench.py 20 steps): 44.2 ms/step fused against 30.5 ms with the separate
+  // pass — write-through slab stores and bypassing loads put the ~6 GB/step of slab traffic on HBM, where the
+  // write-back path keeps it in L2 / Infinity Cache until splitk_finish has read it.  Kept as a measured alternative.
+  static const bool on = [] { const char* e = getenv("JTSM_SPLITK_FUSED"); return e && atoi(e) != 0; }();
   const int o = g_splitk_fused_override.load();
   return o < 0 ? on : o != 0;
 }
