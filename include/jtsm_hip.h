@@ -340,6 +340,35 @@ int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, fl
 int jtsm_conv2d_backward_weight_f16(const uint16_t* dy_h, const uint16_t* x_h, float* dw, const jtsm_conv_shape* s,
                                     const float* row_scale, int zero_dw, int grad_shift, void* workspace,
                                     size_t workspace_bytes, void* stream);
+/* ---- ConvTranspose2d(kernel 2, stride 2, padding 0, bias) — the mask heads' upsampler
+ * (detectron2/modeling/roi_heads/mask_head.py:245-252 `deconv`; projects/WSL/wsl/modeling/roi_heads/mask_head.py:303-305;
+ * ATen conv_transpose2d behind detectron2/layers/wrappers.py `ConvTranspose2d = torch.nn.ConvTranspose2d`).
+ * Tensors are NHWC: x (batch, h, w, in_c), y (batch, 2h, 2w, out_c); the weight is the parameter (in_c, out_c, 2, 2)
+ * in channels_last memory order [in_c][dy][dx][out_c].  in_c % 32 == 0, out_c % 32 == 0.
+ *   forward        y[b,2i+dy,2j+dx,o] = relu?(bias[o] + sum_c x[b,i,j,c] W[c][dy][dx][o]) — one GEMM whose epilogue
+ *                  writes straight to the four output pixels.  wt_* = planes of W^T as
+ *                  jtsm_split_bf16_transposed_f32(W, null, .., out_c = in_c, taps = 1, in_c = 4*out_c) makes them;
+ *                  y_hi / y_lo (nullable pair): planes of y for the next contraction.
+ *   backward_data  dx[b,i,j,c] = sum_{dy,dx,o} g[b,2i+dy,2j+dx,o] W[c][dy][dx][o], kept where relu_mask > 0 (nullable:
+ *                  the ReLU output x came from) — the forward role of the 2x2/stride-2 convolution whose OHWI weight is
+ *                  the same memory: w_* = plain planes of W (jtsm_split_bf16_f32); dx_hi / dx_lo nullable pair;
+ *                  workspace: jtsm_conv_transpose2x2_workspace_bytes (may be null: no K split).
+ *   backward_weight: jtsm_conv2d_backward_weight_bf16x3 with shape {batch, 2h, 2w, in_c = out_c, out_c = in_c, 2, 2,
+ *                  stride 2, pad 0}, dy planes = x's, x planes = g's: dW comes out in the parameter's memory order.
+ * The _f16 forms take one fp16 plane per operand; g's plane carries 2^grad_shift as in jtsm_conv2d_backward_data_f16. */
+int jtsm_conv_transpose2x2_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* wt_hi,
+                                          const uint16_t* wt_lo, float* y, uint16_t* y_hi, uint16_t* y_lo, int batch,
+                                          int h, int w, int in_c, int out_c, const float* bias, int relu, void* stream);
+int jtsm_conv_transpose2x2_forward_f16(const uint16_t* x_h, const uint16_t* wt_h, float* y, uint16_t* y_h, int batch,
+                                       int h, int w, int in_c, int out_c, const float* bias, int relu, void* stream);
+size_t jtsm_conv_transpose2x2_workspace_bytes(int batch, int h, int w, int in_c, int out_c);
+int jtsm_conv_transpose2x2_backward_data_bf16x3(const uint16_t* g_hi, const uint16_t* g_lo, const uint16_t* w_hi,
+                                                const uint16_t* w_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                                int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
+                                                void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_conv_transpose2x2_backward_data_f16(const uint16_t* g_h, const uint16_t* w_h, float* dx, uint16_t* dx_h,
+                                             int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
+                                             int grad_shift, void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */
 int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
                                  void* stream);
@@ -356,8 +385,8 @@ int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, vo
 /* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);
 /* The same without atomics (bitwise reproducible) and ~4x faster on large inputs: row slabs are summed into
- * `workspace` (jtsm_channel_sum_workspace_bytes, 16-byte aligned) and folded in slab order.  Falls back to the form
- * above for narrow matrices (C < 128 or C % 4 != 0), short ones, or a workspace that is too small. */
+ * `workspace` (jtsm_channel_sum_workspace_bytes, 16-byte aligned) and folded in slab order, for any C and any
+ * number of rows.  Falls back to the (atomic) form above only when the workspace is missing or too small. */
 size_t jtsm_channel_sum_workspace_bytes(long rows, int C);
 int jtsm_channel_sum_ws_f32(const float* g, float* out, long rows, int C, void* workspace, size_t workspace_bytes,
                             void* stream);

@@ -33,7 +33,7 @@ def lib():
         _lib.jtsm_conv_set_mid_event.restype = None
         _lib.jtsm_conv_set_splitk_fused.restype = None
         _lib.jtsm_moi_pool_workspace_bytes.restype = C.c_size_t
-        for name in ("jtsm_mil_workspace_bytes", "jtsm_oicr_workspace_bytes", "jtsm_conv_workspace_bytes",
+        for name in ("jtsm_mil_workspace_bytes", "jtsm_oicr_workspace_bytes", "jtsm_conv_workspace_bytes", "jtsm_conv_transpose2x2_workspace_bytes",
                      "jtsm_group_norm_workspace_bytes", "jtsm_semseg_ce_workspace_bytes",
                      "jtsm_conv_bf16x3_wgrad_workspace_bytes", "jtsm_moi_pool_levels_workspace_bytes",
                      "jtsm_paint_sem_seg_workspace_bytes", "jtsm_mask_bce_workspace_bytes",

@@ -81,6 +81,9 @@ struct Params {
   // counter per output tile (blockIdx.x): a workgroup publishes its slab with write-through stores and takes a ticket;
   // the last of a tile's gridDim.y slices adds all slabs in slice order and runs the epilogue.
   int* tickets;
+  // FWD as the GEMM of a 2x2 / stride-2 transposed convolution: row m = input pixel (b, y, x), column n = (dy, dx, c)
+  // with c < shuffle_c; the result lands at output pixel (b, 2y + dy, 2x + dx), channel c (bias indexed by c).
+  int shuffle_c, shuffle_h, shuffle_w;
   ConvShape s;
   Epilogue e;
 };
@@ -363,13 +366,13 @@ __device__ __forceinline__ void ld_sc1_8(const float* const (&q)[8], float (&o)[
 
 // After a workgroup's slab is written: true in exactly one workgroup of each tile — the last of its gridDim.y slices
 // (which also re-arms the counter for the next launch).  `flag` is one int of LDS.
-__device__ __forceinline__ bool splitk_last_arrival(const Params& p, int* flag) {
+__device__ __forceinline__ bool splitk_last_arrival(const Params& p, int* flag, int tile_id) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's slab stores are acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
-    const int old = __hip_atomic_fetch_add(p.tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int old = __hip_atomic_fetch_add(p.tickets + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = old == (int)gridDim.y - 1;
-    if (last) __hip_atomic_store(p.tickets + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (last) __hip_atomic_store(p.tickets + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *flag = last;
   }
   __syncthreads();
@@ -429,7 +432,10 @@ __device__ __forceinline__ void splitk_fold(const Params& p, int npiece, PIECE p
 template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256, class MAP = LinearRows>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                 int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */,
-                                                const MAP* map = nullptr) {
+                                                const MAP* map = nullptr, int split = -1, int tile_id = -1) {
+  // (split, tile_id): this workgroup's K slice and tile when the kernel does not take them from blockIdx.y / .x
+  if (split < 0) split = blockIdx.y;
+  if (tile_id < 0) tile_id = blockIdx.x;
   // PASSES > 1: the tile goes through a smaller LDS window in row bands of BM / PASSES (single-buffered kernels)
   constexpr int ROWS = BM / PASSES;
   static_assert(ROWS % (32 * TM) == 0, "a band holds whole wave tiles");
@@ -445,6 +451,14 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
       const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
       o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
     }
+    int nb = n;   // column of the per-column epilogue operands
+    if (ROLE == FWD && p.shuffle_c) {
+      const int ph = n / p.shuffle_c;
+      nb = n - ph * p.shuffle_c;
+      const int x = m % p.shuffle_w, t = m / p.shuffle_w;
+      const int y = t % p.shuffle_h, b = t / p.shuffle_h;
+      o = (((size_t)(b * 2 * p.shuffle_h + 2 * y + (ph >> 1)) * (2 * p.shuffle_w)) + 2 * x + (ph & 1)) * p.shuffle_c + nb;
+    }
     if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
     if (ROLE == WGRAD) {
       if (e.scale) {
@@ -452,13 +466,13 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
         v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
       }
     } else if (e.scale) {
-      const float4 sc = *reinterpret_cast<const float4*>(e.scale + n);
+      const float4 sc = *reinterpret_cast<const float4*>(e.scale + nb);
       v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
     }
     // (every step individually rounded — no FMA contraction — so that the direct epilogue, the in-kernel split-K
     // finishing and the separate splitk_finish pass produce the same bits)
     if (e.bias) {
-      const float4 bi = *reinterpret_cast<const float4*>(e.bias + n);
+      const float4 bi = *reinterpret_cast<const float4*>(e.bias + nb);
       v.x = __fadd_rn(v.x, bi.x); v.y = __fadd_rn(v.y, bi.y); v.z = __fadd_rn(v.z, bi.z); v.w = __fadd_rn(v.w, bi.w);
     }
     if (e.residual) {
@@ -498,7 +512,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
       if (m < 0 || m >= p.M || n >= p.N) continue;
       float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
       if (raw) {
-        float* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n;
+        float* dst = p.slab + ((size_t)split * p.M + m) * p.ldc + n;
         if (p.tickets) st_sc1_x4(dst, v);
         else *reinterpret_cast<float4*>(dst) = v;
         continue;
@@ -509,7 +523,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
   if (!(raw && p.tickets)) return;
   // ---- split-K finishing by the tile's last-arriving slice: every slab in slice order, then the epilogue
   __syncthreads();                                   // (the LDS window is free again)
-  if (!splitk_last_arrival(p, reinterpret_cast<int*>(tile))) return;
+  if (!splitk_last_arrival(p, reinterpret_cast<int*>(tile), tile_id)) return;
   constexpr int NPIECE = BM * CPR / NT;              // float4 pieces of the whole tile per thread
   splitk_fold(p, NPIECE, [&](int k, int& m, int& n) {
     const int c = tid + NT * k;
@@ -1352,12 +1366,19 @@ int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role) {
 }  // extern "C"
 
 // NP = 2: split-bf16 planes (hi, lo).  NP = 1: one fp16 plane (the *_lo arguments are null).
+// What the transposed-convolution entry points add to a forward-role launch.
+struct FwdExtras {
+  const float* mask = nullptr;   // keep the result where mask > 0 (a ReLU gate), as in the data-gradient role
+  int in_shift = 0, out_shift = 0;
+  int shuffle_c = 0, shuffle_h = 0, shuffle_w = 0;   // Params::shuffle_*
+};
+
 template <int NP>
 static int x3_forward(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
                       const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,
                       const jtsm_conv_shape* s, const float* scale, const float* bias,
                       const float* residual, int relu, void* workspace, size_t workspace_bytes,
-                      void* stream) {
+                      void* stream, const FwdExtras& ex = FwdExtras()) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1376,6 +1397,14 @@ static int x3_forward(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t
                 reinterpret_cast<const __bf16*>(w_hi), reinterpret_cast<const __bf16*>(w_lo)};
   p.C = y; p.ldc = p.N;
   p.e.scale = scale; p.e.bias = bias; p.e.residual = residual; p.e.relu = relu;
+  p.e.mask = ex.mask; p.in_shift = ex.in_shift; p.out_shift = ex.out_shift;
+  p.shuffle_c = ex.shuffle_c; p.shuffle_h = ex.shuffle_h; p.shuffle_w = ex.shuffle_w;
+  JTSM_REQUIRE(!ex.mask || aligned16(ex.mask), "conv forward bf16x3: the gate must be 16-byte aligned");
+  if (ex.shuffle_c) {   // only the wide epilogue knows the pixel-shuffle map, and a K split's finishing pass does not
+    JTSM_REQUIRE(p.N == 4 * ex.shuffle_c && ex.shuffle_c % 4 == 0 && aligned16(y) && (!bias || aligned16(bias)) &&
+                 !scale && !residual && !ex.mask, "conv_transpose2x2 forward: out_c %% 4 == 0 and 16-byte aligned tensors");
+    workspace = nullptr;
+  }
   JTSM_REQUIRE(NP == 1 || (y_hi == nullptr) == (y_lo == nullptr), "conv forward bf16x3: give both output planes or neither");
   if (y_hi) {
     JTSM_REQUIRE(p.N % 4 == 0 && aligned16(y) && aligned16(y_hi) && aligned16(y_lo) &&
@@ -1576,6 +1605,74 @@ int jtsm_conv2d_forward_f16(const uint16_t* x_h, const uint16_t* w_h, float* y, 
                             void* stream) {
   return x3_forward<1>(x_h, nullptr, w_h, nullptr, y, y_h, nullptr, s, scale, bias, residual, relu, workspace,
                        workspace_bytes, stream);
+}
+
+// ---- ConvTranspose2d(kernel 2, stride 2, padding 0): the mask heads' upsampler -----------------------------------
+// Weight = the parameter's channels_last memory, [in][dy][dx][out].  Forward is ONE GEMM of (B*H*W) x (4*out) whose
+// epilogue writes each row's four 'out'-wide column groups to the four output pixels (no pixel-shuffle copy);
+// its B operand [4*out][in] is the transposing split of that memory seen as a 1x1 weight (out_c = in, in_c = 4*out).
+// Backward-data is the FORWARD role of the 2x2 / stride-2 convolution whose OHWI weight is the same memory.
+static jtsm_conv_shape ct_gemm_shape(int batch, int h, int w, int in_c, int out_c) {
+  jtsm_conv_shape g = {};
+  g.batch = batch; g.in_h = h; g.in_w = w; g.in_c = in_c; g.out_c = 4 * out_c;
+  g.kernel_h = g.kernel_w = 1; g.stride = 1; g.pad = 0; g.dilation = 1;
+  return g;
+}
+static jtsm_conv_shape ct_conv_shape(int batch, int h, int w, int in_c, int out_c) {
+  jtsm_conv_shape g = {};   // the convolution that the transposed convolution is the data gradient of
+  g.batch = batch; g.in_h = 2 * h; g.in_w = 2 * w; g.in_c = out_c; g.out_c = in_c;
+  g.kernel_h = g.kernel_w = 2; g.stride = 2; g.pad = 0; g.dilation = 1;
+  return g;
+}
+#define JTSM_CT_DIMS_OK(what)                                                                                    \
+  JTSM_REQUIRE(batch >= 0 && h > 0 && w > 0 && in_c > 0 && out_c > 0 && in_c % 32 == 0 && out_c % 32 == 0 &&      \
+               (long)batch * h * w * 4 * (long)(in_c > out_c ? in_c : out_c) < (1L << 31),                       \
+               what ": needs in_c %% 32 == 0, out_c %% 32 == 0 and fewer than 2^31 elements per tensor")
+
+int jtsm_conv_transpose2x2_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* wt_hi,
+                                          const uint16_t* wt_lo, float* y, uint16_t* y_hi, uint16_t* y_lo, int batch,
+                                          int h, int w, int in_c, int out_c, const float* bias, int relu, void* stream) {
+  JTSM_CT_DIMS_OK("conv_transpose2x2 forward");
+  const jtsm_conv_shape g = ct_gemm_shape(batch, h, w, in_c, out_c);
+  FwdExtras ex; ex.shuffle_c = out_c; ex.shuffle_h = h; ex.shuffle_w = w;
+  return x3_forward<2>(x_hi, x_lo, wt_hi, wt_lo, y, y_hi, y_lo, &g, nullptr, bias, nullptr, relu, nullptr, 0, stream, ex);
+}
+
+int jtsm_conv_transpose2x2_forward_f16(const uint16_t* x_h, const uint16_t* wt_h, float* y, uint16_t* y_h, int batch,
+                                       int h, int w, int in_c, int out_c, const float* bias, int relu, void* stream) {
+  JTSM_CT_DIMS_OK("conv_transpose2x2 forward");
+  const jtsm_conv_shape g = ct_gemm_shape(batch, h, w, in_c, out_c);
+  FwdExtras ex; ex.shuffle_c = out_c; ex.shuffle_h = h; ex.shuffle_w = w;
+  return x3_forward<1>(x_h, nullptr, wt_h, nullptr, y, y_h, nullptr, &g, nullptr, bias, nullptr, relu, nullptr, 0, stream,
+                       ex);
+}
+
+size_t jtsm_conv_transpose2x2_workspace_bytes(int batch, int h, int w, int in_c, int out_c) {
+  if (batch <= 0 || h <= 0 || w <= 0 || in_c <= 0 || out_c <= 0) return 0;
+  const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
+  return jtsm_conv_workspace_bytes(&g, 0);
+}
+
+int jtsm_conv_transpose2x2_backward_data_bf16x3(const uint16_t* g_hi, const uint16_t* g_lo, const uint16_t* w_hi,
+                                                const uint16_t* w_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                                int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_CT_DIMS_OK("conv_transpose2x2 backward-data");
+  const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
+  FwdExtras ex; ex.mask = relu_mask;
+  return x3_forward<2>(g_hi, g_lo, w_hi, w_lo, dx, dx_hi, dx_lo, &g, nullptr, nullptr, nullptr, 0, workspace,
+                       workspace_bytes, stream, ex);
+}
+
+int jtsm_conv_transpose2x2_backward_data_f16(const uint16_t* g_h, const uint16_t* w_h, float* dx, uint16_t* dx_h,
+                                             int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
+                                             int grad_shift, void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_CT_DIMS_OK("conv_transpose2x2 backward-data");
+  JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv_transpose2x2 backward-data f16: grad_shift must be in 0..24");
+  const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
+  FwdExtras ex; ex.mask = relu_mask; ex.in_shift = grad_shift; ex.out_shift = grad_shift;
+  return x3_forward<1>(g_h, nullptr, w_h, nullptr, dx, dx_h, nullptr, &g, nullptr, nullptr, nullptr, 0, workspace,
+                       workspace_bytes, stream, ex);
 }
 
 int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,

@@ -41,6 +41,20 @@ constexpr int x3_passes(int kbytes, int BM, int BN, int TM) {
   return kbytes >= BM * BN * 4 ? 1 : (kbytes >= BM * BN * 2 ? 2 : (((BM / 4) % (32 * TM) == 0 && kbytes >= BM * BN) ? 4 : 2));
 }
 
+// (tile, K slice) of this workgroup in a tiles x slices grid, chosen so that the workgroups sharing an XCD (those
+// with equal dispatch index % 8, MI355X_MICROARCH.md "Workgroup dispatch") hold a CONTIGUOUS run of the slice-major
+// work list: the tiles of one K slice read the same operand rows, and now find them in the XCD's own L2 instead of
+// eight L2s each fetching them from the fabric.  A speed choice only: any placement gives the same result.
+__device__ __forceinline__ void xcd_slice_major(int ntiles, int& tile, int& split) {
+  const int total = gridDim.x * gridDim.y;
+  const int id = blockIdx.y * gridDim.x + blockIdx.x;
+  const int xcd = id % 8, idx = id / 8;
+  const int qq = total / 8, r = total % 8;
+  const int w = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+  split = w / ntiles;
+  tile = w - split * ntiles;
+}
+
 struct X3Planes {
   const __bf16* A_hi; const __bf16* A_lo;
   const __bf16* B_hi; const __bf16* B_lo;
@@ -90,14 +104,25 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
   }
   const int ntile_k = kbeg < kend ? (kend - kbeg + XBK - 1) / XBK : 0;
 
-  // ---- addressing state: the tap and first channel of a stage are wave-uniform and advance incrementally
+  // ---- addressing state: the tap and first channel of a stage are wave-uniform and advance incrementally.
+  // K ORDER of a k x k layer: channel block outer, taps inner (any order sums to the same product).  With the taps
+  // outermost a workgroup came back to its activation rows only after a whole pass over the channels — 256 KiB per
+  // workgroup, ~8 MB per XCD, twice its L2: measured 641 MB of fabric traffic per launch for 134 MB of operands on
+  // the mask heads' 3x3 layers.  Now the nine taps of one 32-channel block follow each other: 32 KiB per workgroup.
+  // (Eligibility guarantees whole stages per tap when there is more than one tap.)
   const int Cdim = ROLE == FWD ? s.Cin : s.Cout;
+  const int taps = s.KH * s.KW;
+  const bool perm = taps > 1;
+  const int klim = perm ? p.K : kend;       // permuted stages are always whole: only the slice's stage range bounds them
   int t_kh, t_kw, t_c;
-  {
-    const int tap = kbeg / Cdim;
-    t_c = kbeg - tap * Cdim;
+  if (perm) {
+    const int sidx = kbeg / XBK, cb = sidx / taps, tap = sidx - cb * taps;
+    t_c = cb * XBK;
     t_kh = tap / s.KW;
     t_kw = tap - t_kh * s.KW;
+  } else {
+    t_c = kbeg;
+    t_kh = t_kw = 0;
   }
   // Per-row state: element offset of (row, tap (0,0), this lane's chunk) and one validity bit per kh and per
   // kw (zero padding, rows past M) — so a stage costs one add, two shifts and a select per load instead of
@@ -136,8 +161,9 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
   // One direct-to-LDS load ("piece") of the next stage: pieces 0 .. 2*A_INS-1 are the A rows (hi, lo
   // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups.
   constexpr int PIECES = NP * (A_INS + B_INS);
-  auto issue_piece = [&](int idx, int k0, int buf) {
+  auto issue_piece = [&](int idx, int buf) {
     char* St = lds + buf * STAGE;
+    const int k0 = (t_kh * s.KW + t_kw) * Cdim + t_c;   // first k of the stage the state points at (wave-uniform)
     if (idx < NP * A_INS) {
       const int j = idx / NP, lo = idx % NP;
       bool ok;
@@ -145,13 +171,13 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
       if (linear) {
         const int tap_delta = ROLE == FWD ? ((t_kh * s.dil) * s.W + t_kw * s.dil) * s.Cin + t_c
                                           : -((t_kh * s.dil) * s.Wo + t_kw * s.dil) * s.Cout + t_c;
-        ok = ((a_mh[j] >> t_kh) & (a_mw[j] >> t_kw) & 1u) != 0u && (k0 + a_chunk[j]) < kend;
+        ok = ((a_mh[j] >> t_kh) & (a_mw[j] >> t_kw) & 1u) != 0u && (k0 + a_chunk[j]) < klim;
         off = a_base[j] + tap_delta;
       } else {
         const PixelRow& r = arow[j];
         const int th = r.h0 - t_kh * s.dil, tw = r.w0 - t_kw * s.dil;
         const int oh = th / s.stride, ow = tw / s.stride;
-        ok = r.ok && (k0 + a_chunk[j]) < kend && th >= 0 && tw >= 0 && oh * s.stride == th && ow * s.stride == tw &&
+        ok = r.ok && (k0 + a_chunk[j]) < klim && th >= 0 && tw >= 0 && oh * s.stride == th && ow * s.stride == tw &&
              oh < s.Ho && ow < s.Wo;
         off = ((r.b * s.Ho + oh) * s.Wo + ow) * s.Cout + t_c + a_chunk[j];
       }
@@ -159,21 +185,24 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
       dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + lo * A_PL + (wave * A_INS + j) * 1024);
     } else {
       const int j = (idx - NP * A_INS) / NP, lo = (idx - NP * A_INS) % NP;
-      const bool ok = b_off[j] >= 0 && (k0 + b_chunk[j]) < kend;
+      const bool ok = b_off[j] >= 0 && (k0 + b_chunk[j]) < klim;
       const __bf16* src = q.B_hi + (b_off[j] + k0 + b_chunk[j]) + (lo ? lo_delta_b : 0);
       dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + NP * A_PL + lo * B_PL + (wave * B_INS + j) * 1024);
     }
   };
-  auto advance_tap = [&]() {   // next stage: same tap or the next one (stages never straddle taps)
-    t_c += XBK;
-    if (t_c >= Cdim) {
-      t_c -= Cdim;
-      if (++t_kw == s.KW) { t_kw = 0; ++t_kh; }
+  auto advance_tap = [&]() {   // next stage: the next tap of this channel block, then the next block
+    if (perm) {
+      if (++t_kw == s.KW) {
+        t_kw = 0;
+        if (++t_kh == s.KH) { t_kh = 0; t_c += XBK; }
+      }
+    } else {
+      t_c += XBK;
     }
   };
-  auto issue = [&](int k0, int buf) {
+  auto issue = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) issue_piece(i, k0, buf);
+    for (int i = 0; i < PIECES; ++i) issue_piece(i, buf);
     advance_tap();
   };
 
@@ -201,16 +230,16 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
 
   constexpr int SLOTS = 2 * TM * TN;                        // MFMA groups per stage (2 k-steps x TM x TN tiles)
   constexpr int PER_SLOT = (PIECES + SLOTS - 1) / SLOTS;    // loads placed behind each group
-  if (NBUF == 2 && ntile_k > 0) issue(kbeg, 0);
+  if (NBUF == 2 && ntile_k > 0) issue(0);
   for (int t = 0; t < ntile_k; ++t) {
     if (NBUF == 1) {
       __syncthreads();
-      issue(kbeg + t * XBK, 0);
+      issue(0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const bool more = NBUF == 2 && t + 1 < ntile_k;   // wave-uniform
-    const int knext = kbeg + (t + 1) * XBK, bnext = (t + 1) & 1;
+    const int bnext = (t + 1) & 1;
     const char* St = lds + (NBUF == 2 ? (t & 1) : 0) * STAGE;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
@@ -238,7 +267,7 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
             if (more) {
 #pragma unroll
               for (int e = 0; e < PER_SLOT; ++e)
-                if (slot * PER_SLOT + e < PIECES) issue_piece(slot * PER_SLOT + e, knext, bnext);
+                if (slot * PER_SLOT + e < PIECES) issue_piece(slot * PER_SLOT + e, bnext);
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the load behind this MFMA group
           }
@@ -508,16 +537,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
 
   const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
   const int ntiles = ntn * ntm;
-  int tile = blockIdx.x;
-  {
-    const int qq = ntiles / 8, r = ntiles % 8, xcd = tile % 8, idx = tile / 8;
-    tile = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
-  }
+  // all tiles of a pixel slice on one XCD: they read the same dY / X rows (the mask heads' 3x3 layers: 9 tiles x 28
+  // slices measured 679 MB of fabric traffic per launch for 152 MB of operands with the slices dealt over the XCDs)
+  int tile, split;
+  xcd_slice_major(ntiles, tile, split);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
   int kbeg = 0, kend = p.K;
   if (gridDim.y > 1) {
-    kbeg = blockIdx.y * p.ktiles_per_split * XBK;
+    kbeg = split * p.ktiles_per_split * XBK;
     kend = min(p.K, kbeg + p.ktiles_per_split * XBK);
     if (kbeg >= kend && !p.wide) return;   // (slab path: an empty slice still writes its zero slab)
   }
@@ -661,7 +689,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
   }
   static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
   if (p.wide)
-    store_tile_wide<WGRAD, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
+    store_tile_wide<WGRAD, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds),
+                                                       (const LinearRows*)nullptr, split, tile);
   else
     store_tile<WGRAD, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -817,7 +846,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
   if (!(gridDim.y > 1 && p.tickets)) return;
   // split-K finishing by the tile's last-arriving slice (conv_igemm.hip: splitk_fold): 128 rows x nine 32-column runs
   __syncthreads();
-  if (!splitk_last_arrival(p, reinterpret_cast<int*>(lds))) return;
+  if (!splitk_last_arrival(p, reinterpret_cast<int*>(lds), blockIdx.x)) return;
   constexpr int NPIECE = 128 * TAPS * 8 / 256;          // float4 pieces per thread
   splitk_fold(p, NPIECE, [&](int k, int& m, int& n) {
     const int c = tid + 256 * k;                        // (row, tap, 4-column group): the group is fastest

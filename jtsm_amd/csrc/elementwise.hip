@@ -119,6 +119,28 @@ __global__ __launch_bounds__(256) void channel_sum4_kernel(const float4* __restr
                                                      (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
   }
 }
+// Any C (not a multiple of 4, narrower than 128, few rows): `cols` <= 256 columns per workgroup, 256 / cols row groups
+// striding the slab's rows, partial sums to part[slab][C] — the same fixed-order scheme, so bias gradients are
+// reproducible whatever the layer's width (the atomic form above is kept for callers without a workspace).
+__global__ __launch_bounds__(256) void channel_sum_slab_kernel(const float* __restrict__ g, float* __restrict__ part,
+                                                               long rows, int C, long rows_per_block, int cols) {
+  __shared__ float red[256];
+  const int rpi = 256 / cols, tid = threadIdx.x;
+  const int cl = tid % cols, rg = tid / cols;
+  const int c = blockIdx.x * cols + cl;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc = 0.f;
+  if (rg < rpi && c < C)
+    for (long r = r0 + rg; r < r1; r += rpi) acc += g[r * C + c];
+  red[tid] = acc;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float t = 0.f;
+    for (int k = 0; k < rpi; ++k) t += red[k * cols + cl];
+    part[(size_t)blockIdx.y * C + c] = t;
+  }
+}
 // out[c] = sum_s part[s][c], slabs in a fixed order: a workgroup folds 16 channels, 16 threads per channel each
 // taking every 16th slab, then the 16 partial sums are added in order.
 __global__ __launch_bounds__(256) void channel_sum_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -439,8 +461,9 @@ int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint
   return JTSM_OK;
 }
 
+static bool csum_wide(long rows, int C) { return C % 4 == 0 && C >= 128 && rows >= 256; }
 static void csum_plan(long rows, int C, long* rpb, int* nslab) {
-  const int cg = ceil_div(C / 4, 64);
+  const int cg = csum_wide(rows, C) ? ceil_div(C / 4, 64) : ceil_div(C, C < 256 ? C : 256);
   long slabs = 1024 / cg;            // ~4 workgroups per CU in all
   if (slabs < 1) slabs = 1;
   if (slabs > (rows + 63) / 64) slabs = (rows + 63) / 64;
@@ -450,7 +473,7 @@ static void csum_plan(long rows, int C, long* rpb, int* nslab) {
 }
 
 size_t jtsm_channel_sum_workspace_bytes(long rows, int C) {
-  if (rows <= 0 || C <= 0 || C % 4) return 0;
+  if (rows <= 0 || C <= 0) return 0;
   long rpb; int nslab;
   csum_plan(rows, C, &rpb, &nslab);
   return (size_t)nslab * C * sizeof(float) + 16;
@@ -461,15 +484,21 @@ int jtsm_channel_sum_ws_f32(const float* g, float* out, long rows, int C, void* 
   JTSM_REQUIRE(rows >= 0 && C > 0, "channel_sum: bad sizes");
   JTSM_REQUIRE(out, "channel_sum: null out");
   hipStream_t st = as_stream(stream);
-  const bool wide = C % 4 == 0 && C >= 128 && ((uintptr_t)g & 15) == 0 && rows >= 256 && workspace &&
-                    ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= jtsm_channel_sum_workspace_bytes(rows, C);
-  if (!wide) return jtsm_channel_sum_f32(g, out, rows, C, stream);
+  const bool have_ws = workspace && ((uintptr_t)workspace & 15) == 0 && rows > 0 &&
+                       workspace_bytes >= jtsm_channel_sum_workspace_bytes(rows, C);
+  if (!have_ws) return jtsm_channel_sum_f32(g, out, rows, C, stream);
   JTSM_REQUIRE(g, "channel_sum: null pointer");
   long rpb; int nslab;
   csum_plan(rows, C, &rpb, &nslab);
   float* part = reinterpret_cast<float*>(workspace);
-  hipLaunchKernelGGL(channel_sum4_kernel, dim3(ceil_div(C / 4, 64), (unsigned)nslab), dim3(256), 0, st,
-                     reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(part), rows, C / 4, rpb);
+  if (csum_wide(rows, C) && ((uintptr_t)g & 15) == 0) {
+    hipLaunchKernelGGL(channel_sum4_kernel, dim3(ceil_div(C / 4, 64), (unsigned)nslab), dim3(256), 0, st,
+                       reinterpret_cast<const float4*>(g), reinterpret_cast<float4*>(part), rows, C / 4, rpb);
+  } else {
+    const int cols = C < 256 ? C : 256;
+    hipLaunchKernelGGL(channel_sum_slab_kernel, dim3(ceil_div(C, cols), (unsigned)nslab), dim3(256), 0, st, g, part,
+                       rows, C, rpb, cols);
+  }
   hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
   JTSM_CHECK_LAUNCH("channel_sum");
   return JTSM_OK;

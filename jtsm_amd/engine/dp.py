@@ -63,15 +63,18 @@ class GradientExchange(object):
     (no collective; gradients still land in the flat buckets), which is how the single-process tests exercise the
     slot / hook machinery."""
 
-    def __init__(self, model, device=None, collective=None, group=None):
+    def __init__(self, model, device=None, collective=None, group=None, force_collectives=False):
+        """force_collectives: issue the collectives even in a one-rank group (they are then copies) — how the GPU
+        suite drives the RCCL calls and the side-stream ordering on a single device."""
         self.model, self.group = model, group
-        self.world = dist.get_world_size(group) if _active() else 1
+        self.force = bool(force_collectives) and dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if (_active() or self.force) else 1
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("GradientExchange: the model has no trainable parameter")
         self.device = device if device is not None else named[0][1].device
         self.cuda = self.device.type == "cuda"
-        backend = dist.get_backend(group) if self.world > 1 else None
+        backend = dist.get_backend(group) if (self.world > 1 or self.force) else None
         if collective is None:
             collective = os.environ.get("JTSM_DP_COLLECTIVE", "rs_ag" if backend == "nccl" else "allreduce")
         if collective not in ("rs_ag", "allreduce"):
@@ -108,7 +111,8 @@ class GradientExchange(object):
                 conv.GRAD_SLOTS[(p.data_ptr(), p.numel())] = view
                 p.register_post_accumulate_grad_hook(self._hook)
             self.buckets.append(b)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.cuda and self.world > 1) else None
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.cuda and (self.world > 1 or self.force)) \
+            else None
         self._in_backward = False
         self.bytes = 4 * sum(b.numel for b in self.buckets)
 
@@ -127,7 +131,7 @@ class GradientExchange(object):
             self._launch(b)
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if self.comm_stream is None:     # CPU tensors (gloo)
             dist.all_reduce(b.flat, group=self.group)

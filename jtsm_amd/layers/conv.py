@@ -565,6 +565,120 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
     return out
 
 
+# ---- ConvTranspose2d(kernel 2, stride 2, padding 0): the mask heads' upsampler -----------------------------------
+def conv_transpose2x2_ok(x, w):
+    """The native path: planes arithmetic, channels_last (in, out, 2, 2) weight, 32-channel multiples."""
+    return (MATH != "f32" and w.dim() == 4 and tuple(w.shape[2:]) == (2, 2) and w.shape[0] % 32 == 0 and
+            w.shape[1] % 32 == 0 and w.permute(0, 2, 3, 1).is_contiguous() and x.shape[0] > 0)
+
+
+def _ct_desc(n, h, w, i, o):
+    elems = n * h * w * (i + 4 * o) + 4 * i * o
+    return (n, h, w, i, 4 * o, 1, 1, 4.0 * elems)
+
+
+def conv_transpose2x2_forward(x, w, bias=None, relu=False, emit_planes=False):
+    """y (N, out, 2H, 2W) channels_last = relu?(conv_transpose2d(x, w, stride 2) + bias): one GEMM of (N*H*W) x
+    (4*out) whose epilogue writes each row's four column groups to the four output pixels."""
+    _check(x, w, bias)
+    x = _cl(x)
+    n, i, h, wd = x.shape
+    o = w.shape[1]
+    y = torch.empty((n, o, 2 * h, 2 * wd), dtype=x.dtype, device=x.device, memory_format=CL)
+    xh, xl = _hl(planes_of(x))
+    w1 = w.as_strided((i, 4 * o, 1, 1), (4 * o, 1, 1, 1))       # the same memory as a 1x1 weight: [in][(dy,dx,out)]
+    wth, wtl = _hl(_weight_planes(w1, True))
+    ybuf = _planes_buf(y.numel(), y.device) if emit_planes else None
+    yh, yl = _hl(ybuf)
+    lib = L.lib()
+    flops = 2.0 * n * h * wd * i * 4 * o
+    var = _x3_variant(_plan((n, i, h, wd), (4 * o, i, 1, 1), 1, 0, 1).s, 0)
+    var = _Variant(str(var), 1) if var is not None else None      # (the pixel-shuffle epilogue never splits K)
+    if MATH == "f16":
+        L.check(_timed(var, flops, lambda: lib.jtsm_conv_transpose2x2_forward_f16(
+            xh, wth, L.ptr(y), yh, n, h, wd, i, o, L.ptr(bias), int(bool(relu)), L.stream()),
+            _ct_desc(n, h, wd, i, o), 0, y.numel(), ybuf is not None), "conv_transpose2x2_forward_f16")
+    else:
+        L.check(_timed(var, flops, lambda: lib.jtsm_conv_transpose2x2_forward_bf16x3(
+            xh, xl, wth, wtl, L.ptr(y), yh, yl, n, h, wd, i, o, L.ptr(bias), int(bool(relu)), L.stream()),
+            _ct_desc(n, h, wd, i, o), 0, y.numel(), ybuf is not None), "conv_transpose2x2_forward_bf16x3")
+    if ybuf is not None:
+        planes_put(y, ybuf)
+    return y
+
+
+def conv_transpose2x2_backward_data(g, w, relu_mask=None, emit_planes=False):
+    """dx (N, in, H, W) of conv_transpose2x2_forward, kept where relu_mask > 0: the forward role of the 2x2 / stride-2
+    convolution whose OHWI weight is the parameter's memory."""
+    _check(g, w, relu_mask)
+    g = _cl(g)
+    n, o, h2, w2 = g.shape
+    i = w.shape[0]
+    h, wd = h2 // 2, w2 // 2
+    pl = _plan(g.shape, (i, o, 2, 2), 2, 0, 1)
+    dx = torch.empty((n, i, h, wd), dtype=g.dtype, device=g.device, memory_format=CL)
+    if relu_mask is not None:
+        relu_mask = _cl(relu_mask)
+        assert relu_mask.shape == dx.shape
+    gh, gl = _hl(planes_of(g, grad=True))
+    wh, wl = _hl(_weight_planes(w))
+    dbuf = _planes_buf(dx.numel(), dx.device) if emit_planes else None
+    dh, dl = _hl(dbuf)
+    nbytes = pl.ws[0]
+    ws = _scratch(nbytes, g.device)
+    lib = L.lib()
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_f16(
+            gh, wh, L.ptr(dx), dh, n, h, wd, i, o, L.ptr(relu_mask), GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, _numel(relu_mask), dx.numel(), dbuf is not None), "conv_transpose2x2_backward_data_f16")
+    else:
+        L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_bf16x3(
+            gh, gl, wh, wl, L.ptr(dx), dh, dl, n, h, wd, i, o, L.ptr(relu_mask), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, _numel(relu_mask), dx.numel(), dbuf is not None),
+                "conv_transpose2x2_backward_data_bf16x3")
+    if dbuf is not None:
+        planes_put(dx, dbuf)
+    return dx
+
+
+def conv_transpose2x2_backward_weight(g, x, w):
+    """dW in the parameter's own (channels_last) memory: the weight gradient of that 2x2 / stride-2 convolution with
+    the roles swapped — its 'dy' is x, its input is g."""
+    i, o = w.shape[0], w.shape[1]
+    if MATH == "f16":   # exactly one operand may carry 2^GRAD_SHIFT: g's planes do, so x's must be plain
+        planes_of(x)
+        planes_of(g, grad=True)
+    return conv2d_backward_weight(x, g, (i, o, 2, 2), 2, 0, 1, w=w)
+
+
+class _ConvTranspose2x2(Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, relu):
+        y = conv_transpose2x2_forward(x, w, bias, relu, emit_planes=True)
+        ctx.relu = relu
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        from .elementwise import channel_sum, relu_backward
+        x, w, y = ctx.saved_tensors
+        g = relu_backward(dy, y, emit_planes=True) if ctx.relu else _cl(dy)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv_transpose2x2_backward_data(g, w)
+        if ctx.needs_input_grad[1]:
+            dw = conv_transpose2x2_backward_weight(g, x, w)
+        if ctx.needs_input_grad[2]:
+            db = channel_sum(g)
+        return dx, dw, db, None
+
+
+def conv_transpose2x2_fused(x, w, bias=None, relu=False):
+    return _ConvTranspose2x2.apply(x, w, bias, relu)
+
+
 class _ConvFused(Function):
     """y = relu?(conv(x, w) * scale + bias + residual); scale/bias are constants of the op
     (FrozenBN statistics or a conv bias treated by the caller), residual gets dy * relu'."""

@@ -8,6 +8,8 @@ sits between two contractions —
     * the sum of the two gradient paths into the block input (`accumulate`): no autograd add.
 Per block that removes two elementwise passes over the bottleneck activations and one over the block input.
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -19,6 +21,7 @@ CL = torch.channels_last
 # False: residual blocks run layer by layer (the same kernels, one autograd node per convolution) — used by the
 # frozen-gates parity test, whose forward hooks need every convolution's output
 ENABLED = True
+MASK_TOWER = os.environ.get("JTSM_MASK_TOWER", "1") != "0"   # (A/B switch for the mask-head node alone)
 
 
 def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=None, emit_planes=False):
@@ -87,3 +90,93 @@ def bottleneck_fused(x, w1, sb1, w2, sb2, w3, sb3, ws, sbs, stride1, stride2, pa
     ss, bs = sbs if sbs is not None else (None, None)
     return _BottleneckFn.apply(x, w1, sb1[0], sb1[1], w2, sb2[0], sb2[1], w3, sb3[0], sb3[1], ws, ss, bs,
                                stride1, stride2, pad2, dil2, stride_s)
+
+
+class _MaskTowerFn(Function):
+    """The mask head's layers (detectron2/modeling/roi_heads/mask_head.py:201-290; WSL variant
+    projects/WSL/wsl/modeling/roi_heads/mask_head.py:266-343) as ONE autograd node: k x [conv3x3 + bias + ReLU],
+    ConvTranspose2d(2, stride 2) + bias + ReLU, the 1x1 predictor.  As with the bottleneck, the point is the backward:
+    every ReLU gate between two contractions rides in the epilogue of the data-gradient launch that produces the
+    gradient (`relu_mask`), which also emits the gated gradient's planes — no relu_backward pass, no plane split —
+    and the transposed convolution never materialises a pixel-shuffled copy (layers/conv.py: conv_transpose2x2_*).
+
+    apply(x, w_1, b_1, ..., w_k, b_k, w_deconv, b_deconv, w_pred, b_pred) -> (logits, upsampled features)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        k = (len(params) - 4) // 2
+        hs = [x]
+        for j in range(k):
+            hs.append(K.conv2d_forward(hs[-1], params[2 * j], 1, 1, 1, None, params[2 * j + 1], None, True,
+                                       emit_planes=True))
+        wd, bd, wp, bp = params[2 * k:]
+        u = K.conv_transpose2x2_forward(hs[-1], wd, bd, True, emit_planes=True)
+        logits = K.conv2d_forward(u, wp, 1, 0, 1, None, bp, None, False)
+        ctx.k = k
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(u, *hs, *params[0:2 * k:2], wd, wp)
+        return logits, u
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dlogits, du):
+        from .elementwise import channel_sum
+
+        k = ctx.k
+        saved = ctx.saved_tensors
+        u, hs, ws, wd, wp = saved[0], saved[1:k + 2], saved[k + 2:2 * k + 2], saved[2 * k + 2], saved[2 * k + 3]
+        need = ctx.needs_input_grad
+        grads = [None] * (1 + 2 * k + 4)
+        if dlogits is None and du is None:
+            return tuple(grads)
+        # ---- predictor; its data gradient lands gated by the upsampler's ReLU, with planes
+        if dlogits is not None:
+            gl = dlogits.contiguous(memory_format=CL)
+            if need[2 * k + 3]:
+                grads[2 * k + 3] = _same_strides(K.conv2d_backward_weight(gl, u, tuple(wp.shape), 1, 0, 1, w=wp), wp)
+            if need[2 * k + 4]:
+                grads[2 * k + 4] = channel_sum(gl)
+            gu = K.conv2d_backward_data(gl, wp, tuple(u.shape), 1, 0, 1, accumulate=du, relu_mask=u, emit_planes=True)
+        else:
+            gu = relu_backward(du, u, emit_planes=True)
+        # ---- transposed convolution
+        if need[2 * k + 1]:
+            grads[2 * k + 1] = K.conv_transpose2x2_backward_weight(gu, hs[k], wd)
+        if need[2 * k + 2]:
+            grads[2 * k + 2] = channel_sum(gu)
+        g = K.conv_transpose2x2_backward_data(gu, wd, relu_mask=hs[k] if k > 0 else None, emit_planes=True)
+        # ---- the 3x3 tower, last layer first
+        for j in range(k - 1, -1, -1):
+            w = ws[j]
+            if need[1 + 2 * j]:
+                grads[1 + 2 * j] = K.conv2d_backward_weight(g, hs[j], tuple(w.shape), 1, 1, 1, w=w)
+            if need[2 + 2 * j]:
+                grads[2 + 2 * j] = channel_sum(g)
+            if j > 0 or need[0]:
+                g = K.conv2d_backward_data(g, w, tuple(hs[j].shape), 1, 1, 1, relu_mask=hs[j] if j > 0 else None,
+                                           emit_planes=j > 0)
+        if need[0]:
+            grads[0] = g
+        return tuple(grads)
+
+
+def mask_tower_ok(x, convs, deconv, predictor):
+    """Can the fused node take these layers?  (Plane arithmetic, 3x3/s1/p1 biased convolutions, the native
+    transposed convolution, a predictor whose width the 16-byte epilogue can write.)"""
+    if not (ENABLED and MASK_TOWER and K.MATH != "f32" and x.is_cuda and x.shape[0] > 0 and x.dtype == torch.float32):
+        return False
+    for c in convs:
+        if c.kernel_size != (3, 3) or c.stride != (1, 1) or c.padding != (1, 1) or c.dilation != (1, 1) or \
+                c.bias is None or c.norm is not None or c.in_channels % 32 or c.out_channels % 32:
+            return False
+    if deconv.bias is None or not K.conv_transpose2x2_ok(x, deconv.weight):
+        return False
+    return predictor.kernel_size == (1, 1) and predictor.out_channels % 8 == 0 and predictor.bias is not None and \
+        predictor.norm is None and predictor.activation is None
+
+
+def mask_tower_fused(x, convs, deconv, predictor):
+    params = []
+    for c in convs:
+        params += [c.weight, c.bias]
+    return _MaskTowerFn.apply(x, *params, deconv.weight, deconv.bias, predictor.weight, predictor.bias)

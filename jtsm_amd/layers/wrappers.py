@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from .batch_norm import FrozenBatchNorm2d
-from .conv import conv2d_fused, linear_fused
+from .conv import conv2d_fused, conv_transpose2x2_fused, conv_transpose2x2_ok, linear_fused
 
 CL = torch.channels_last
 
@@ -93,15 +93,25 @@ class Linear(nn.Linear):
 
 class ConvTranspose2d(nn.ConvTranspose2d):
     """kernel 2, stride 2, padding 0 only (the mask head's upsampler, mask_head.py:303-305): each of
-    the 4 output phases is a 1x1 convolution, so the layer is ONE GEMM with 4*out columns followed
-    by a pixel shuffle."""
+    the 4 output phases is a 1x1 convolution, so the layer is ONE GEMM with 4*out columns whose epilogue
+    does the pixel shuffle (exact-fp32 arithmetic: the GEMM, then a shuffle copy)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        # (in, kh, kw, out) storage: what the kernels read; the logical shape stays (in, out, kh, kw)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
 
     def forward(self, x, relu=False):
         if self.kernel_size != (2, 2) or self.stride != (2, 2) or self.padding != (0, 0):
             raise NotImplementedError("jtsm_amd ConvTranspose2d: kernel=stride=2, padding=0 only")
+        if x.is_cuda and conv_transpose2x2_ok(x, self.weight):
+            # the GEMM's epilogue writes the four output pixels of every input pixel itself; the backward is the
+            # forward / weight-gradient role of the 2x2 stride-2 convolution this layer transposes (layers/conv.py)
+            return conv_transpose2x2_fused(x, self.weight, self.bias, relu)
         n, c, h, w = x.shape
         o = self.out_channels
-        wl = self.weight.permute(2, 3, 1, 0).reshape(4 * o, c)            # [(dy,dx,o)][i]
+        wl = self.weight.permute(2, 3, 1, 0).reshape(4 * o, c).contiguous()   # [(dy,dx,o)][i] (a copy: the parameter
+        # is stored (in, kh, kw, out))
         b = self.bias.repeat(4) if self.bias is not None else None
         rows = x.permute(0, 2, 3, 1).reshape(n * h * w, c)                # NHWC rows (view when channels_last)
         z = linear_fused(rows, wl, b, relu, b is not None)                # (n*h*w, 4*o)

@@ -2,12 +2,15 @@
 :266-343 (MaskRCNNConvUpsampleWSLHead, whose `layers` returns logits AND the upsampled features).
 
 4 x [conv3x3 + ReLU] and the 1x1 predictor are MFMA launches with bias/ReLU in the epilogue; the
-2x2/stride-2 ConvTranspose is one GEMM + pixel shuffle (jtsm_amd/layers/wrappers.py)."""
+2x2/stride-2 ConvTranspose is one GEMM whose epilogue does the pixel shuffle; in the default arithmetic the whole
+tower is ONE autograd node whose backward keeps the ReLU gates in the data-gradient epilogues
+(jtsm_amd/layers/fused_blocks.py: _MaskTowerFn)."""
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ...layers.shape_spec import ShapeSpec
+from ...layers.fused_blocks import mask_tower_fused, mask_tower_ok
 from ...layers.wrappers import Conv2d, ConvTranspose2d, cat
 from ...layers.postprocess import mask_probs
 from ...layers.wsl_losses import mask_bce_loss
@@ -75,6 +78,8 @@ class MaskRCNNConvUpsampleWSLHead(nn.Module):
         nn.init.constant_(self.predictor.bias, 0)
 
     def layers(self, x):
+        if mask_tower_ok(x, self.conv_norm_relus, self.deconv, self.predictor):
+            return mask_tower_fused(x, self.conv_norm_relus, self.deconv, self.predictor)   # one autograd node
         for layer in self.conv_norm_relus:
             x = layer(x)
         x = self.deconv(x, relu=True)

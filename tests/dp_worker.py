@@ -5,7 +5,9 @@
 WORLD > 1: ranks share GPU 0 and talk over gloo (RCCL refuses two ranks on one device; the exchange code path —
 buckets, kernel-side gradient slots, hooks, side stream, end-of-backward callback — is the one bench.py runs).
 WORLD == 0 (the reference computation): a single process runs BOTH shards, averages the two gradients itself and takes
-the same optimizer step.  Saves {name: parameter after the step} to OUTDIR/rank{RANK}.pt."""
+the same optimizer step.  WORLD == 1: ONE rank over the real RCCL backend ("nccl") with the collectives forced — on a
+single device this is how reduce_scatter_tensor(AVG) / all_gather_into_tensor, the side stream and the event ordering
+of the exchange are driven through RCCL itself; WORLD == -1 is its reference (the same shard, no exchange).  Saves the parameters before (`init`) and after (`params`) the step to OUTDIR/rank{RANK}.pt."""
 import os
 import sys
 
@@ -50,7 +52,26 @@ def main():
     torch.cuda.set_device(0)
     model = build(device)
     opt = optimizer(model)
-    if world > 1:
+    init = {n: p.detach().cpu().clone() for n, p in model.named_parameters() if p.requires_grad}
+    if world == 1:
+        import torch.distributed as dist
+        from jtsm_amd.engine import dp
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+        ex = dp.GradientExchange(model, device, collective or "rs_ag", force_collectives=True)
+        assert ex.comm_stream is not None and ex.collective == (collective or "rs_ag")
+        for _ in range(2):     # twice: the end-of-backward callback re-arms the buckets
+            model.zero_grad(set_to_none=True)
+            losses = model(shard(0, device))
+            sum(losses.values()).backward()
+        for p in ex._slot:
+            assert p.grad is not None and p.grad.data_ptr() == ex._slot[p][1].data_ptr()
+        info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes}
+    elif world == -1:
+        losses = model(shard(0, device))
+        sum(losses.values()).backward()
+        info = {}
+    elif world > 1:
         os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
         from jtsm_amd.engine import dp
         dp.init_distributed("gloo", device)
@@ -77,9 +98,10 @@ def main():
     opt.step()
     torch.cuda.synchronize()
     state = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
-    torch.save({"params": state, "info": info}, os.path.join(out, "rank%d.pt" % rank))
+    torch.save({"params": state, "init": init, "info": info}, os.path.join(out, "rank%d.pt" % rank))
     if world > 1:
         torch.distributed.barrier()
+    if world >= 1:
         torch.distributed.destroy_process_group()
 
 

@@ -202,6 +202,13 @@ def test_relu_backward_and_channel_sum(cuda):
     close(channel_sum(dy), dy.sum((0, 2, 3)), "channel_sum")
     m = torch.randn(1000, 133, generator=g).to(cuda)
     close(channel_sum(m), m.sum(0), "channel_sum 2d")
+    # every width / height class of the slab scheme (narrow, not a multiple of 4, wider than a workgroup, few rows,
+    # the float4 form), each reproducible bit for bit: bias gradients carry no atomics
+    for rows, ch in ((5000, 56), (70000, 80), (37, 256), (300, 1027), (4096, 256), (1, 8), (129, 2048)):
+        m = torch.randn(rows, ch, generator=g).to(cuda)
+        a = channel_sum(m)
+        close(a, m.double().sum(0), "channel_sum %dx%d" % (rows, ch))
+        assert torch.equal(a, channel_sum(m)) and torch.equal(a, channel_sum(m.clone()))
 
 
 def test_spatial_helpers_match_torch(cuda):
@@ -325,6 +332,81 @@ def test_empty_batch_through_conv_linear_and_mask_head(cuda):
     y = K.linear_fused(torch.zeros(0, 12, device=cuda), w, None, True, False)
     y.sum().backward()
     assert y.shape == (0, 8) and float(w.grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_transpose_2x2_matches_torch(cuda, relu):
+    """ConvTranspose2d(kernel 2, stride 2) (+ ReLU) — the mask heads' upsampler — against torch's conv_transpose2d in
+    fp64 on the CPU: output, input gradient, weight gradient (in the parameter's own channels_last strides) and bias
+    gradient.  In the plane arithmetics this is the GEMM with the pixel-shuffle epilogue and the 2x2/stride-2
+    convolution roles (layers/conv.py: conv_transpose2x2_*); in exact fp32 the GEMM + shuffle copy."""
+    from jtsm_amd.layers.wrappers import ConvTranspose2d
+
+    g = torch.Generator().manual_seed(5)
+    n, ci, co, h, w = 7, 64, 96, 14, 14
+    layer = ConvTranspose2d(ci, co, kernel_size=2, stride=2, padding=0)
+    with torch.no_grad():
+        layer.weight.copy_(torch.randn(ci, co, 2, 2, generator=g) * 0.1)
+        layer.bias.copy_(torch.randn(co, generator=g) * 0.3)
+    x0 = torch.randn(n, ci, h, w, generator=g)
+    dy0 = torch.randn(n, co, 2 * h, 2 * w, generator=g)
+    xr = x0.double().requires_grad_()
+    wr, br = layer.weight.detach().double().requires_grad_(), layer.bias.detach().double().requires_grad_()
+    yr = torch.nn.functional.conv_transpose2d(xr, wr, br, stride=2)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(dy0.double())
+
+    layer = layer.to(cuda)
+    assert layer.weight.permute(0, 2, 3, 1).is_contiguous()      # (in, kh, kw, out) storage
+    x = x0.to(cuda).contiguous(memory_format=CL).requires_grad_()
+    y = layer(x, relu=relu)
+    assert y.shape == (n, co, 2 * h, 2 * w) and y.permute(0, 2, 3, 1).is_contiguous()
+    y.backward(dy0.to(cuda).contiguous(memory_format=CL))
+    if K.MATH != "f32":
+        assert type(y.grad_fn).__name__ == "_ConvTranspose2x2Backward"
+    close(y, yr, "conv_transpose y", chain=relu)
+    close(x.grad, xr.grad, "conv_transpose dx", chain=relu)
+    close(layer.weight.grad, wr.grad, "conv_transpose dw", chain=relu)
+    close(layer.bias.grad, br.grad, "conv_transpose db", chain=relu)
+    assert layer.weight.grad.stride() == layer.weight.stride()
+
+
+def test_mask_tower_as_one_node_matches_layer_by_layer(cuda):
+    """The mask head's layers as one autograd node (ReLU gates in the data-gradient epilogues, planes handed from
+    launch to launch) against the same head run layer by layer: logits and every gradient.  Same kernels and the same
+    summation orders, so the bar is the arithmetic's own (1e-4 relative; fp16: relative L2, gates may flip)."""
+    from jtsm_amd.layers import fused_blocks
+    from jtsm_amd.layers.shape_spec import ShapeSpec
+    from jtsm_amd.modeling.roi_heads.mask_head import MaskRCNNConvUpsampleWSLHead
+
+    torch.manual_seed(3)
+    head = MaskRCNNConvUpsampleWSLHead(ShapeSpec(channels=64, height=14, width=14), num_classes=8,
+                                       conv_dims=[64, 64, 64]).to(cuda)
+    with torch.no_grad():
+        for p in head.parameters():
+            if p.dim() == 1:
+                p.normal_(0, 0.2)
+        head.predictor.weight.normal_(0, 0.1)
+    x0 = torch.randn(9, 64, 14, 14, device=cuda).contiguous(memory_format=CL)
+    dl = torch.randn(9, 8, 28, 28, device=cuda).contiguous(memory_format=CL)
+    out = {}
+    for fused in (False, True):
+        fused_blocks.ENABLED = fused
+        try:
+            K.planes_clear()
+            head.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            logits, up = head.layers(x)
+            if K.MATH != "f32":
+                assert (type(logits.grad_fn).__name__ == "_MaskTowerFnBackward") == fused
+            logits.backward(dl)
+            out[fused] = [logits.detach(), up.detach(), x.grad] + [p.grad.clone() for p in head.parameters()]
+        finally:
+            fused_blocks.ENABLED = True
+    names = ["logits", "upsampled", "dx"] + [n for n, _ in head.named_parameters()]
+    for n, a, b in zip(names, out[True], out[False]):
+        close(a, b, "mask tower " + n, chain=True)
 
 
 @pytest.mark.parametrize("shape", [

@@ -40,23 +40,49 @@ def test_two_ranks_real_model_step_is_mean_of_means(cuda, tmp_path):
     assert _run([0, 0, 0, ref_dir]).wait(timeout=900) == 0
     r0 = torch.load(os.path.join(out, "rank0.pt"))
     r1 = torch.load(os.path.join(out, "rank1.pt"))
-    ref = torch.load(os.path.join(ref_dir, "rank0.pt"))["params"]
+    refd = torch.load(os.path.join(ref_dir, "rank0.pt"))
+    ref, init = refd["params"], refd["init"]
     assert r0["info"]["loss"] != r1["info"]["loss"]                       # different shards
     assert len(r0["info"]["buckets"]) == 5 and r0["info"]["bytes"] >= 300e6    # heads, FPN, res5, res4, res3: 301 MB
     assert set(r0["params"]) == set(r1["params"]) == set(ref)
     # identical on both ranks, bit for bit: same averaged gradient, same update
     for n in ref:
         assert torch.equal(r0["params"][n], r1["params"][n]), n
-    # and equal to the single-process mean-of-means step.  The initial weights are known (seed 0), so compare the
-    # UPDATES; gradients carry the float atomics of the pooling backward, hence a tolerance
-    torch.manual_seed(0)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+        assert torch.equal(r0["init"][n], init[n]), n                      # (all three processes start from seed 0)
+    # and equal to the single-process mean-of-means step: compare the UPDATES (parameter after - before).  Two runs
+    # of the same backward differ by the float atomics of the pooling backward kernels, and a bias gradient is a sum
+    # over all pixels with heavy cancellation (measured run-to-run: up to 1e-3 of the update on the coarse FPN levels),
+    # so the bar is a relative L2 error of 2e-3 and a max-norm error of 1e-2 per parameter — a wrong reduction (sum for
+    # mean, a missed bucket, one rank's gradient only) is an O(1) error.
     worst = {}
     for n in ref:
         if n.endswith("box_predictor.det.bias"):
             continue   # its gradient is exactly zero in exact arithmetic (softmax over the bag): rounding noise only
-        a, b = r0["params"][n].double(), ref[n].double()
-        scale = (b - b.mean()).abs().max().item() + 1e-12
-        worst[n] = (a - b).abs().max().item() / scale
-    bad = {k: v for k, v in worst.items() if v > 1e-5}
-    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:6]
+        a, b = (r0["params"][n] - init[n]).double(), (ref[n] - init[n]).double()
+        assert b.abs().max().item() > 0, n                                # every parameter moved
+        worst[n] = ((a - b).norm().item() / (b.norm().item() + 1e-30), (a - b).abs().max().item() / b.abs().max().item())
+    bad = {k: v for k, v in worst.items() if v[0] > 2e-3 or v[1] > 1e-2}
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]
+
+
+@pytest.mark.parametrize("collective", ["rs_ag", "allreduce"])
+def test_exchange_over_rccl_on_one_rank(cuda, tmp_path, collective):
+    """The exchange's RCCL calls themselves — reduce_scatter_tensor(AVG) + all_gather_into_tensor in place on the side
+    stream (or all_reduce), ordered against the backward by events — on the real "nccl" backend with a one-rank group
+    (all this box's single GPU allows: RCCL refuses two ranks on one device).  With one rank the collectives are
+    copies, so the step must equal the plain single-process step on the same shard."""
+    out = str(tmp_path)
+    assert _run([0, 1, _free_port(), out, collective]).wait(timeout=900) == 0
+    ref_dir = os.path.join(out, "ref")
+    os.makedirs(ref_dir)
+    assert _run([0, -1, 0, ref_dir]).wait(timeout=900) == 0
+    got, ref = torch.load(os.path.join(out, "rank0.pt")), torch.load(os.path.join(ref_dir, "rank0.pt"))
+    assert len(got["info"]["buckets"]) == 5
+    worst = {}
+    for n, b1 in ref["params"].items():
+        if n.endswith("box_predictor.det.bias"):
+            continue
+        a, b = (got["params"][n] - got["init"][n]).double(), (b1 - ref["init"][n]).double()
+        worst[n] = ((a - b).norm().item() / (b.norm().item() + 1e-30), (a - b).abs().max().item() / b.abs().max().item())
+    bad = {k: v for k, v in worst.items() if v[0] > 2e-3 or v[1] > 1e-2}     # (bars: see the two-rank test)
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:6]
