@@ -54,7 +54,7 @@ TIMING = None
 _pending_bytes = None
 _UNTIMED = ("jtsm_event_", "jtsm_last_error", "jtsm_version", "jtsm_device_count", "jtsm_conv_set_mid_event",
             "jtsm_conv_set_splitk_fused", "jtsm_conv_plan", "jtsm_conv_bf16x3_plan", "jtsm_conv_bf16x3_eligible", "jtsm_conv_out_size",
-            "jtsm_conv2d_")   # (the contractions carry their own, finer instrumentation: layers/conv.py LAUNCH_LOG)
+            "jtsm_conv2d_", "jtsm_conv_transpose2x2_")   # (the contractions carry their own, finer instrumentation: layers/conv.py LAUNCH_LOG)
 
 
 def note_bytes(nbytes):

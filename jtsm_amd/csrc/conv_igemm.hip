@@ -990,28 +990,53 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // Fold the split-K slabs in slice order (deterministic) and apply the fused epilogue.  VEC = 4 when the
 // row length and leading dimension are multiples of 4 (every layer of the model), else 1.
-template <int VEC>
+// G > 1 (many slices of a SMALL result — the weight gradients of narrow layers over 10^5 pixels): G threads share an
+// output piece, thread g adding slices g, g + G, ... and the G partial sums being added in order g = 0 .. G-1 through
+// LDS; with one thread per piece those launches were a few thousand threads each walking 64-256 dependent loads.
+template <int VEC, int G = 1>
 __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
   const int nv = p.N / VEC;
   const long total = (long)p.M * nv;
   const Epilogue& e = p.e;
   const float alpha = pow2i(-p.in_shift);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % nv) * VEC;
-    const long m = i / nv;
+  constexpr int PPB = 256 / G;                       // output pieces per workgroup and trip
+  __shared__ float red[G > 1 ? 256 * VEC : 1];
+  const int pl = threadIdx.x % PPB, g = threadIdx.x / PPB;
+  for (long i0 = (long)blockIdx.x * PPB; i0 < total; i0 += (long)gridDim.x * PPB) {   // (trip count is block-uniform)
+    const long i = i0 + pl;
+    const bool live = i < total;
+    const int n = live ? (int)(i % nv) * VEC : 0;
+    const long m = live ? i / nv : 0;
     float v[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) v[j] = 0.f;
-    for (int s = 0; s < splits; ++s) {
-      const float* src = p.slab + ((size_t)s * p.M + m) * p.ldc + n;
-      if (VEC == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(src);
-        v[0] = __fadd_rn(v[0], t.x); v[1 % VEC] = __fadd_rn(v[1 % VEC], t.y);
-        v[2 % VEC] = __fadd_rn(v[2 % VEC], t.z); v[3 % VEC] = __fadd_rn(v[3 % VEC], t.w);
-      } else {
-        v[0] += src[0];
+    if (live)
+      for (int s = g; s < splits; s += G) {
+        const float* src = p.slab + ((size_t)s * p.M + m) * p.ldc + n;
+        if (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(src);
+          v[0] = __fadd_rn(v[0], t.x); v[1 % VEC] = __fadd_rn(v[1 % VEC], t.y);
+          v[2 % VEC] = __fadd_rn(v[2 % VEC], t.z); v[3 % VEC] = __fadd_rn(v[3 % VEC], t.w);
+        } else {
+          v[0] += src[0];
+        }
       }
+    if (G > 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[(g * PPB + pl) * VEC + j] = v[j];
+      __syncthreads();
+      if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float t = 0.f;
+          for (int k = 0; k < G; ++k) t = __fadd_rn(t, red[(k * PPB + pl) * VEC + j]);
+          v[j] = t;
+        }
+      }
+      __syncthreads();
+      if (g != 0) continue;
     }
+    if (!live) continue;
     size_t o = (size_t)m * p.ldc + n;
     if (p.scatter) {
       const int ow = (int)(m % p.sc_Wo);
@@ -1094,6 +1119,9 @@ inline int* tickets_for(hipStream_t st) {
 inline bool use_fused_finish(Params& p, int ntiles, int splits, hipStream_t st) {
   p.tickets = nullptr;
   if (splits <= 1 || !p.wide || ntiles > kTicketCap || !splitk_fused_enabled()) return false;
+  // (the separate pass adds 32+ slices of a small result in a different — still fixed — order: keep those on it, so
+  // that the two ways of finishing stay bit-identical wherever both exist)
+  if (splits >= 32 && (long)p.M * (p.N / 4) <= (1L << 18)) return false;
   p.tickets = tickets_for(st);
   return p.tickets != nullptr;
 }
@@ -1102,6 +1130,13 @@ inline int finish_split(const Params& p, int splits, hipStream_t st, int scale_b
   const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
                    (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
   const long total = (long)p.M * (vec ? p.N / 4 : p.N);
+  if (vec && splits >= 32 && total <= (1L << 18)) {   // many slices of a result below 4 MB: 16 threads per piece
+    const long nb = (total + 15) / 16;
+    hipLaunchKernelGGL((splitk_finish<4, 16>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, st, p, splits,
+                       scale_by_row);
+    JTSM_CHECK_LAUNCH("splitk_finish");
+    return JTSM_OK;
+  }
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
   if (vec) hipLaunchKernelGGL(splitk_finish<4>, dim3(blocks), dim3(256), 0, st, p, splits, scale_by_row);
   else hipLaunchKernelGGL(splitk_finish<1>, dim3(blocks), dim3(256), 0, st, p, splits, scale_by_row);
@@ -1466,6 +1501,7 @@ static bool x3_wgrad_big(const Params& p) {
   if (p.M < 256 || p.N < 256) return false;
   constexpr long min_work = 2000;
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
+  if (t256 < 4) return false;   // 1-2 tiles cannot fill 256 CUs even at the slice cap: take four times as many 128s
   return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, tools/sweeps/wgrad_sweep.py)
 }
 
@@ -1499,7 +1535,13 @@ static int x3_wgrad_splits(const Params& p) {
   if (!big && ceil_div(ktiles, splits) > 64) splits = max(1, 768 / ntiles);
   const int min_stages = big ? 16 : 8;
   if (splits > ceil_div(ktiles, min_stages)) splits = ceil_div(ktiles, min_stages);
-  if (splits > 64) splits = 64;   // slab traffic: the finishing pass reads splits x dW
+  // slab traffic: the finishing pass reads splits x dW — 64 slices at most, more (up to 256) only while all the slabs
+  // together stay below 48 MB: the narrow predictors (80 x 256, 56 x 128 outputs over 10^5 pixels) were running on
+  // 64-128 workgroups
+  int cap = 64;
+  const size_t out_bytes = (size_t)p.M * p.N * sizeof(float);
+  while (cap < 256 && (size_t)cap * 2 * out_bytes <= (48u << 20)) cap *= 2;
+  if (splits > cap) splits = cap;
   if (splits < 1) splits = 1;
   const int kps = ceil_div(ktiles, splits);
   return kps > 0 ? ceil_div(ktiles, kps) : 1;
