@@ -352,6 +352,7 @@ int jtsm_conv2d_backward_weight_f16(const uint16_t* dy_h, const uint16_t* x_h, f
  *   backward_data  dx[b,i,j,c] = sum_{dy,dx,o} g[b,2i+dy,2j+dx,o] W[c][dy][dx][o], kept where relu_mask > 0 (nullable:
  *                  the ReLU output x came from) — the forward role of the 2x2/stride-2 convolution whose OHWI weight is
  *                  the same memory: w_* = plain planes of W (jtsm_split_bf16_f32); dx_hi / dx_lo nullable pair;
+ *                  gate_plane: the gate as a plane (see "planes only" below), nullable;
  *                  workspace: jtsm_conv_transpose2x2_workspace_bytes (may be null: no K split).
  *   backward_weight: jtsm_conv2d_backward_weight_bf16x3 with shape {batch, 2h, 2w, in_c = out_c, out_c = in_c, 2, 2,
  *                  stride 2, pad 0}, dy planes = x's, x planes = g's: dW comes out in the parameter's memory order.
@@ -365,10 +366,31 @@ size_t jtsm_conv_transpose2x2_workspace_bytes(int batch, int h, int w, int in_c,
 int jtsm_conv_transpose2x2_backward_data_bf16x3(const uint16_t* g_hi, const uint16_t* g_lo, const uint16_t* w_hi,
                                                 const uint16_t* w_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
                                                 int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
-                                                void* workspace, size_t workspace_bytes, void* stream);
+                                                const uint16_t* gate_plane, void* workspace, size_t workspace_bytes,
+                                                void* stream);
 int jtsm_conv_transpose2x2_backward_data_f16(const uint16_t* g_h, const uint16_t* w_h, float* dx, uint16_t* dx_h,
                                              int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
-                                             int grad_shift, void* workspace, size_t workspace_bytes, void* stream);
+                                             const uint16_t* gate_plane, int grad_shift, void* workspace,
+                                             size_t workspace_bytes, void* stream);
+/* ---- Chains that keep their activations as PLANES only (the mask heads' tower, layers/fused_blocks.py).
+ * In every plane-arithmetic entry point the fp32 result pointer (y / dx) may be NULL when its planes (y_hi.. / dx_hi..)
+ * are requested: the fp32 copy is then never written.  A ReLU gate can be read from the gated activation's hi (bf16)
+ * or only (fp16) plane instead of its fp32 copy: `gate_plane` (nullable, 16-byte aligned, same layout as the result)
+ * keeps the result where the 16-bit pattern is a positive number — the same gate (both formats round a positive fp32
+ * to a positive value) at half the bytes.  jtsm_conv2d_backward_data_pgate_* = jtsm_conv2d_backward_data_* with the
+ * gate given that way; jtsm_channel_sum_planes = the bias gradient (jtsm_channel_sum_ws_f32) of a gradient held as
+ * planes: out[c] = sum_r (hi + lo)[r][c] (lo null: the fp16 plane times 2^-shift); C % 8 == 0; workspace of
+ * 1024 * C floats. */
+int jtsm_conv2d_backward_data_pgate_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                           const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                           const jtsm_conv_shape* s, const float* accumulate,
+                                           const uint16_t* gate_plane, void* workspace, size_t workspace_bytes,
+                                           void* stream);
+int jtsm_conv2d_backward_data_pgate_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                        const jtsm_conv_shape* s, const float* accumulate, const uint16_t* gate_plane,
+                                        int grad_shift, void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, long rows, int C, int shift,
+                            void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */
 int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
                                  void* stream);

@@ -84,6 +84,11 @@ struct Params {
   // FWD as the GEMM of a 2x2 / stride-2 transposed convolution: row m = input pixel (b, y, x), column n = (dy, dx, c)
   // with c < shuffle_c; the result lands at output pixel (b, 2y + dy, 2x + dx), channel c (bias indexed by c).
   int shuffle_c, shuffle_h, shuffle_w;
+  // A ReLU gate read from the hi (or only) PLANE of the activation instead of its fp32 copy: keep the result where the
+  // plane's 16-bit pattern is a positive number (sign clear, not zero) — bf16 and fp16 round a positive fp32 to a
+  // positive value, so this is the same gate at half the bytes, and lets a chain keep activations as planes only
+  // (C == null: the fp32 result is not stored at all; needs out_hi).
+  const unsigned short* mask_plane;
   ConvShape s;
   Epilogue e;
 };
@@ -484,7 +489,11 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
       const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
       v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
     }
-    *reinterpret_cast<float4*>(p.C + o) = v;
+    if (p.mask_plane) {
+      const short4 mk = *reinterpret_cast<const short4*>(p.mask_plane + o);
+      v.x = mk.x > 0 ? v.x : 0.f; v.y = mk.y > 0 ? v.y : 0.f; v.z = mk.z > 0 ? v.z : 0.f; v.w = mk.w > 0 ? v.w : 0.f;
+    }
+    if (p.C) *reinterpret_cast<float4*>(p.C + o) = v;
     if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
   };
 #pragma unroll
@@ -1052,11 +1061,12 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
       if (e.residual) x = __fadd_rn(x, e.residual[o + j]);
       if (e.relu) x = fmaxf(x, 0.f);
       if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
+      if (p.mask_plane) x = (short)p.mask_plane[o + j] > 0 ? x : 0.f;
       v[j] = x;
     }
     if (VEC == 4) {
       const float4 out = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
-      *reinterpret_cast<float4*>(p.C + o) = out;
+      if (p.C) *reinterpret_cast<float4*>(p.C + o) = out;
       if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out, p.out_shift);
     } else {
       p.C[o] = v[0];
@@ -1404,6 +1414,7 @@ int jtsm_conv_bf16x3_eligible(const jtsm_conv_shape* s, int role) {
 // What the transposed-convolution entry points add to a forward-role launch.
 struct FwdExtras {
   const float* mask = nullptr;   // keep the result where mask > 0 (a ReLU gate), as in the data-gradient role
+  const uint16_t* mask_plane = nullptr;   // the same gate read from the activation's hi / fp16 plane (Params::mask_plane)
   int in_shift = 0, out_shift = 0;
   int shuffle_c = 0, shuffle_h = 0, shuffle_w = 0;   // Params::shuffle_*
 };
@@ -1425,14 +1436,15 @@ static int x3_forward(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t
   p.N = p.s.Cout;
   p.K = p.s.KH * p.s.KW * p.s.Cin;
   if (p.M == 0) return JTSM_OK;
-  JTSM_REQUIRE(x_hi && w_hi && y && (NP == 1 || (x_lo && w_lo)), "conv forward bf16x3 / f16: null pointer");
+  JTSM_REQUIRE(x_hi && w_hi && (y || y_hi) && (NP == 1 || (x_lo && w_lo)), "conv forward bf16x3 / f16: null pointer");
   JTSM_REQUIRE(aligned16(x_hi) && aligned16(x_lo) && aligned16(w_hi) && aligned16(w_lo),
                "conv forward bf16x3 / f16: planes must be 16-byte aligned");
   X3Planes q = {reinterpret_cast<const __bf16*>(x_hi), reinterpret_cast<const __bf16*>(x_lo),
                 reinterpret_cast<const __bf16*>(w_hi), reinterpret_cast<const __bf16*>(w_lo)};
   p.C = y; p.ldc = p.N;
   p.e.scale = scale; p.e.bias = bias; p.e.residual = residual; p.e.relu = relu;
-  p.e.mask = ex.mask; p.in_shift = ex.in_shift; p.out_shift = ex.out_shift;
+  p.e.mask = ex.mask; p.mask_plane = ex.mask_plane; p.in_shift = ex.in_shift; p.out_shift = ex.out_shift;
+  JTSM_REQUIRE(!ex.mask_plane || aligned16(ex.mask_plane), "conv forward bf16x3: the gate plane must be 16-byte aligned");
   p.shuffle_c = ex.shuffle_c; p.shuffle_h = ex.shuffle_h; p.shuffle_w = ex.shuffle_w;
   JTSM_REQUIRE(!ex.mask || aligned16(ex.mask), "conv forward bf16x3: the gate must be 16-byte aligned");
   if (ex.shuffle_c) {   // only the wide epilogue knows the pixel-shuffle map, and a K split's finishing pass does not
@@ -1456,7 +1468,8 @@ template <int NP>
 static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
                             const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
                             const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask, int grad_shift,
-                            void* workspace, size_t workspace_bytes, void* stream) {
+                            void* workspace, size_t workspace_bytes, void* stream,
+                            const uint16_t* gate_plane = nullptr) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1468,7 +1481,10 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
   p.N = p.s.Cin;
   p.K = p.s.KH * p.s.KW * p.s.Cout;
   if (p.M == 0) return JTSM_OK;
-  JTSM_REQUIRE(dy_hi && wt_hi && dx && (NP == 1 || (dy_lo && wt_lo)), "conv backward-data bf16x3 / f16: null pointer");
+  JTSM_REQUIRE(dy_hi && wt_hi && (dx || dx_hi) && (NP == 1 || (dy_lo && wt_lo)),
+               "conv backward-data bf16x3 / f16: null pointer");
+  JTSM_REQUIRE(!gate_plane || aligned16(gate_plane), "conv backward-data bf16x3: the gate plane must be 16-byte aligned");
+  p.mask_plane = gate_plane;
   JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv backward-data f16: grad_shift must be in 0..24");
   p.in_shift = grad_shift; p.out_shift = grad_shift;   // dy planes carry 2^shift; so do the dx planes written here
   JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(wt_hi) && aligned16(wt_lo),
@@ -1480,7 +1496,8 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
   JTSM_REQUIRE(NP == 1 || (dx_hi == nullptr) == (dx_lo == nullptr), "conv backward-data bf16x3: give both output planes or neither");
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
-  const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask;
+  const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask &&
+                       !gate_plane && dx;
   if (dx_hi) {   // planes of the finished gradient (e.g. already gated by relu_mask) for the next layer's contractions
     JTSM_REQUIRE(!scatter, "conv backward-data bf16x3: output planes are not produced by the strided 1x1 scatter path");
     JTSM_REQUIRE(p.N % 4 == 0 && aligned16(dx) && aligned16(dx_hi) && aligned16(dx_lo),
@@ -1698,23 +1715,43 @@ size_t jtsm_conv_transpose2x2_workspace_bytes(int batch, int h, int w, int in_c,
 int jtsm_conv_transpose2x2_backward_data_bf16x3(const uint16_t* g_hi, const uint16_t* g_lo, const uint16_t* w_hi,
                                                 const uint16_t* w_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
                                                 int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
-                                                void* workspace, size_t workspace_bytes, void* stream) {
+                                                const uint16_t* gate_plane, void* workspace, size_t workspace_bytes,
+                                                void* stream) {
   JTSM_CT_DIMS_OK("conv_transpose2x2 backward-data");
   const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
-  FwdExtras ex; ex.mask = relu_mask;
+  FwdExtras ex; ex.mask = relu_mask; ex.mask_plane = gate_plane;
   return x3_forward<2>(g_hi, g_lo, w_hi, w_lo, dx, dx_hi, dx_lo, &g, nullptr, nullptr, nullptr, 0, workspace,
                        workspace_bytes, stream, ex);
 }
 
 int jtsm_conv_transpose2x2_backward_data_f16(const uint16_t* g_h, const uint16_t* w_h, float* dx, uint16_t* dx_h,
                                              int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
-                                             int grad_shift, void* workspace, size_t workspace_bytes, void* stream) {
+                                             const uint16_t* gate_plane, int grad_shift, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
   JTSM_CT_DIMS_OK("conv_transpose2x2 backward-data");
   JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv_transpose2x2 backward-data f16: grad_shift must be in 0..24");
   const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
-  FwdExtras ex; ex.mask = relu_mask; ex.in_shift = grad_shift; ex.out_shift = grad_shift;
+  FwdExtras ex; ex.mask = relu_mask; ex.mask_plane = gate_plane; ex.in_shift = grad_shift; ex.out_shift = grad_shift;
   return x3_forward<1>(g_h, nullptr, w_h, nullptr, dx, dx_h, nullptr, &g, nullptr, nullptr, nullptr, 0, workspace,
                        workspace_bytes, stream, ex);
+}
+
+// The data gradient with its ReLU gate read from the gated activation's hi / fp16 PLANE (Params::mask_plane); dx may
+// be null when only the planes of the gated gradient are wanted (a chain that keeps activations as planes).
+int jtsm_conv2d_backward_data_pgate_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                           const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                           const jtsm_conv_shape* s, const float* accumulate,
+                                           const uint16_t* gate_plane, void* workspace, size_t workspace_bytes,
+                                           void* stream) {
+  return x3_backward_data<2>(dy_hi, dy_lo, wt_hi, wt_lo, dx, dx_hi, dx_lo, s, accumulate, nullptr, 0, workspace,
+                             workspace_bytes, stream, gate_plane);
+}
+
+int jtsm_conv2d_backward_data_pgate_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                        const jtsm_conv_shape* s, const float* accumulate, const uint16_t* gate_plane,
+                                        int grad_shift, void* workspace, size_t workspace_bytes, void* stream) {
+  return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, nullptr, grad_shift,
+                             workspace, workspace_bytes, stream, gate_plane);
 }
 
 int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,

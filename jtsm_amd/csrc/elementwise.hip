@@ -119,6 +119,46 @@ __global__ __launch_bounds__(256) void channel_sum4_kernel(const float4* __restr
                                                      (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
   }
 }
+// The same from operand PLANES (layers/conv.py): value = hi + lo (split-bf16) or the fp16 plane times 2^-shift.  A lane
+// owns eight channels (16 bytes per plane), slabs and fold as above.  For gradients a chain keeps as planes only.
+typedef __bf16 ew_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 ew_h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void channel_sum_planes_kernel(const unsigned short* __restrict__ hi,
+                                                                 const unsigned short* __restrict__ lo,
+                                                                 float* __restrict__ part, long rows, int C8,
+                                                                 long rows_per_block, float unshift) {
+  __shared__ float red[4][64][9];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c8 = blockIdx.x * 64 + lane;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c8 < C8) {
+    for (long r = r0 + wv; r < r1; r += 4) {
+      const size_t o = ((size_t)r * C8 + c8) * 8;
+      if (lo) {
+        const ew_bf16x8 a = *reinterpret_cast<const ew_bf16x8*>(hi + o), b = *reinterpret_cast<const ew_bf16x8*>(lo + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)a[j] + (float)b[j];
+      } else {
+        const ew_h8 a = *reinterpret_cast<const ew_h8*>(hi + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[wv][lane][j] = acc[j];
+  __syncthreads();
+  if (wv == 0 && c8 < C8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      part[(size_t)blockIdx.y * C8 * 8 + c8 * 8 + j] =
+          ((red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j])) * unshift;
+  }
+}
 // Any C (not a multiple of 4, narrower than 128, few rows): `cols` <= 256 columns per workgroup, 256 / cols row groups
 // striding the slab's rows, partial sums to part[slab][C] — the same fixed-order scheme, so bias gradients are
 // reproducible whatever the layer's width (the atomic form above is kept for callers without a workspace).
@@ -501,6 +541,35 @@ int jtsm_channel_sum_ws_f32(const float* g, float* out, long rows, int C, void* 
   }
   hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
   JTSM_CHECK_LAUNCH("channel_sum");
+  return JTSM_OK;
+}
+
+int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, long rows, int C, int shift,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0, "channel_sum_planes: C must be a positive multiple of 8");
+  JTSM_REQUIRE(out, "channel_sum_planes: null out");
+  JTSM_REQUIRE(shift >= 0 && shift <= 24, "channel_sum_planes: shift must be in 0..24");
+  hipStream_t st = as_stream(stream);
+  if (rows == 0) {
+    JTSM_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+    return JTSM_OK;
+  }
+  JTSM_REQUIRE(hi && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0, "channel_sum_planes: planes must be 16-byte aligned");
+  const int cg = ceil_div(C / 8, 64);
+  long slabs = 1024 / cg;
+  if (slabs > (rows + 31) / 32) slabs = (rows + 31) / 32;
+  if (slabs < 1) slabs = 1;
+  const long rpb = (rows + slabs - 1) / slabs;
+  const int nslab = (int)((rows + rpb - 1) / rpb);
+  JTSM_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)nslab * C * sizeof(float),
+               "channel_sum_planes: workspace of %zu bytes needed (1024 x C floats always suffice)",
+               (size_t)nslab * C * sizeof(float));
+  float* part = reinterpret_cast<float*>(workspace);
+  const float unshift = __builtin_ldexpf(1.f, -shift);
+  hipLaunchKernelGGL(channel_sum_planes_kernel, dim3(cg, (unsigned)nslab), dim3(256), 0, st, hi, lo, part, rows, C / 8,
+                     rpb, unshift);
+  hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
+  JTSM_CHECK_LAUNCH("channel_sum_planes");
   return JTSM_OK;
 }
 

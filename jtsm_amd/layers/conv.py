@@ -354,7 +354,7 @@ class LaunchSpan(object):
             pass
 
 
-def _timed(variant, flops, call, shape=None, extra_elems=0, out_elems=0, planes=False):
+def _timed(variant, flops, call, shape=None, extra_elems=0, out_elems=0, planes=False, fp32_out=True):
     """`extra_elems`: elements of the fused epilogue's extra fp32 operands (residual, accumulate, ReLU mask) — part
     of the launch's algorithmic bytes.  `out_elems` / `planes`: size of the result and whether its operand planes are
     emitted — what a split-K finishing pass moves: every slab read once, the result (+ planes, + the epilogue's extra
@@ -365,7 +365,7 @@ def _timed(variant, flops, call, shape=None, extra_elems=0, out_elems=0, planes=
     finish_bytes = 0.0
     if splits > 1:
         plane_b = (2.0 if MATH == "f16" else 4.0) if planes else 0.0
-        finish_bytes = out_elems * (4.0 * splits + 4.0 + plane_b) + 4.0 * extra_elems
+        finish_bytes = out_elems * (4.0 * splits + (4.0 if fp32_out else 0.0) + plane_b) + 4.0 * extra_elems
     if shape is not None and extra_elems and splits <= 1:
         shape = shape[:-1] + (shape[-1] + 4.0 * extra_elems,)
     lib = L.lib()
@@ -629,11 +629,11 @@ def conv_transpose2x2_backward_data(g, w, relu_mask=None, emit_planes=False):
     lib = L.lib()
     if MATH == "f16":
         L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_f16(
-            gh, wh, L.ptr(dx), dh, n, h, wd, i, o, L.ptr(relu_mask), GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes),
+            gh, wh, L.ptr(dx), dh, n, h, wd, i, o, L.ptr(relu_mask), None, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes),
             L.stream()), pl.desc, _numel(relu_mask), dx.numel(), dbuf is not None), "conv_transpose2x2_backward_data_f16")
     else:
         L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_bf16x3(
-            gh, gl, wh, wl, L.ptr(dx), dh, dl, n, h, wd, i, o, L.ptr(relu_mask), L.ptr(ws), C.c_size_t(nbytes),
+            gh, gl, wh, wl, L.ptr(dx), dh, dl, n, h, wd, i, o, L.ptr(relu_mask), None, L.ptr(ws), C.c_size_t(nbytes),
             L.stream()), pl.desc, _numel(relu_mask), dx.numel(), dbuf is not None),
                 "conv_transpose2x2_backward_data_bf16x3")
     if dbuf is not None:
@@ -649,6 +649,204 @@ def conv_transpose2x2_backward_weight(g, x, w):
         planes_of(x)
         planes_of(g, grad=True)
     return conv2d_backward_weight(x, g, (i, o, 2, 2), 2, 0, 1, w=w)
+
+
+# ---- the same contractions on PLANE BUFFERS: a chain (layers/fused_blocks.py: the mask tower) that keeps its
+# activations and gradients as operand planes only — no fp32 copy is written, ReLU gates are read from the hi plane
+class PlaneTensor(object):
+    """Planes buffer (layers/conv.py: _planes_buf) of a logical (N, C, H, W) channels_last tensor."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+
+    @property
+    def numel(self):
+        n = 1
+        for d in self.shape:
+            n *= d
+        return n
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    @staticmethod
+    def of(t, grad=False):
+        return PlaneTensor(planes_of(_cl(t), grad), t.shape)
+
+    @staticmethod
+    def empty(shape, device):
+        n = 1
+        for d in shape:
+            n *= d
+        return PlaneTensor(_planes_buf(n, device), shape)
+
+
+def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=False):
+    """x: PlaneTensor -> PlaneTensor of relu?(conv(x, w) + bias) (fp32=False: planes only, no fp32 copy is written), or
+    the fp32 result alone (fp32=True: a chain's last layer, read by a loss)."""
+    pl = _plan(x.shape, w.shape, stride, pad, dil)
+    s = pl.s
+    if not pl.x3[0]:
+        raise RuntimeError("planes_forward: shape is not eligible for the plane arithmetic")
+    oshape = (s.batch, s.out_c, pl.oh, pl.ow)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device, memory_format=CL) if fp32 else None
+    yp = None if fp32 else PlaneTensor.empty(oshape, x.device)
+    xh, xl = _hl(x.buf)
+    wh, wl = _hl(_weight_planes(_cl(w)))
+    yh, yl = _hl(yp.buf if yp is not None else None)
+    nbytes = pl.ws[0]
+    ws = _scratch(nbytes, x.device)
+    lib = L.lib()
+    n_out = s.batch * s.out_c * pl.oh * pl.ow
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f16(
+            xh, wh, L.ptr(y), yh, pl.ref, None, L.ptr(bias), None, int(bool(relu)), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, 0, n_out, not fp32, fp32), "conv2d_forward_f16")
+    else:
+        L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
+            xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, None, L.ptr(bias), None, int(bool(relu)), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, 0, n_out, not fp32, fp32), "conv2d_forward_bf16x3")
+    return y if fp32 else yp
+
+
+def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None):
+    """g: PlaneTensor of the output gradient (gradient planes: times 2^GRAD_SHIFT in fp16 mode); gate: PlaneTensor of
+    the ReLU output the result is gated by (or None) -> the input gradient as fp32 tensor (fp32=True) or PlaneTensor."""
+    pl = _plan(x_shape, w.shape, stride, pad, dil)
+    s = pl.s
+    if not pl.x3[1]:
+        raise RuntimeError("planes_backward_data: shape is not eligible for the plane arithmetic")
+    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=g.device, memory_format=CL) if fp32 else None
+    dp = None if fp32 else PlaneTensor.empty(x_shape, g.device)
+    gh, gl = _hl(g.buf)
+    wh, wl = _hl(_weight_planes(_cl(w), True, None))
+    dh, dl = _hl(dp.buf if dp is not None else None)
+    gate_h = _hl(gate.buf)[0] if gate is not None else None
+    nbytes = pl.ws[1]
+    ws = _scratch(nbytes, g.device)
+    lib = L.lib()
+    n_in = 1
+    for d in x_shape:
+        n_in *= d
+    extra = (0.5 * n_in if gate is not None else 0) + _numel(accumulate)     # (the gate plane: 2 bytes per element)
+    if accumulate is not None:
+        accumulate = _cl(accumulate)
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_pgate_f16(
+            gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(accumulate), gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_pgate_f16")
+    else:
+        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_pgate_bf16x3(
+            gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), gate_h, L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_pgate_bf16x3")
+    return dx if fp32 else dp
+
+
+def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None):
+    """dW from the planes of the output gradient g and of the input x; written into the parameter's gradient slot when
+    the data-parallel exchange registered one."""
+    w_shape = tuple(w.shape) if w_shape is None else tuple(w_shape)
+    pl = _plan(x.shape, w_shape, stride, pad, dil)
+    s = pl.s
+    if not pl.x3[2]:
+        raise RuntimeError("planes_backward_weight: shape is not eligible for the plane arithmetic")
+    slot = grad_slot(w)
+    if slot is not None:
+        taps = w_shape[2] * w_shape[3]
+        slot = slot.as_strided(w_shape, (taps * w_shape[1], 1, w_shape[3] * w_shape[1], w_shape[1]))
+    out = slot if slot is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device, memory_format=CL)
+    gh, gl = _hl(g.buf)
+    xh, xl = _hl(x.buf)
+    nbytes = pl.ws[2]
+    ws = _scratch(nbytes, x.device)
+    lib = L.lib()
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_f16(
+            gh, xh, L.ptr(out), pl.ref, None, 1, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            pl.desc, 0, out.numel()), "conv2d_backward_weight_f16")
+    else:
+        L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
+            gh, gl, xh, xl, L.ptr(out), pl.ref, None, 1, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            pl.desc, 0, out.numel()), "conv2d_backward_weight_bf16x3")
+    return out
+
+
+def planes_channel_sum(g, grad=True):
+    """Bias gradient of a gradient held as planes: sum over every axis but channels."""
+    ch = g.shape[1]
+    rows = g.numel // ch
+    out = torch.empty(ch, dtype=torch.float32, device=g.device)
+    nbytes = 4 * 1024 * ch
+    ws = _scratch(nbytes, g.device)
+    gh, gl = _hl(g.buf)
+    L.note_bytes((2.0 if MATH == "f16" else 4.0) * g.numel)
+    L.check(L.lib().jtsm_channel_sum_planes(gh, gl, L.ptr(out), C.c_long(rows), ch,
+                                                  GRAD_SHIFT if (grad and MATH == "f16") else 0, L.ptr(ws),
+                                                  C.c_size_t(nbytes), L.stream()), "channel_sum_planes")
+    return out
+
+
+def planes_conv_transpose2x2_forward(x, w, bias=None, relu=False, fp32=False):
+    """conv_transpose2x2_forward on a PlaneTensor -> PlaneTensor of y (or the fp32 y with fp32=True)."""
+    n, i, h, wd = x.shape
+    o = w.shape[1]
+    oshape = (n, o, 2 * h, 2 * wd)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device, memory_format=CL) if fp32 else None
+    yp = PlaneTensor.empty(oshape, x.device)
+    xh, xl = _hl(x.buf)
+    w1 = w.as_strided((i, 4 * o, 1, 1), (4 * o, 1, 1, 1))
+    wth, wtl = _hl(_weight_planes(w1, True))
+    yh, yl = _hl(yp.buf)
+    lib = L.lib()
+    flops = 2.0 * n * h * wd * i * 4 * o
+    var = _x3_variant(_plan((n, i, h, wd), (4 * o, i, 1, 1), 1, 0, 1).s, 0)
+    var = _Variant(str(var), 1) if var is not None else None
+    if MATH == "f16":
+        L.check(_timed(var, flops, lambda: lib.jtsm_conv_transpose2x2_forward_f16(
+            xh, wth, L.ptr(y), yh, n, h, wd, i, o, L.ptr(bias), int(bool(relu)), L.stream()),
+            _ct_desc(n, h, wd, i, o), 0, yp.numel, True, fp32), "conv_transpose2x2_forward_f16")
+    else:
+        L.check(_timed(var, flops, lambda: lib.jtsm_conv_transpose2x2_forward_bf16x3(
+            xh, xl, wth, wtl, L.ptr(y), yh, yl, n, h, wd, i, o, L.ptr(bias), int(bool(relu)), L.stream()),
+            _ct_desc(n, h, wd, i, o), 0, yp.numel, True, fp32), "conv_transpose2x2_forward_bf16x3")
+    if y is not None:
+        planes_put(y, yp.buf)
+    return (y, yp) if fp32 else yp
+
+
+def planes_conv_transpose2x2_backward_data(g, w, gate=None):
+    """PlaneTensor g (N, out, 2H, 2W) -> PlaneTensor of dx (N, in, H, W), gated by the PlaneTensor `gate`."""
+    n, o, h2, w2 = g.shape
+    i = w.shape[0]
+    h, wd = h2 // 2, w2 // 2
+    pl = _plan(g.shape, (i, o, 2, 2), 2, 0, 1)
+    dp = PlaneTensor.empty((n, i, h, wd), g.device)
+    gh, gl = _hl(g.buf)
+    wh, wl = _hl(_weight_planes(w))
+    dh, dl = _hl(dp.buf)
+    gate_h = _hl(gate.buf)[0] if gate is not None else None
+    nbytes = pl.ws[0]
+    ws = _scratch(nbytes, g.device)
+    lib = L.lib()
+    extra = 0.5 * dp.numel if gate is not None else 0
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_f16(
+            gh, wh, None, dh, n, h, wd, i, o, None, gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            pl.desc, extra, dp.numel, True, False), "conv_transpose2x2_backward_data_f16")
+    else:
+        L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_bf16x3(
+            gh, gl, wh, wl, None, dh, dl, n, h, wd, i, o, None, gate_h, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            pl.desc, extra, dp.numel, True, False), "conv_transpose2x2_backward_data_bf16x3")
+    return dp
+
+
+def planes_conv_transpose2x2_backward_weight(g, x, w):
+    """dW of the transposed convolution from PlaneTensors: the weight gradient of the 2x2 / stride-2 convolution it
+    transposes, with that convolution's 'dy' = x and input = g."""
+    i, o = w.shape[0], w.shape[1]
+    return planes_backward_weight(x, g, w, 2, 0, 1, w_shape=(i, o, 2, 2))
 
 
 class _ConvTranspose2x2(Function):

@@ -95,26 +95,32 @@ def bottleneck_fused(x, w1, sb1, w2, sb2, w3, sb3, ws, sbs, stride1, stride2, pa
 class _MaskTowerFn(Function):
     """The mask head's layers (detectron2/modeling/roi_heads/mask_head.py:201-290; WSL variant
     projects/WSL/wsl/modeling/roi_heads/mask_head.py:266-343) as ONE autograd node: k x [conv3x3 + bias + ReLU],
-    ConvTranspose2d(2, stride 2) + bias + ReLU, the 1x1 predictor.  As with the bottleneck, the point is the backward:
-    every ReLU gate between two contractions rides in the epilogue of the data-gradient launch that produces the
-    gradient (`relu_mask`), which also emits the gated gradient's planes — no relu_backward pass, no plane split —
-    and the transposed convolution never materialises a pixel-shuffled copy (layers/conv.py: conv_transpose2x2_*).
+    ConvTranspose2d(2, stride 2) + bias + ReLU, the 1x1 predictor.
 
-    apply(x, w_1, b_1, ..., w_k, b_k, w_deconv, b_deconv, w_pred, b_pred) -> (logits, upsampled features)."""
+    Inside the node the activations and their gradients exist as operand PLANES only (layers/conv.py: PlaneTensor):
+    a contraction's epilogue writes the planes the next contraction reads and no fp32 copy; every ReLU gate between
+    two contractions rides in the epilogue of the data-gradient launch that produces the gradient, read from the
+    gated activation's hi plane; bias gradients are summed from the gradient planes; the transposed convolution never
+    materialises a pixel-shuffled copy (conv_transpose2x2_*).  fp32 tensors: the input, the logits, the input
+    gradient — and the upsampled features when the caller asks for them (`want_features`).
+
+    apply(x, want_features, w_1, b_1, ..., w_k, b_k, w_deconv, b_deconv, w_pred, b_pred) -> (logits, features | None)."""
 
     @staticmethod
-    def forward(ctx, x, *params):
+    def forward(ctx, x, want_features, *params):
         k = (len(params) - 4) // 2
-        hs = [x]
+        hs = [K.PlaneTensor.of(x)]
         for j in range(k):
-            hs.append(K.conv2d_forward(hs[-1], params[2 * j], 1, 1, 1, None, params[2 * j + 1], None, True,
-                                       emit_planes=True))
+            hs.append(K.planes_forward(hs[-1], params[2 * j], 1, 1, 1, params[2 * j + 1], True))
         wd, bd, wp, bp = params[2 * k:]
-        u = K.conv_transpose2x2_forward(hs[-1], wd, bd, True, emit_planes=True)
-        logits = K.conv2d_forward(u, wp, 1, 0, 1, None, bp, None, False)
-        ctx.k = k
+        if want_features:
+            u, up = K.planes_conv_transpose2x2_forward(hs[-1], wd, bd, True, fp32=True)
+        else:
+            u, up = None, K.planes_conv_transpose2x2_forward(hs[-1], wd, bd, True)
+        logits = K.planes_forward(up, wp, 1, 0, 1, bp, False, fp32=True)
+        ctx.k, ctx.hs, ctx.up, ctx.xshape = k, hs, up, tuple(x.shape)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(u, *hs, *params[0:2 * k:2], wd, wp)
+        ctx.save_for_backward(*params[0:2 * k:2], wd, wp)
         return logits, u
 
     @staticmethod
@@ -122,48 +128,57 @@ class _MaskTowerFn(Function):
     def backward(ctx, dlogits, du):
         from .elementwise import channel_sum
 
-        k = ctx.k
+        k, hs, up = ctx.k, ctx.hs, ctx.up
         saved = ctx.saved_tensors
-        u, hs, ws, wd, wp = saved[0], saved[1:k + 2], saved[k + 2:2 * k + 2], saved[2 * k + 2], saved[2 * k + 3]
-        need = ctx.needs_input_grad
-        grads = [None] * (1 + 2 * k + 4)
+        ws, wd, wp = saved[:k], saved[k], saved[k + 1]
+        need = ctx.needs_input_grad[2:]                 # per parameter
+        grads = [None] * (2 * k + 4)
         if dlogits is None and du is None:
-            return tuple(grads)
-        # ---- predictor; its data gradient lands gated by the upsampler's ReLU, with planes
+            return (None, None) + tuple(grads)
+        # ---- predictor; its data gradient lands gated by the upsampler's ReLU, as planes
         if dlogits is not None:
-            gl = dlogits.contiguous(memory_format=CL)
+            dl = dlogits.contiguous(memory_format=CL)
+            gl = K.PlaneTensor.of(dl, grad=True)
+            if need[2 * k + 2]:
+                grads[2 * k + 2] = _same_strides(K.planes_backward_weight(gl, up, wp), wp)
             if need[2 * k + 3]:
-                grads[2 * k + 3] = _same_strides(K.conv2d_backward_weight(gl, u, tuple(wp.shape), 1, 0, 1, w=wp), wp)
-            if need[2 * k + 4]:
-                grads[2 * k + 4] = channel_sum(gl)
-            gu = K.conv2d_backward_data(gl, wp, tuple(u.shape), 1, 0, 1, accumulate=du, relu_mask=u, emit_planes=True)
+                grads[2 * k + 3] = channel_sum(dl)
+            gu = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up, accumulate=du)
         else:
-            gu = relu_backward(du, u, emit_planes=True)
+            gu = K.PlaneTensor(relu_backward_planes(du, up), up.shape)
         # ---- transposed convolution
+        if need[2 * k]:
+            grads[2 * k] = K.planes_conv_transpose2x2_backward_weight(gu, hs[k], wd)
         if need[2 * k + 1]:
-            grads[2 * k + 1] = K.conv_transpose2x2_backward_weight(gu, hs[k], wd)
-        if need[2 * k + 2]:
-            grads[2 * k + 2] = channel_sum(gu)
-        g = K.conv_transpose2x2_backward_data(gu, wd, relu_mask=hs[k] if k > 0 else None, emit_planes=True)
+            grads[2 * k + 1] = K.planes_channel_sum(gu)
+        g = K.planes_conv_transpose2x2_backward_data(gu, wd, gate=hs[k] if k > 0 else None)
         # ---- the 3x3 tower, last layer first
+        dx = None
         for j in range(k - 1, -1, -1):
             w = ws[j]
-            if need[1 + 2 * j]:
-                grads[1 + 2 * j] = K.conv2d_backward_weight(g, hs[j], tuple(w.shape), 1, 1, 1, w=w)
-            if need[2 + 2 * j]:
-                grads[2 + 2 * j] = channel_sum(g)
-            if j > 0 or need[0]:
-                g = K.conv2d_backward_data(g, w, tuple(hs[j].shape), 1, 1, 1, relu_mask=hs[j] if j > 0 else None,
-                                           emit_planes=j > 0)
-        if need[0]:
-            grads[0] = g
-        return tuple(grads)
+            if need[2 * j]:
+                grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1)
+            if need[2 * j + 1]:
+                grads[2 * j + 1] = K.planes_channel_sum(g)
+            if j > 0:
+                g = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j])
+            elif ctx.needs_input_grad[0]:
+                dx = K.planes_backward_data(g, w, ctx.xshape, 1, 1, 1, fp32=True)
+        if k == 0 and ctx.needs_input_grad[0]:
+            raise NotImplementedError("mask tower without 3x3 layers")   # (mask_tower_ok requires k >= 1)
+        return (dx, None) + tuple(grads)
+
+
+def relu_backward_planes(du, up):
+    raise NotImplementedError("a gradient into the upsampled features without one into the logits")
 
 
 def mask_tower_ok(x, convs, deconv, predictor):
     """Can the fused node take these layers?  (Plane arithmetic, 3x3/s1/p1 biased convolutions, the native
     transposed convolution, a predictor whose width the 16-byte epilogue can write.)"""
     if not (ENABLED and MASK_TOWER and K.MATH != "f32" and x.is_cuda and x.shape[0] > 0 and x.dtype == torch.float32):
+        return False
+    if not convs:
         return False
     for c in convs:
         if c.kernel_size != (3, 3) or c.stride != (1, 1) or c.padding != (1, 1) or c.dilation != (1, 1) or \
@@ -175,8 +190,9 @@ def mask_tower_ok(x, convs, deconv, predictor):
         predictor.norm is None and predictor.activation is None
 
 
-def mask_tower_fused(x, convs, deconv, predictor):
+def mask_tower_fused(x, convs, deconv, predictor, want_features=True):
     params = []
     for c in convs:
         params += [c.weight, c.bias]
-    return _MaskTowerFn.apply(x, *params, deconv.weight, deconv.bias, predictor.weight, predictor.bias)
+    return _MaskTowerFn.apply(x, bool(want_features), *params, deconv.weight, deconv.bias, predictor.weight,
+                              predictor.bias)

@@ -79,7 +79,10 @@ class MaskRCNNConvUpsampleWSLHead(nn.Module):
 
     def layers(self, x):
         if mask_tower_ok(x, self.conv_norm_relus, self.deconv, self.predictor):
-            return mask_tower_fused(x, self.conv_norm_relus, self.deconv, self.predictor)   # one autograd node
+            # one autograd node; `return_features = False` (set by a caller that uses the logits only, as
+            # JTSMROIHeads does) spares the fp32 copy of the upsampled features: the second value is then None
+            return mask_tower_fused(x, self.conv_norm_relus, self.deconv, self.predictor,
+                                    getattr(self, "return_features", True))
         for layer in self.conv_norm_relus:
             x = layer(x)
         x = self.deconv(x, relu=True)

@@ -144,6 +144,8 @@ class JTSMROIHeads(ROIHeads):
             head = build_mask_head(cfg, shape)
             self.add_module("mask_refinery_0", head)
             self.mask_refinery.append(head)
+            for h in [self.mask_head] + self.mask_refinery:
+                h.return_features = False    # only the logits of `layers` are used here: no fp32 upsampled features
         self.pgt_sem_seg = None
         self.aux = {}
         self.mask_mined_top_k = 10            # roi_heads_jtsm.py:420 (self.mask_mined_top_k = 10)

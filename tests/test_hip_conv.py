@@ -407,6 +407,19 @@ def test_mask_tower_as_one_node_matches_layer_by_layer(cuda):
     names = ["logits", "upsampled", "dx"] + [n for n, _ in head.named_parameters()]
     for n, a, b in zip(names, out[True], out[False]):
         close(a, b, "mask tower " + n, chain=True)
+    if K.MATH != "f32":
+        # a caller that uses the logits only: the node writes no fp32 upsampled features at all
+        head.return_features = False
+        K.planes_clear()
+        head.zero_grad(set_to_none=True)
+        x = x0.clone().requires_grad_()
+        logits, up = head.layers(x)
+        assert up is None
+        logits.backward(dl)
+        got = [logits.detach(), None, x.grad] + [p.grad.clone() for p in head.parameters()]
+        for n, a, b in zip(names, got, out[True]):
+            if a is not None:
+                assert torch.equal(a, b), n          # the same launches, minus one store
 
 
 @pytest.mark.parametrize("shape", [
