@@ -550,6 +550,13 @@ int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois,
                                       const int32_t* roi_level, int level, float* grad_input, int B,
                                       int C, int H, int W, int M, float spatial_scale, int pooled_h,
                                       int pooled_w, int sampling_ratio, int aligned, void* stream);
+/* All levels' gradient maps in ONE call (the backward of ROIPooler's level loop, detectron2/modeling/poolers.py:236-247):
+ * grad_inputs[l] (nullable: that level needs no gradient) is the (B,H[l],W[l],C) NHWC map of the rois with
+ * roi_level[m] == l.  The tiles of every level are workgroups of one launch. */
+int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                       float* const* grad_inputs, const int* H, const int* W, const float* scales,
+                                       int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,
+                                       int aligned, void* stream);
 int jtsm_moi_pool_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
                                     int level, const int32_t* oh_labels, const int32_t* superpixels,
                                     float* output, int32_t* argmax, void* workspace, int B, int C,

@@ -202,14 +202,35 @@ static int census_limit() {
   return v;
 }
 
-__global__ __launch_bounds__(256) void align_census_kernel(const float* __restrict__ rois, int M, float scale, int PH,
-                                                           int PW, int sr, int aligned, int H, int W,
-                                                           const int* __restrict__ roi_level, int level, int tiles_x,
-                                                           int tiles_y, int* __restrict__ census) {
+// The maps of the call: one level (jtsm_roi_align_backward_level_f32 / the plain entry) or all FPN levels at once
+// (jtsm_roi_align_backward_levels_f32) — tiles of every level are workgroups of ONE launch, so the levels' critical
+// paths (the busiest tile of each) overlap instead of adding up.
+constexpr int kAlignLevels = 8;
+struct AlignLevels {
+  float* gin[kAlignLevels];
+  int H[kAlignLevels], W[kAlignLevels];
+  float scale[kAlignLevels];
+  int tiles_x[kAlignLevels], tiles_y[kAlignLevels];
+  int first_tile[kAlignLevels + 1];   // running sum of B * tiles_x * tiles_y
+  int level_id[kAlignLevels];         // the roi_level value this entry serves
+  int n;
+};
+
+__global__ __launch_bounds__(256) void align_census_kernel(const float* __restrict__ rois, int M, int PH, int PW, int sr,
+                                                           int aligned, const int* __restrict__ roi_level,
+                                                           const AlignLevels lv, int* __restrict__ census) {
 #pragma clang fp contract(off)
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= M || (roi_level && roi_level[n] != level)) return;
-  const RoiGeom<float> g = geom_box<float>(rois + (size_t)n * 5, scale, PH, PW, sr, aligned != 0);
+  if (n >= M) return;
+  int l = 0;
+  if (roi_level) {
+    const int id = roi_level[n];
+    for (l = 0; l < lv.n && lv.level_id[l] != id; ++l) {}
+    if (l == lv.n) return;
+  }
+  const int H = lv.H[l], W = lv.W[l], tiles_x = lv.tiles_x[l], tiles_y = lv.tiles_y[l];
+  census += lv.first_tile[l];
+  const RoiGeom<float> g = geom_box<float>(rois + (size_t)n * 5, lv.scale[l], PH, PW, sr, aligned != 0);
   if (g.gh <= 0 || g.gw <= 0) return;
   const int xa = max((int)floorf(g.x0), 0), xz = min((int)floorf(g.x0 + (float)PW * g.bw) + 1, W - 1);
   const int ya = max((int)floorf(g.y0), 0), yz = min((int)floorf(g.y0 + (float)PH * g.bh) + 1, H - 1);
@@ -240,11 +261,16 @@ constexpr int kSub = 64;        // listed rois whose tile weights are staged in 
 constexpr int kMaxBins = 16;    // PH, PW <= 16 (7 and 14 on the JTSM path); wider poolers use the scatter form
 
 __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                       float* __restrict__ gin, int C, int H, int W, int M, float scale,
-                                                       int PH, int PW, int sr, int aligned,
-                                                       const int* __restrict__ roi_level, int level, int tiles_x,
-                                                       int tiles_y, const int* __restrict__ census_max, int census_lim) {
+                                                       const AlignLevels lv, int C, int M, int PH, int PW, int sr,
+                                                       int aligned, const int* __restrict__ roi_level,
+                                                       const int* __restrict__ census_max, int census_lim) {
 #pragma clang fp contract(off)
+  int lvl = 0;
+  while (lvl + 1 < lv.n && (int)blockIdx.x >= lv.first_tile[lvl + 1]) ++lvl;
+  float* __restrict__ gin = lv.gin[lvl];
+  const int H = lv.H[lvl], W = lv.W[lvl], tiles_x = lv.tiles_x[lvl], tiles_y = lv.tiles_y[lvl];
+  const int level = lv.level_id[lvl];
+  const float scale = lv.scale[lvl];
   // One workgroup per (8 x 8-cell tile, 64 channels): lane = channel, and each of the four wavefronts keeps its own
   // copy of the tile's 64 cells in REGISTERS.  The rois that can reach the tile are listed (256 at a time); for 64 of
   // them at a time the 256 threads compute, one (roi, axis, bin) each, the bilinear weights of every bin that reaches
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
   __shared__ int first_bin[kSub][2], nbin[kSub][2];
   __shared__ float inv_cnt[kSub];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  int rel = blockIdx.x;
+  int rel = blockIdx.x - lv.first_tile[lvl];
   const int tx = rel % tiles_x; rel /= tiles_x;
   const int ty = rel % tiles_y;
   const int b = rel / tiles_y;
@@ -532,6 +558,43 @@ int launch_forward(const T* in, const T* rois, T* out, int B, int C, int H, int 
   return JTSM_OK;
 }
 
+// Gather form with the census guard over a level table: both forms are launched, the device-side census lets one of
+// them return at once.
+static int align_backward_gather(const float* grad, const float* rois, AlignLevels& lv, int B, int C, int M, int PH,
+                                 int PW, int sr, int aligned, const int* roi_level, hipStream_t st) {
+  int ntile = 0;
+  for (int l = 0; l < lv.n; ++l) {
+    lv.tiles_x[l] = ceil_div(lv.W[l], kTile);
+    lv.tiles_y[l] = ceil_div(lv.H[l], kTile);
+    lv.first_tile[l] = ntile;
+    ntile += B * lv.tiles_x[l] * lv.tiles_y[l];
+  }
+  lv.first_tile[lv.n] = ntile;
+  int* census = nullptr;
+  JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), (size_t)(ntile + 1) * sizeof(int), st));
+  JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
+  hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, rois, M, PH, PW, sr, aligned,
+                     roi_level, lv, census);
+  hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
+  hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 0, st, grad, rois, lv, C, M, PH, PW, sr, aligned,
+                     roi_level, census + ntile, census_limit());
+  constexpr int V = WideVec<float>::value;
+  const int blocks = ceil_div((long)M * PH * PW, 4);
+  for (int l = 0; l < lv.n; ++l) {   // the scatter form, level by level (each returns at once unless the census says so)
+    if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
+      hipLaunchKernelGGL((align_bwd_nhwc<float, V, false>), dim3(blocks), dim3(256), 0, st, grad, rois, lv.gin[l], C,
+                         lv.H[l], lv.W[l], M, lv.scale[l], PH, PW, sr, aligned, roi_level, lv.level_id[l],
+                         census + ntile, census_limit());
+    else
+      hipLaunchKernelGGL((align_bwd_nhwc<float, 1, false>), dim3(blocks), dim3(256), 0, st, grad, rois, lv.gin[l], C,
+                         lv.H[l], lv.W[l], M, lv.scale[l], PH, PW, sr, aligned, roi_level, lv.level_id[l],
+                         census + ntile, census_limit());
+  }
+  JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
+  JTSM_CHECK_HIP(hipFreeAsync(census, st));
+  return JTSM_OK;
+}
+
 template <typename T, bool ROT>
 int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, int W, int M,
                     T scale, int PH, int PW, int sr, int aligned, int layout, void* stream,
@@ -547,32 +610,12 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
   // tile of the whole map: the gather starts at 8192 bins)
   if (std::is_same<T, float>::value && !ROT && layout == JTSM_NHWC && C % 64 == 0 && grad && rois && PW <= kMaxBins && PH <= kMaxBins &&
       (long)M * PH * PW >= 8192 && (long)M * PH * PW < (1L << 30)) {
-    // gather form with the census guard: both forms are launched, the device-side census lets one of them return
-    const int tiles_x = ceil_div(W, kTile), tiles_y = ceil_div(H, kTile), ntile = B * tiles_x * tiles_y;
-    int* census = nullptr;
-    JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), (size_t)(ntile + 1) * sizeof(int), st));
-    JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
-    const float* g32 = reinterpret_cast<const float*>(grad);
-    const float* r32 = reinterpret_cast<const float*>(rois);
-    hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, r32, M, (float)scale, PH, PW, sr,
-                       aligned, H, W, roi_level, level, tiles_x, tiles_y, census);
-    hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
-    hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 0, st, g32,
-                       r32, reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
-                       tiles_x, tiles_y, census + ntile, census_limit());
-    constexpr int V = WideVec<float>::value;
-    const int blocks = ceil_div((long)M * PH * PW, 4);
-    if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
-      hipLaunchKernelGGL((align_bwd_nhwc<float, V, false>), dim3(blocks), dim3(256), 0, st, g32, r32,
-                         reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
-                         census + ntile, census_limit());
-    else
-      hipLaunchKernelGGL((align_bwd_nhwc<float, 1, false>), dim3(blocks), dim3(256), 0, st, g32, r32,
-                         reinterpret_cast<float*>(gin), C, H, W, M, (float)scale, PH, PW, sr, aligned, roi_level, level,
-                         census + ntile, census_limit());
-    JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
-    JTSM_CHECK_HIP(hipFreeAsync(census, st));
-    return JTSM_OK;
+    AlignLevels lv = {};
+    lv.n = 1;
+    lv.gin[0] = reinterpret_cast<float*>(gin); lv.H[0] = H; lv.W[0] = W; lv.scale[0] = (float)scale;
+    lv.level_id[0] = level;
+    return align_backward_gather(reinterpret_cast<const float*>(grad), reinterpret_cast<const float*>(rois), lv, B, C, M,
+                                 PH, PW, sr, aligned, roi_level, st);
   }
   JTSM_CHECK_HIP(hipMemsetAsync(gin, 0, in_elems * sizeof(T), st));
   if ((long)M * C * PH * PW == 0) return JTSM_OK;  // empty gradient: zeros (ROIAlign_cuda.cu:402-405)
@@ -815,6 +858,38 @@ int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois, cons
   JTSM_REQUIRE(roi_level || M == 0, "roi_align level: null roi_level");
   return launch_backward<float, false>(grad, rois, grad_input, B, C, H, W, M, spatial_scale, pooled_h,
                                        pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, level);
+}
+
+int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                       float* const* grad_inputs, const int* H, const int* W, const float* scales,
+                                       int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,
+                                       int aligned, void* stream) {
+  JTSM_REQUIRE(nlevels > 0 && nlevels <= kAlignLevels && grad_inputs && H && W && scales,
+               "roi_align levels: bad level table");
+  JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0, "roi_align levels: negative size");
+  JTSM_REQUIRE(roi_level || M == 0, "roi_align levels: null roi_level");
+  hipStream_t st = as_stream(stream);
+  const bool gather = C % 64 == 0 && C > 0 && B > 0 && grad && rois && pooled_w <= kMaxBins && pooled_h <= kMaxBins &&
+                      (long)M * pooled_h * pooled_w >= 8192 && (long)M * pooled_h * pooled_w < (1L << 30);
+  if (gather) {
+    AlignLevels lv = {};
+    lv.n = 0;
+    for (int l = 0; l < nlevels; ++l) {
+      if (!grad_inputs[l]) continue;           // a level whose map needs no gradient
+      JTSM_REQUIRE(H[l] > 0 && W[l] > 0, "roi_align levels: empty map");
+      const int k = lv.n++;
+      lv.gin[k] = grad_inputs[l]; lv.H[k] = H[l]; lv.W[k] = W[l]; lv.scale[k] = scales[l]; lv.level_id[k] = l;
+    }
+    if (lv.n == 0) return JTSM_OK;
+    return align_backward_gather(grad, rois, lv, B, C, M, pooled_h, pooled_w, sampling_ratio, aligned, roi_level, st);
+  }
+  for (int l = 0; l < nlevels; ++l) {
+    if (!grad_inputs[l]) continue;
+    const int rc = launch_backward<float, false>(grad, rois, grad_inputs[l], B, C, H[l], W[l], M, scales[l], pooled_h,
+                                                 pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, l);
+    if (rc) return rc;
+  }
+  return JTSM_OK;
 }
 
 int jtsm_roi_sample_table_f32(const float* rois, int rotated, int M, int H, int W,

@@ -82,18 +82,19 @@ class _AlignLevels(Function):
         rois, roi_level = ctx.saved_tensors
         res, sampling_ratio, aligned, scales, shapes = ctx.cfg
         g = g.contiguous(memory_format=CL)
-        grads = []
-        for lvl, (shape, sc) in enumerate(zip(shapes, scales)):
-            if not ctx.needs_input_grad[6 + lvl]:
-                grads.append(None)
-                continue
-            B, C, H, W = shape
-            gi = torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
-            L.note_bytes(4.0 * (g.numel() / len(shapes) + gi.numel() + rois.numel()))   # read g, write the map
-            L.check(L.lib().jtsm_roi_align_backward_level_f32(
-                L.ptr(g), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(gi), B, C, H, W, rois.shape[0], L.f32(sc),
-                res, res, sampling_ratio, int(aligned), L.stream()), "roi_align_backward_level")
-            grads.append(gi)
+        nl = len(shapes)
+        B, Cc = shapes[0][0], shapes[0][1]
+        grads = [torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
+                 if ctx.needs_input_grad[6 + lvl] else None for lvl, shape in enumerate(shapes)]
+        Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
+        Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
+        sc = (C.c_float * nl)(*[float(x) for x in scales])
+        ptrs = (C.c_void_p * nl)(*[(t.data_ptr() if t is not None else None) for t in grads])
+        # read g, write every map
+        L.note_bytes(4.0 * (g.numel() + sum(t.numel() for t in grads if t is not None) + rois.numel()))
+        L.check(L.lib().jtsm_roi_align_backward_levels_f32(
+            L.ptr(g), L.ptr(rois), L.ptr(roi_level), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
+            sampling_ratio, int(aligned), L.stream()), "roi_align_backward_levels")
         return (None, None, None, None, None, None, *grads)
 
 
