@@ -377,18 +377,38 @@ int jtsm_conv_transpose2x2_backward_data_f16(const uint16_t* g_h, const uint16_t
  * are requested: the fp32 copy is then never written.  A ReLU gate can be read from the gated activation's hi (bf16)
  * or only (fp16) plane instead of its fp32 copy: `gate_plane` (nullable, 16-byte aligned, same layout as the result)
  * keeps the result where the 16-bit pattern is a positive number — the same gate (both formats round a positive fp32
- * to a positive value) at half the bytes.  jtsm_conv2d_backward_data_pgate_* = jtsm_conv2d_backward_data_* with the
- * gate given that way; jtsm_channel_sum_planes = the bias gradient (jtsm_channel_sum_ws_f32) of a gradient held as
+ * to a positive value) at half the bytes.  jtsm_conv2d_backward_data_ex_* = jtsm_conv2d_backward_data_* with every
+ * epilogue option: row_scale (nullable, one factor per result row — pixel or roi — applied first: the data gradient
+ * of a layer whose input rows were rescaled, e.g. the per-roi factor in front of the box head,
+ * projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:607-633), accumulate, relu_mask (fp32 gate) and gate_plane;
+ * jtsm_channel_sum_planes = the bias gradient (jtsm_channel_sum_ws_f32) of a gradient held as
  * planes: out[c] = sum_r (hi + lo)[r][c] (lo null: the fp16 plane times 2^-shift); C % 8 == 0; workspace of
  * 1024 * C floats. */
-int jtsm_conv2d_backward_data_pgate_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
-                                           const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
-                                           const jtsm_conv_shape* s, const float* accumulate,
-                                           const uint16_t* gate_plane, void* workspace, size_t workspace_bytes,
-                                           void* stream);
-int jtsm_conv2d_backward_data_pgate_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
-                                        const jtsm_conv_shape* s, const float* accumulate, const uint16_t* gate_plane,
-                                        int grad_shift, void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_conv2d_backward_data_ex_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                        const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                        const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                        const float* relu_mask, const uint16_t* gate_plane, void* workspace,
+                                        size_t workspace_bytes, void* stream);
+int jtsm_conv2d_backward_data_ex_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                     const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                     const float* relu_mask, const uint16_t* gate_plane, int grad_shift, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+/* Streaming passes that end in operand planes (hi + lo bf16, or lo == NULL: one fp16 plane of v * 2^shift; all
+ * pointers 16-byte aligned, element counts multiples of 8):
+ *   jtsm_relu_backward_split_scaled_f32  g = y > 0 ? dy * scale : 0 (+ planes of g): the backward of ReLU followed by
+ *       inverted dropout when y is the DROPOUT's output (positive exactly where the unit was kept and active;
+ *       scale = 1 / (1 - p)) — torch.nn.functional.dropout + F.relu of the box head,
+ *       projects/WSL/wsl/modeling/roi_heads/box_head.py DiscriminativeAdaptionNeck;
+ *   jtsm_split_rowscale_f32              planes of src[r][c] * row_scale[r] (nothing else is written): the per-roi
+ *       rescale in front of the box head (roi_heads_jtsm.py:607-633) folded into the plane split;
+ *   jtsm_dropout_split_f32               y = keep(i) ? x / (1 - p) : 0 (y may alias x) + planes of y (y_hi nullable);
+ *       keep(i) is a counter-based hash of (seed, i), so no mask is stored. */
+int jtsm_relu_backward_split_scaled_f32(const float* dy, const float* y, float scale, float* g, uint16_t* g_hi,
+                                        uint16_t* g_lo, long n, int shift, void* stream);
+int jtsm_split_rowscale_f32(const float* src, const float* row_scale, long rows, int cols, uint16_t* hi, uint16_t* lo,
+                            int shift, void* stream);
+int jtsm_dropout_split_f32(const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, long n, float p,
+                           unsigned long long seed, void* stream);
 int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, long rows, int C, int shift,
                             void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */

@@ -89,6 +89,7 @@ struct Params {
   // positive value, so this is the same gate at half the bytes, and lets a chain keep activations as planes only
   // (C == null: the fp32 result is not stored at all; needs out_hi).
   const unsigned short* mask_plane;
+  int scale_rows;   // FWD / DGRAD: e.scale holds one factor per output ROW (pixel / roi), not per column
   ConvShape s;
   Epilogue e;
 };
@@ -470,6 +471,9 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
         const float sc = e.scale[m];
         v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
       }
+    } else if (e.scale && p.scale_rows) {
+      const float sc = e.scale[m];
+      v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
     } else if (e.scale) {
       const float4 sc = *reinterpret_cast<const float4*>(e.scale + nb);
       v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
@@ -1137,6 +1141,7 @@ inline bool use_fused_finish(Params& p, int ntiles, int splits, hipStream_t st) 
 }
 
 inline int finish_split(const Params& p, int splits, hipStream_t st, int scale_by_row = 0) {
+  scale_by_row = scale_by_row || p.scale_rows;
   const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
                    (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
   const long total = (long)p.M * (vec ? p.N / 4 : p.N);
@@ -1469,7 +1474,7 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
                             const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
                             const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask, int grad_shift,
                             void* workspace, size_t workspace_bytes, void* stream,
-                            const uint16_t* gate_plane = nullptr) {
+                            const uint16_t* gate_plane = nullptr, const float* row_scale = nullptr) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1485,6 +1490,7 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
                "conv backward-data bf16x3 / f16: null pointer");
   JTSM_REQUIRE(!gate_plane || aligned16(gate_plane), "conv backward-data bf16x3: the gate plane must be 16-byte aligned");
   p.mask_plane = gate_plane;
+  if (row_scale) { p.e.scale = row_scale; p.scale_rows = 1; }   // dx[m][:] *= row_scale[m] (before accumulate / gates)
   JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv backward-data f16: grad_shift must be in 0..24");
   p.in_shift = grad_shift; p.out_shift = grad_shift;   // dy planes carry 2^shift; so do the dx planes written here
   JTSM_REQUIRE(aligned16(dy_hi) && aligned16(dy_lo) && aligned16(wt_hi) && aligned16(wt_lo),
@@ -1497,7 +1503,8 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
   const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask &&
-                       !gate_plane && dx;
+                       !gate_plane && !row_scale && dx;
+  JTSM_REQUIRE(!row_scale || (p.N % 4 == 0 && aligned16(dx)), "conv backward-data: a row scale needs in_c %% 4 == 0");
   if (dx_hi) {   // planes of the finished gradient (e.g. already gated by relu_mask) for the next layer's contractions
     JTSM_REQUIRE(!scatter, "conv backward-data bf16x3: output planes are not produced by the strided 1x1 scatter path");
     JTSM_REQUIRE(p.N % 4 == 0 && aligned16(dx) && aligned16(dx_hi) && aligned16(dx_lo),
@@ -1738,20 +1745,21 @@ int jtsm_conv_transpose2x2_backward_data_f16(const uint16_t* g_h, const uint16_t
 
 // The data gradient with its ReLU gate read from the gated activation's hi / fp16 PLANE (Params::mask_plane); dx may
 // be null when only the planes of the gated gradient are wanted (a chain that keeps activations as planes).
-int jtsm_conv2d_backward_data_pgate_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
-                                           const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
-                                           const jtsm_conv_shape* s, const float* accumulate,
-                                           const uint16_t* gate_plane, void* workspace, size_t workspace_bytes,
-                                           void* stream) {
-  return x3_backward_data<2>(dy_hi, dy_lo, wt_hi, wt_lo, dx, dx_hi, dx_lo, s, accumulate, nullptr, 0, workspace,
-                             workspace_bytes, stream, gate_plane);
+int jtsm_conv2d_backward_data_ex_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                        const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                        const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                        const float* relu_mask, const uint16_t* gate_plane, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return x3_backward_data<2>(dy_hi, dy_lo, wt_hi, wt_lo, dx, dx_hi, dx_lo, s, accumulate, relu_mask, 0, workspace,
+                             workspace_bytes, stream, gate_plane, row_scale);
 }
 
-int jtsm_conv2d_backward_data_pgate_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
-                                        const jtsm_conv_shape* s, const float* accumulate, const uint16_t* gate_plane,
-                                        int grad_shift, void* workspace, size_t workspace_bytes, void* stream) {
-  return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, nullptr, grad_shift,
-                             workspace, workspace_bytes, stream, gate_plane);
+int jtsm_conv2d_backward_data_ex_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                     const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                     const float* relu_mask, const uint16_t* gate_plane, int grad_shift, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, relu_mask, grad_shift,
+                             workspace, workspace_bytes, stream, gate_plane, row_scale);
 }
 
 int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,

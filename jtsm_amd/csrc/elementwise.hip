@@ -61,6 +61,83 @@ __global__ __launch_bounds__(256) void relu_bwd_split_f16_kernel(const float4* _
     h[i] = o;
   }
 }
+// ---- one streaming pass that ends in operand planes (layers/conv.py), three uses:
+//   kGateScaled  v = y > 0 ? dy * scale : 0          the backward of ReLU followed by dropout (y = the dropout's output:
+//                                                    positive exactly where the unit was kept AND active), g = v stored
+//   kRowScale    v = x[r][c] * row_scale[r]          planes of a row-rescaled matrix (the per-roi factor in front of the
+//                                                    box head) without materialising it; nothing else stored
+//   kDropout     v = keep(i) ? x * scale : 0         inverted dropout, y = v stored (may alias x); keep(i) is a
+//                                                    counter-based hash of (seed, element index): nothing to remember,
+//                                                    the backward reads the mask off y (kGateScaled)
+// Planes: bf16 hi + lo, or (lo == null) one fp16 plane of v * 2^shift; hi == null: no planes.
+enum PassMode { kGateScaled = 0, kRowScale = 1, kDropout = 2 };
+struct PassArgs {
+  const float* a;           // dy | x | x
+  const float* b;           // y  | - | -
+  float* out;               // g  | - | y
+  unsigned short* hi;
+  unsigned short* lo;
+  const float* row_scale;
+  long n8;                  // elements / 8
+  int cols;                 // kRowScale: row length (a multiple of 8)
+  float scale;
+  float drop_p;
+  unsigned long long seed;
+  int shift;
+};
+__device__ __forceinline__ float uniform01(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1);     // splitmix64
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);            // 24 bits -> [0, 1)
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void planes_pass_kernel(const PassArgs q) {
+  const float4* __restrict__ a = reinterpret_cast<const float4*>(q.a);
+  const float4* __restrict__ b = reinterpret_cast<const float4*>(q.b);
+  float4* __restrict__ out = reinterpret_cast<float4*>(q.out);
+  const float sh = __int_as_float((127 + q.shift) << 23);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < q.n8; i += (long)gridDim.x * blockDim.x) {
+    const float4 a0 = a[2 * i], a1 = a[2 * i + 1];
+    float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    if (MODE == kGateScaled) {
+      const float4 b0 = b[2 * i], b1 = b[2 * i + 1];
+      const float y[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = y[e] > 0.f ? v[e] * q.scale : 0.f;
+    } else if (MODE == kRowScale) {
+      const float rs = q.row_scale[(i * 8) / q.cols];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= rs;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        v[e] = uniform01(q.seed, (unsigned long long)(i * 8 + e)) >= q.drop_p ? v[e] * q.scale : 0.f;
+    }
+    if (MODE != kRowScale) {
+      out[2 * i] = make_float4(v[0], v[1], v[2], v[3]);
+      out[2 * i + 1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (!q.hi) continue;
+    if (q.lo) {
+      ew_bf16x8 h, l;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const __bf16 hh = (__bf16)v[e];
+        h[e] = hh;
+        l[e] = (__bf16)(v[e] - (float)hh);
+      }
+      reinterpret_cast<ew_bf16x8*>(q.hi)[i] = h;
+      reinterpret_cast<ew_bf16x8*>(q.lo)[i] = l;
+    } else {
+      ew_f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)(v[e] * sh);
+      reinterpret_cast<ew_f16x8*>(q.hi)[i] = o;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void relu_bwd_tail(const float* __restrict__ dy,
                                                      const float* __restrict__ y,
                                                      float* __restrict__ g, long beg, long n) {
@@ -499,6 +576,55 @@ int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint
                      (const float4*)y, (float4*)g, reinterpret_cast<ew_f16x8*>(g_h), n8, shift);
   JTSM_CHECK_LAUNCH("relu_backward_split_f16");
   return JTSM_OK;
+}
+
+static int launch_planes_pass(int mode, const PassArgs& q, const char* what, void* stream) {
+  const int blocks = (int)((q.n8 + 255) / 256 < 8192 ? (q.n8 + 255) / 256 : 8192);
+  hipStream_t st = as_stream(stream);
+  if (mode == kGateScaled) hipLaunchKernelGGL(planes_pass_kernel<kGateScaled>, dim3(blocks), dim3(256), 0, st, q);
+  else if (mode == kRowScale) hipLaunchKernelGGL(planes_pass_kernel<kRowScale>, dim3(blocks), dim3(256), 0, st, q);
+  else hipLaunchKernelGGL(planes_pass_kernel<kDropout>, dim3(blocks), dim3(256), 0, st, q);
+  JTSM_CHECK_LAUNCH(what);
+  return JTSM_OK;
+}
+static bool pass_aligned(const void* a, const void* b, const void* c, const void* d, const void* e) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 15) == 0;
+}
+
+int jtsm_relu_backward_split_scaled_f32(const float* dy, const float* y, float scale, float* g, uint16_t* g_hi,
+                                        uint16_t* g_lo, long n, int shift, void* stream) {
+  JTSM_REQUIRE(n >= 0 && n % 8 == 0, "relu_backward_split_scaled: n must be a non-negative multiple of 8");
+  JTSM_REQUIRE(shift >= 0 && shift <= 24, "relu_backward_split_scaled: shift must be in 0..24");
+  if (n == 0) return JTSM_OK;
+  JTSM_REQUIRE(dy && y && g && (g_hi || !g_lo), "relu_backward_split_scaled: null pointer");
+  JTSM_REQUIRE(pass_aligned(dy, y, g, g_hi, g_lo), "relu_backward_split_scaled: pointers must be 16-byte aligned");
+  PassArgs q = {};
+  q.a = dy; q.b = y; q.out = g; q.hi = g_hi; q.lo = g_lo; q.n8 = n / 8; q.scale = scale; q.shift = shift;
+  return launch_planes_pass(kGateScaled, q, "relu_backward_split_scaled", stream);
+}
+
+int jtsm_split_rowscale_f32(const float* src, const float* row_scale, long rows, int cols, uint16_t* hi, uint16_t* lo,
+                            int shift, void* stream) {
+  JTSM_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0, "split_rowscale: cols must be a positive multiple of 8");
+  JTSM_REQUIRE(shift >= 0 && shift <= 24, "split_rowscale: shift must be in 0..24");
+  if (rows == 0) return JTSM_OK;
+  JTSM_REQUIRE(src && row_scale && hi, "split_rowscale: null pointer");
+  JTSM_REQUIRE(pass_aligned(src, hi, lo, nullptr, nullptr), "split_rowscale: pointers must be 16-byte aligned");
+  PassArgs q = {};
+  q.a = src; q.row_scale = row_scale; q.hi = hi; q.lo = lo; q.n8 = rows * (long)(cols / 8); q.cols = cols; q.shift = shift;
+  return launch_planes_pass(kRowScale, q, "split_rowscale", stream);
+}
+
+int jtsm_dropout_split_f32(const float* x, float* y, uint16_t* y_hi, uint16_t* y_lo, long n, float p,
+                           unsigned long long seed, void* stream) {
+  JTSM_REQUIRE(n >= 0 && n % 8 == 0, "dropout_split: n must be a non-negative multiple of 8");
+  JTSM_REQUIRE(p >= 0.f && p < 1.f, "dropout_split: p must be in [0, 1)");
+  if (n == 0) return JTSM_OK;
+  JTSM_REQUIRE(x && y && (y_hi || !y_lo), "dropout_split: null pointer");
+  JTSM_REQUIRE(pass_aligned(x, y, y_hi, y_lo, nullptr), "dropout_split: pointers must be 16-byte aligned");
+  PassArgs q = {};
+  q.a = x; q.out = y; q.hi = y_hi; q.lo = y_lo; q.n8 = n / 8; q.scale = 1.f / (1.f - p); q.drop_p = p; q.seed = seed;
+  return launch_planes_pass(kDropout, q, "dropout_split", stream);
 }
 
 static bool csum_wide(long rows, int C) { return C % 4 == 0 && C >= 128 && rows >= 256; }

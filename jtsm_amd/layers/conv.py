@@ -691,8 +691,9 @@ def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=Fal
     if not pl.x3[0]:
         raise RuntimeError("planes_forward: shape is not eligible for the plane arithmetic")
     oshape = (s.batch, s.out_c, pl.oh, pl.ow)
+    both = fp32 == "both"            # -> (y fp32, PlaneTensor)
     y = torch.empty(oshape, dtype=torch.float32, device=x.device, memory_format=CL) if fp32 else None
-    yp = None if fp32 else PlaneTensor.empty(oshape, x.device)
+    yp = PlaneTensor.empty(oshape, x.device) if (both or not fp32) else None
     xh, xl = _hl(x.buf)
     wh, wl = _hl(_weight_planes(_cl(w)))
     yh, yl = _hl(yp.buf if yp is not None else None)
@@ -703,15 +704,18 @@ def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=Fal
     if MATH == "f16":
         L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f16(
             xh, wh, L.ptr(y), yh, pl.ref, None, L.ptr(bias), None, int(bool(relu)), L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc, 0, n_out, not fp32, fp32), "conv2d_forward_f16")
+            L.stream()), pl.desc, 0, n_out, yp is not None, bool(fp32)), "conv2d_forward_f16")
     else:
         L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
             xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, None, L.ptr(bias), None, int(bool(relu)), L.ptr(ws),
-            C.c_size_t(nbytes), L.stream()), pl.desc, 0, n_out, not fp32, fp32), "conv2d_forward_bf16x3")
+            C.c_size_t(nbytes), L.stream()), pl.desc, 0, n_out, yp is not None, bool(fp32)), "conv2d_forward_bf16x3")
+    if both:
+        return y, yp
     return y if fp32 else yp
 
 
-def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None):
+def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
+                         row_scale=None):
     """g: PlaneTensor of the output gradient (gradient planes: times 2^GRAD_SHIFT in fp16 mode); gate: PlaneTensor of
     the ReLU output the result is gated by (or None) -> the input gradient as fp32 tensor (fp32=True) or PlaneTensor."""
     pl = _plan(x_shape, w.shape, stride, pad, dil)
@@ -734,13 +738,13 @@ def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=
     if accumulate is not None:
         accumulate = _cl(accumulate)
     if MATH == "f16":
-        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_pgate_f16(
-            gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(accumulate), gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
-            pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_pgate_f16")
+        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_ex_f16(
+            gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(row_scale), L.ptr(accumulate), None, gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_ex_f16")
     else:
-        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_pgate_bf16x3(
-            gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(accumulate), gate_h, L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_pgate_bf16x3")
+        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_ex_bf16x3(
+            gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(row_scale), L.ptr(accumulate), None, gate_h, L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_ex_bf16x3")
     return dx if fp32 else dp
 
 

@@ -60,6 +60,51 @@ def channel_sum(g):
     return out
 
 
+def relu_backward_scaled(dy, y, scale):
+    """(g, planes buffer of g): g = y > 0 ? dy * scale : 0 — the backward of ReLU followed by inverted dropout when y is
+    the dropout's output and scale = 1 / (1 - p) (scale 1: a plain ReLU gate).  Needs numel % 8 == 0."""
+    from . import conv
+    L.require_gpu(dy, y)
+    y = y.contiguous()
+    dy = dy.contiguous()
+    g = torch.empty_like(y)
+    n = y.numel()
+    buf = conv._planes_buf(n, y.device)
+    hi, lo = conv._hl(buf)
+    L.note_bytes((14.0 if conv.MATH == "f16" else 16.0) * n)
+    L.check(L.lib().jtsm_relu_backward_split_scaled_f32(
+        L.ptr(dy), L.ptr(y), L.f32(scale), L.ptr(g), hi, lo, C.c_long(n), conv.GRAD_SHIFT if conv.MATH == "f16" else 0,
+        L.stream()), "relu_backward_split_scaled")
+    return g, buf
+
+
+def split_rowscale(x2d, row_scale):
+    """Planes buffer of x2d[r][c] * row_scale[r] (x2d dense (R, K), K % 8 == 0); the product itself is never stored."""
+    from . import conv
+    L.require_gpu(x2d, row_scale)
+    r, k = x2d.shape
+    buf = conv._planes_buf(r * k, x2d.device)
+    hi, lo = conv._hl(buf)
+    L.note_bytes((6.0 if conv.MATH == "f16" else 8.0) * r * k)
+    L.check(L.lib().jtsm_split_rowscale_f32(L.ptr(x2d), L.ptr(row_scale), C.c_long(r), k, hi, lo, 0, L.stream()),
+            "split_rowscale")
+    return buf
+
+
+def dropout_split_(y, p, seed):
+    """In place: y <- inverted dropout of y with the counter-based mask of `seed`; returns the planes buffer of the
+    result (numel % 8 == 0)."""
+    from . import conv
+    L.require_gpu(y)
+    n = y.numel()
+    buf = conv._planes_buf(n, y.device)
+    hi, lo = conv._hl(buf)
+    L.note_bytes((10.0 if conv.MATH == "f16" else 12.0) * n)
+    L.check(L.lib().jtsm_dropout_split_f32(L.ptr(y), L.ptr(y), hi, lo, C.c_long(n), L.f32(p), C.c_ulonglong(seed),
+                                           L.stream()), "dropout_split")
+    return buf
+
+
 def _cl4(x):
     if x.dim() != 4 or x.shape[1] % 4:
         raise RuntimeError("jtsm_amd spatial helpers need a (N,C,H,W) tensor with C %% 4 == 0, got %s" % (tuple(x.shape),))

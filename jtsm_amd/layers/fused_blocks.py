@@ -196,3 +196,87 @@ def mask_tower_fused(x, convs, deconv, predictor, want_features=True):
         params += [c.weight, c.bias]
     return _MaskTowerFn.apply(x, bool(want_features), *params, deconv.weight, deconv.bias, predictor.weight,
                               predictor.bias)
+
+
+class _FcStackFn(Function):
+    """The box head's fully connected stack (DiscriminativeAdaptionNeck, projects/WSL/wsl/modeling/roi_heads/
+    box_head.py; its input rescale: roi_heads_jtsm.py:607-633) as ONE autograd node:
+        x' = x * row_scale[r]            folded into the plane split of x (the product is never stored)
+        h_j = dropout(relu(fc_j(h_{j-1})))   one MFMA GEMM (bias + ReLU in its epilogue) + one pass that applies the
+                                             counter-based dropout mask in place and emits the planes for fc_{j+1}
+    Backward: the ReLU-and-dropout gate of every layer is ONE pass over dy (mask read off the stored output: positive
+    exactly where the unit was kept and active), and the input gradient leaves fc_1's data-gradient launch already
+    multiplied by row_scale (epilogue).  No torch multiply, dropout or masked-scale kernels.
+
+    apply(x (R, K) dense, row_scale (R,) | None, p, seeds, w_1, b_1, ..., w_k, b_k) -> h_k (R, out_k)."""
+
+    @staticmethod
+    def forward(ctx, x, row_scale, p, seeds, *params):
+        from .elementwise import dropout_split_, split_rowscale
+
+        k = len(params) // 2
+        r, kin = x.shape
+        if row_scale is not None:
+            hp = K.PlaneTensor(split_rowscale(x, row_scale), (r, kin, 1, 1))
+        else:
+            hp = K.PlaneTensor.of(x.view(r, kin, 1, 1))
+        hs, ys = [hp], []
+        for j in range(k):
+            w, b = params[2 * j], params[2 * j + 1]
+            w4 = w.view(w.shape[0], w.shape[1], 1, 1)
+            if p > 0:
+                y = K.planes_forward(hs[-1], w4, 1, 0, 1, b, True, fp32=True)
+                yp = K.PlaneTensor(dropout_split_(y, p, seeds[j]), y.shape)
+            else:
+                y, yp = K.planes_forward(hs[-1], w4, 1, 0, 1, b, True, fp32="both")
+            hs.append(yp)
+            ys.append(y)
+        out = ys[-1].view(r, -1)
+        K.planes_put(out, hs[-1].buf)              # the predictor GEMM behind the stack finds its operand planes
+        ctx.k, ctx.hs, ctx.inv_keep = k, hs[:-1], 1.0 / (1.0 - p)
+        ctx.row_scale = row_scale
+        ctx.save_for_backward(*ys, *params[0::2])
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        from .elementwise import channel_sum, relu_backward_scaled
+
+        k, hs = ctx.k, ctx.hs
+        ys, ws = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
+        need = ctx.needs_input_grad
+        grads = [None] * (2 * k)
+        dy = dout.contiguous().view(ys[-1].shape)
+        dx = None
+        for j in range(k - 1, -1, -1):
+            w = ws[j]
+            w4 = w.view(w.shape[0], w.shape[1], 1, 1)
+            g, gbuf = relu_backward_scaled(dy, ys[j], ctx.inv_keep)
+            gp = K.PlaneTensor(gbuf, ys[j].shape)
+            if need[4 + 2 * j]:
+                grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1).view(w.shape)
+            if need[5 + 2 * j]:
+                grads[2 * j + 1] = channel_sum(g.view(g.shape[0], -1))
+            if j > 0:
+                dy = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, fp32=True)
+            elif need[0]:
+                dx = K.planes_backward_data(gp, w4, hs[0].shape, 1, 0, 1, fp32=True, row_scale=ctx.row_scale)
+                dx = dx.view(dx.shape[0], -1)
+        return (dx, None, None, None) + tuple(grads)
+
+
+def fc_stack_ok(x2d, fcs):
+    """Plane arithmetic, dense fp32 rows, every width a multiple of 32 (whole 16-byte chunks and K stages)."""
+    if not (ENABLED and K.MATH != "f32" and x2d.is_cuda and x2d.dtype == torch.float32 and x2d.dim() == 2 and
+            x2d.is_contiguous() and x2d.shape[0] > 0 and x2d.shape[1] % 32 == 0 and len(fcs) > 0):
+        return False
+    return all(fc.bias is not None and fc.out_features % 32 == 0 and fc.in_features % 32 == 0 for fc in fcs)
+
+
+def fc_stack_fused(x2d, fcs, row_scale=None, p=0.0):
+    seeds = tuple(int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in fcs) if p > 0 else None
+    params = []
+    for fc in fcs:
+        params += [fc.weight, fc.bias]
+    return _FcStackFn.apply(x2d, row_scale, float(p), seeds, *params)

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 from torch import nn
 
+from ...layers.fused_blocks import fc_stack_fused, fc_stack_ok
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d, Linear
 from ...utils.registry import Registry
@@ -45,6 +46,7 @@ class DiscriminativeAdaptionNeck(nn.Module):
             self.fcs.append(fc)
             self._output_size = fc_dim
         self.dropout_p = 0.5
+        self.takes_roi_scale = True      # forward(x, roi_scale=...): see JTSMROIHeads._box_features
         self._register_load_state_dict_pre_hook(self._to_hwc_hook)
         self._register_state_dict_hook(self._to_chw_hook)
         for layer in self.fcs:
@@ -73,11 +75,17 @@ class DiscriminativeAdaptionNeck(nn.Module):
         if key in state_dict:
             state_dict[key] = module._hwc_cols(state_dict[key], False)
 
-    def forward(self, x):
+    def forward(self, x, roi_scale=None):
+        """roi_scale (R,), optional: the per-roi factor the features are multiplied by first
+        (roi_heads_jtsm.py:607-633) — folded into the fused stack's plane split and data-gradient epilogue."""
         if x.dim() == 4:
             if x.shape[2] * x.shape[3] > 1:
                 x = x.permute(0, 2, 3, 1)               # (h,w,c) order: a view of a channels_last tensor
             x = x.reshape(x.shape[0], -1)
+        if fc_stack_ok(x, self.fcs):                    # one autograd node (layers/fused_blocks.py: _FcStackFn)
+            return fc_stack_fused(x, self.fcs, roi_scale, self.dropout_p if self.training else 0.0)
+        if roi_scale is not None:
+            x = x * roi_scale.view(-1, 1)
         for k, fc in enumerate(self.fcs):
             x = fc(x, relu=True)                       # Linear + bias + ReLU: one MFMA GEMM launch
             if self.training and self.dropout_p > 0:

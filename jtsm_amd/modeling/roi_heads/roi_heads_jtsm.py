@@ -250,9 +250,12 @@ class JTSMROIHeads(ROIHeads):
             nvalid = (argmax[:, 0, :, :] != -1).reshape(argmax.size(0), -1).sum(dim=1).to(dtype=torch.float32)
             roi_scale = bins * (nvalid + 1).reciprocal()
             roi_scale = roi_scale * torch.cat([x.objectness_logits + 1 for x in proposals], dim=0)
-        # reference: (features * mask_scale) * (objectness + 1), two passes; here one combined factor
-        box_features = box_features * roi_scale.view(-1, 1, 1, 1)
-        box_features = self.box_head(box_features)
+        # reference: (features * mask_scale) * (objectness + 1), two passes; here one combined factor, which the box
+        # head folds into the plane split in front of fc1 and into fc1's data-gradient epilogue (no multiply pass)
+        if getattr(self.box_head, "takes_roi_scale", False):
+            box_features = self.box_head(box_features, roi_scale=roi_scale)
+        else:
+            box_features = self.box_head(box_features * roi_scale.view(-1, 1, 1, 1))
         return self._predictor_gemm(box_features), argmax
 
     @torch.no_grad()

@@ -422,6 +422,69 @@ def test_mask_tower_as_one_node_matches_layer_by_layer(cuda):
                 assert torch.equal(a, b), n          # the same launches, minus one store
 
 
+def test_fc_stack_as_one_node_matches_layer_by_layer(cuda):
+    """The box head's FC stack as one autograd node — the per-roi rescale folded into the plane split and into fc1's
+    data-gradient epilogue, ReLU + dropout gates as one pass — against the layer-by-layer form (explicit multiply,
+    Linear + ReLU per layer).  Dropout off: same arithmetic, same summation orders, the arithmetic's own bar.  Then
+    dropout on: the counter-based mask keeps ~(1 - p) of the units, scales the rest by 1 / (1 - p), is a function of
+    the seed alone, and the backward gates with exactly that mask."""
+    from jtsm_amd.layers import fused_blocks
+    from jtsm_amd.layers.elementwise import dropout_split_
+    from jtsm_amd.layers.shape_spec import ShapeSpec
+    from jtsm_amd.modeling.roi_heads.box_head import DiscriminativeAdaptionNeck
+
+    torch.manual_seed(4)
+    head = DiscriminativeAdaptionNeck(ShapeSpec(channels=32, height=2, width=2), fc_dims=[64, 96]).to(cuda)
+    with torch.no_grad():
+        for fc in head.fcs:
+            fc.weight.normal_(0, 0.1)
+            fc.bias.normal_(0, 0.2)
+    head.train()
+    head.dropout_p = 0.0
+    x0 = torch.randn(40, 32, 2, 2, device=cuda).contiguous(memory_format=CL)
+    rs = torch.rand(40, device=cuda) + 0.5
+    dout = torch.randn(40, 96, device=cuda)
+    out = {}
+    for fused in (False, True):
+        fused_blocks.ENABLED = fused
+        try:
+            K.planes_clear()
+            head.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            y = head(x, roi_scale=rs)
+            if K.MATH != "f32":
+                assert (type(y.grad_fn).__name__ == "_FcStackFnBackward") == fused
+            y.backward(dout)
+            out[fused] = [y.detach(), x.grad] + [p.grad.clone() for p in head.parameters()]
+        finally:
+            fused_blocks.ENABLED = True
+    names = ["out", "dx"] + [n for n, _ in head.named_parameters()]
+    for n, a, b in zip(names, out[True], out[False]):
+        close(a, b, "fc stack " + n, chain=True)
+    # ---- the dropout pass on its own
+    t = torch.rand(1 << 16, device=cuda) + 0.1
+    a, b, c = t.clone(), t.clone(), t.clone()
+    dropout_split_(a, 0.5, 1234)
+    dropout_split_(b, 0.5, 1234)
+    dropout_split_(c, 0.5, 1235)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    kept = a != 0
+    assert abs(float(kept.float().mean()) - 0.5) < 0.02 and torch.equal(a[kept], (t * 2.0)[kept])
+    if K.MATH == "f32":
+        return
+    # ---- dropout on, through the node: forward zeros = dropped or inactive units, gradient flows only through the rest
+    head.dropout_p = 0.5
+    K.planes_clear()
+    head.zero_grad(set_to_none=True)
+    x = x0.clone().requires_grad_()
+    y = head(x, roi_scale=rs)
+    y.backward(torch.ones_like(y))
+    frac = float((y == 0).float().mean())
+    assert 0.5 < frac < 0.95 and bool(torch.isfinite(x.grad).all())
+    g_b2 = head.fcs[-1].bias.grad                 # = sum over rows of (y > 0) * 1 / (1 - p)
+    close(g_b2, (y > 0).float().sum(0) * 2.0, "fc stack dropout bias gradient")
+
+
 @pytest.mark.parametrize("shape", [
     (2, 256, 256, 256, 256, 3, 1, 1),      # FPN p2 output conv (256x256 tiles, no split)
     (2, 1024, 64, 64, 256, 1, 1, 0),       # res4 1x1 (split-K, wide epilogue)
