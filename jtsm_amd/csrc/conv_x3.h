@@ -1057,6 +1057,8 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
+  JTSM_REQUIRE((!p.mask_plane && !p.scale_rows && p.C) || p.wide,
+               "conv bf16x3: a gate plane, a row scale or a planes-only result needs N %% 4 == 0 and 16-byte aligned tensors");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
   const bool fused = use_fused_finish(p, ntiles, splits, st);
   if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
@@ -1124,6 +1126,8 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
+  JTSM_REQUIRE((!p.mask_plane && !p.scale_rows && p.C) || p.wide,
+               "conv bf16x3: a gate plane, a row scale or a planes-only result needs N %% 4 == 0 and 16-byte aligned tensors");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
   const bool fused = use_fused_finish(p, ntiles, splits, st);
   if (BIG) hipLaunchKernelGGL((igemm_x3_halo_kernel<ROLE, 16, 4, 2, 4, 21, NP>), grid, dim3(512), 0, st, p, q);

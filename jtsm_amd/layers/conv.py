@@ -683,7 +683,7 @@ class PlaneTensor(object):
         return PlaneTensor(_planes_buf(n, device), shape)
 
 
-def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=False):
+def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=False, scale=None, residual=None):
     """x: PlaneTensor -> PlaneTensor of relu?(conv(x, w) + bias) (fp32=False: planes only, no fp32 copy is written), or
     the fp32 result alone (fp32=True: a chain's last layer, read by a loss)."""
     pl = _plan(x.shape, w.shape, stride, pad, dil)
@@ -701,31 +701,37 @@ def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=Fal
     ws = _scratch(nbytes, x.device)
     lib = L.lib()
     n_out = s.batch * s.out_c * pl.oh * pl.ow
+    if residual is not None:
+        residual = _cl(residual)
     if MATH == "f16":
         L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f16(
-            xh, wh, L.ptr(y), yh, pl.ref, None, L.ptr(bias), None, int(bool(relu)), L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc, 0, n_out, yp is not None, bool(fp32)), "conv2d_forward_f16")
+            xh, wh, L.ptr(y), yh, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual), n_out, yp is not None, bool(fp32)),
+                "conv2d_forward_f16")
     else:
         L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_bf16x3(
-            xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, None, L.ptr(bias), None, int(bool(relu)), L.ptr(ws),
-            C.c_size_t(nbytes), L.stream()), pl.desc, 0, n_out, yp is not None, bool(fp32)), "conv2d_forward_bf16x3")
+            xh, xl, wh, wl, L.ptr(y), yh, yl, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)),
+            L.ptr(ws), C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual), n_out, yp is not None, bool(fp32)),
+                "conv2d_forward_bf16x3")
     if both:
         return y, yp
     return y if fp32 else yp
 
 
 def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
-                         row_scale=None):
+                         row_scale=None, kscale=None, both=False):
+    """... kscale: per-output-channel factor folded into the weight rows (FrozenBN).  both: fp32 AND planes."""
     """g: PlaneTensor of the output gradient (gradient planes: times 2^GRAD_SHIFT in fp16 mode); gate: PlaneTensor of
     the ReLU output the result is gated by (or None) -> the input gradient as fp32 tensor (fp32=True) or PlaneTensor."""
     pl = _plan(x_shape, w.shape, stride, pad, dil)
     s = pl.s
     if not pl.x3[1]:
         raise RuntimeError("planes_backward_data: shape is not eligible for the plane arithmetic")
+    fp32 = fp32 or both
     dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=g.device, memory_format=CL) if fp32 else None
-    dp = None if fp32 else PlaneTensor.empty(x_shape, g.device)
+    dp = PlaneTensor.empty(x_shape, g.device) if (both or not fp32) else None
     gh, gl = _hl(g.buf)
-    wh, wl = _hl(_weight_planes(_cl(w), True, None))
+    wh, wl = _hl(_weight_planes(_cl(w), True, kscale))
     dh, dl = _hl(dp.buf if dp is not None else None)
     gate_h = _hl(gate.buf)[0] if gate is not None else None
     nbytes = pl.ws[1]
@@ -740,15 +746,17 @@ def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=
     if MATH == "f16":
         L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_ex_f16(
             gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(row_scale), L.ptr(accumulate), None, gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
-            pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_ex_f16")
+            pl.desc, extra, n_in, dp is not None, fp32), "conv2d_backward_data_ex_f16")
     else:
         L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_ex_bf16x3(
             gh, gl, wh, wl, L.ptr(dx), dh, dl, pl.ref, L.ptr(row_scale), L.ptr(accumulate), None, gate_h, L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc, extra, n_in, not fp32, fp32), "conv2d_backward_data_ex_bf16x3")
+            L.stream()), pl.desc, extra, n_in, dp is not None, fp32), "conv2d_backward_data_ex_bf16x3")
+    if both:
+        return dx, dp
     return dx if fp32 else dp
 
 
-def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None):
+def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_scale=None):
     """dW from the planes of the output gradient g and of the input x; written into the parameter's gradient slot when
     the data-parallel exchange registered one."""
     w_shape = tuple(w.shape) if w_shape is None else tuple(w_shape)
@@ -768,11 +776,11 @@ def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None):
     lib = L.lib()
     if MATH == "f16":
         L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_f16(
-            gh, xh, L.ptr(out), pl.ref, None, 1, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            gh, xh, L.ptr(out), pl.ref, L.ptr(row_scale), 1, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
             pl.desc, 0, out.numel()), "conv2d_backward_weight_f16")
     else:
         L.check(_timed(_x3_variant(s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bf16x3(
-            gh, gl, xh, xl, L.ptr(out), pl.ref, None, 1, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
+            gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), 1, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
             pl.desc, 0, out.numel()), "conv2d_backward_weight_bf16x3")
     return out
 

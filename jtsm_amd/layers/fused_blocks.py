@@ -40,19 +40,36 @@ def _same_strides(dw, w):
 
 
 class _BottleneckFn(Function):
+    """In the plane arithmetics the two inner activations (conv1 / conv2 outputs) exist as operand planes only
+    (layers/conv.py: PlaneTensor): no fp32 copy is written, their ReLU gates are read from the hi plane in the
+    data-gradient epilogues.  The block input and output stay fp32 (the residual stream keeps full precision)."""
+
     @staticmethod
     def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, ws, ss, bs, stride1, stride2, pad2, dil2, stride_s):
+        ctx.cfg = (stride1, stride2, pad2, dil2, stride_s)
+        ctx.planes = K.MATH != "f32" and _plane_block_ok(x, w1, w2, w3, ws)
+        if ctx.planes:
+            xp = K.PlaneTensor.of(x)
+            y1 = K.planes_forward(xp, w1, stride1, 0, 1, b1, True, scale=s1)
+            y2 = K.planes_forward(y1, w2, stride2, pad2, dil2, b2, True, scale=s2)
+            sc = x if ws is None else K.planes_forward(xp, ws, stride_s, 0, 1, bs, False, fp32=True, scale=ss)
+            y3, y3p = K.planes_forward(y2, w3, 1, 0, 1, b3, True, fp32="both", scale=s3, residual=sc)
+            K.planes_put(y3, y3p.buf)
+            ctx.inner = (xp, y1, y2)
+            ctx.save_for_backward(x, y3, w1, s1, w2, s2, w3, s3, ws, ss)
+            return y3
         y1 = K.conv2d_forward(x, w1, stride1, 0, 1, s1, b1, None, True, emit_planes=True)
         y2 = K.conv2d_forward(y1, w2, stride2, pad2, dil2, s2, b2, None, True, emit_planes=True)
         sc = x if ws is None else K.conv2d_forward(x, ws, stride_s, 0, 1, ss, bs, None, False)
         y3 = K.conv2d_forward(y2, w3, 1, 0, 1, s3, b3, sc, True, emit_planes=True)
-        ctx.cfg = (stride1, stride2, pad2, dil2, stride_s)
         ctx.save_for_backward(x, y1, y2, y3, w1, s1, w2, s2, w3, s3, ws, ss)
         return y3
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        if ctx.planes:
+            return _BottleneckFn._backward_planes(ctx, dy)
         x, y1, y2, y3, w1, s1, w2, s2, w3, s3, ws, ss = ctx.saved_tensors
         stride1, stride2, pad2, dil2, stride_s = ctx.cfg
         need = ctx.needs_input_grad
@@ -84,6 +101,49 @@ class _BottleneckFn(Function):
                 dx = dx.add_(_dgrad(g3, ws, ss, xs, stride_s, 0, 1))
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
                 None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None)
+
+    @staticmethod
+    def _backward_planes(ctx, dy):
+        x, y3, w1, s1, w2, s2, w3, s3, ws, ss = ctx.saved_tensors
+        xp, y1, y2 = ctx.inner
+        stride1, stride2, pad2, dil2, stride_s = ctx.cfg
+        need = ctx.needs_input_grad
+        dx = dw1 = dw2 = dw3 = dws = None
+        g3 = relu_backward(dy, y3, emit_planes=True)                      # the block's own output gate (fp32 + planes)
+        g3p = K.PlaneTensor.of(g3, grad=True)
+        if need[7]:
+            dw3 = K.planes_backward_weight(g3p, y2, w3, 1, 0, 1, row_scale=s3)
+        d2 = K.planes_backward_data(g3p, w3, y2.shape, 1, 0, 1, gate=y2, kscale=s3)      # gated by conv2's ReLU
+        if need[4]:
+            dw2 = K.planes_backward_weight(d2, y1, w2, stride2, pad2, dil2, row_scale=s2)
+        d1 = K.planes_backward_data(d2, w2, y1.shape, stride2, pad2, dil2, gate=y1, kscale=s2)
+        if need[1]:
+            dw1 = K.planes_backward_weight(d1, xp, w1, stride1, 0, 1, row_scale=s1)
+        if ws is not None and need[10]:
+            dws = K.planes_backward_weight(g3p, xp, ws, stride_s, 0, 1, row_scale=ss)
+        if need[0]:
+            xs = tuple(x.shape)
+            if ws is None:
+                dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=g3, kscale=s1)
+            elif stride1 == 1 and stride_s == 1:
+                dxs = K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss)
+                dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=dxs, kscale=s1)
+            else:
+                dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, kscale=s1)
+                dx = dx.add_(K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss))
+        return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
+                None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None)
+
+
+def _plane_block_ok(x, w1, w2, w3, ws):
+    """Every contraction of the block eligible for the plane kernels in all three roles (whole 32-channel K stages,
+    16-byte rows), a non-empty batch."""
+    if x.shape[0] == 0 or not x.is_cuda:
+        return False
+    for w in (w1, w2, w3, ws):
+        if w is not None and (w.shape[0] % 32 or w.shape[1] % 32):
+            return False
+    return True
 
 
 def bottleneck_fused(x, w1, sb1, w2, sb2, w3, sb3, ws, sbs, stride1, stride2, pad2, dil2, stride_s):
