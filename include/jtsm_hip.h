@@ -411,6 +411,11 @@ int jtsm_dropout_split_f32(const float* x, float* y, uint16_t* y_hi, uint16_t* y
                            unsigned long long seed, void* stream);
 int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, long rows, int C, int shift,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* Up to 8 such gradients of one width C in a single launch (+ one fold): hi[i] / lo[i] (lo NULL: fp16 planes) with
+ * rows[i] rows each -> outs[i][C]; workspace of count * 1024 * C floats. */
+int jtsm_channel_sum_planes_multi(const uint16_t* const* hi, const uint16_t* const* lo, float* const* outs,
+                                  const long* rows, int count, int C, int shift, void* workspace,
+                                  size_t workspace_bytes, void* stream);
 /* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */
 int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
                                  void* stream);

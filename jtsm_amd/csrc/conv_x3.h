@@ -1079,7 +1079,8 @@ inline int x3_tile_choice(const Params& p) {
   // 256x256 pays once its (fewer, larger) workgroups still fill the chip and K is deep enough to amortise them
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
   const int ktiles = ceil_div(p.K, XBK);
-  constexpr long min_work = 9216;   // tiles x stages (measured crossover, tools/sweeps/x3_sweep.py + layer timings)
+  // tiles x stages (measured crossover, tools/sweeps/x3_sweep.py + layer timings; JTSM_X3_MIN_WORK overrides for sweeps)
+  static const long min_work = [] { const char* e = getenv("JTSM_X3_MIN_WORK"); return e ? atol(e) : 9216L; }();
   if (p.N >= 192 && t256 * ktiles >= min_work && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
   return 0;
 }

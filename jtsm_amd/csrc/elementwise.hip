@@ -200,40 +200,65 @@ __global__ __launch_bounds__(256) void channel_sum4_kernel(const float4* __restr
 // owns eight channels (16 bytes per plane), slabs and fold as above.  For gradients a chain keeps as planes only.
 typedef __bf16 ew_bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 ew_h8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void channel_sum_planes_kernel(const unsigned short* __restrict__ hi,
-                                                                 const unsigned short* __restrict__ lo,
-                                                                 float* __restrict__ part, long rows, int C8,
-                                                                 long rows_per_block, float unshift) {
-  __shared__ float red[4][64][9];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int c8 = blockIdx.x * 64 + lane;
+// Up to kCsumMulti gradients of the same width in ONE launch (blockIdx.z = which): the bias gradients of a chain's
+// layers (the mask tower) are summed together when the chain's backward is over, one launch + one fold instead of one
+// pair per layer.
+constexpr int kCsumMulti = 8;
+struct CsumPlanes {
+  const unsigned short* hi[kCsumMulti];
+  const unsigned short* lo[kCsumMulti];
+  float* out[kCsumMulti];
+  long rows[kCsumMulti];
+  long rows_per_block[kCsumMulti];
+  int nslab[kCsumMulti];
+  int n;
+};
+__global__ __launch_bounds__(256) void channel_sum_planes_kernel(const CsumPlanes q, float* __restrict__ part_all,
+                                                                 int max_slab, int C8, float unshift, int cols8) {
+  const int which = blockIdx.z;
+  if ((int)blockIdx.y >= q.nslab[which]) return;
+  const unsigned short* __restrict__ hi = q.hi[which];
+  const unsigned short* __restrict__ lo = q.lo[which];
+  float* __restrict__ part = part_all + (size_t)which * max_slab * C8 * 8;
+  const long rows = q.rows[which], rows_per_block = q.rows_per_block[which];
+  // cols8 <= 256 eight-channel groups per workgroup, 256 / cols8 rows per trip: every lane busy whatever the width
+  // (C = 256 is 32 groups: 8 rows per trip), 32 bytes per lane per row in flight x 2 trips unrolled
+  __shared__ float red[256][9];
+  const int tid = threadIdx.x, rpi = 256 / cols8;
+  const int cl = tid % cols8, rg = tid / cols8;
+  const int c8 = blockIdx.x * cols8 + cl;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float acc[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-  if (c8 < C8) {
-    for (long r = r0 + wv; r < r1; r += 4) {
-      const size_t o = ((size_t)r * C8 + c8) * 8;
-      if (lo) {
-        const ew_bf16x8 a = *reinterpret_cast<const ew_bf16x8*>(hi + o), b = *reinterpret_cast<const ew_bf16x8*>(lo + o);
+  auto add_row = [&](long r) {
+    const size_t o = ((size_t)r * C8 + c8) * 8;
+    if (lo) {
+      const ew_bf16x8 a = *reinterpret_cast<const ew_bf16x8*>(hi + o), b = *reinterpret_cast<const ew_bf16x8*>(lo + o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += (float)a[j] + (float)b[j];
-      } else {
-        const ew_h8 a = *reinterpret_cast<const ew_h8*>(hi + o);
+      for (int j = 0; j < 8; ++j) acc[j] += (float)a[j] + (float)b[j];
+    } else {
+      const ew_h8 a = *reinterpret_cast<const ew_h8*>(hi + o);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
-      }
+      for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
     }
+  };
+  if (rg < rpi && c8 < C8) {
+    long r = r0 + rg;
+    for (; r + rpi < r1; r += 2 * rpi) { add_row(r); add_row(r + rpi); }
+    for (; r < r1; r += rpi) add_row(r);
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) red[wv][lane][j] = acc[j];
+  for (int j = 0; j < 8; ++j) red[tid][j] = acc[j];
   __syncthreads();
-  if (wv == 0 && c8 < C8) {
+  if (rg == 0 && c8 < C8) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j)
-      part[(size_t)blockIdx.y * C8 * 8 + c8 * 8 + j] =
-          ((red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j])) * unshift;
+    for (int j = 0; j < 8; ++j) {
+      float t = 0.f;
+      for (int k = 0; k < rpi; ++k) t += red[k * cols8 + cl][j];
+      part[(size_t)blockIdx.y * C8 * 8 + c8 * 8 + j] = t * unshift;
+    }
   }
 }
 // Any C (not a multiple of 4, narrower than 128, few rows): `cols` <= 256 columns per workgroup, 256 / cols row groups
@@ -260,6 +285,26 @@ __global__ __launch_bounds__(256) void channel_sum_slab_kernel(const float* __re
 }
 // out[c] = sum_s part[s][c], slabs in a fixed order: a workgroup folds 16 channels, 16 threads per channel each
 // taking every 16th slab, then the 16 partial sums are added in order.
+__global__ __launch_bounds__(256) void channel_sum_fold_multi_kernel(const CsumPlanes q, const float* __restrict__ part_all,
+                                                                     int max_slab, int C) {
+  __shared__ float red[16][17];
+  const int which = blockIdx.y, slabs = q.nslab[which];
+  const float* __restrict__ part = part_all + (size_t)which * max_slab * C;
+  float* __restrict__ out = q.out[which];
+  const int cl = threadIdx.x & 15, j = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float a = 0.f;
+  if (c < C)
+    for (int s = j; s < slabs; s += 16) a += part[(size_t)s * C + c];
+  red[j][cl] = a;
+  __syncthreads();
+  if (j == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][cl];
+    out[c] = t;
+  }
+}
 __global__ __launch_bounds__(256) void channel_sum_fold_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                                int C, int slabs) {
   __shared__ float red[16][17];
@@ -670,33 +715,58 @@ int jtsm_channel_sum_ws_f32(const float* g, float* out, long rows, int C, void* 
   return JTSM_OK;
 }
 
-int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, long rows, int C, int shift,
-                            void* workspace, size_t workspace_bytes, void* stream) {
-  JTSM_REQUIRE(rows >= 0 && C > 0 && C % 8 == 0, "channel_sum_planes: C must be a positive multiple of 8");
-  JTSM_REQUIRE(out, "channel_sum_planes: null out");
+static void csum_planes_plan(long rows, int C, long* rpb, int* nslab) {
+  const int cols8 = C / 8 < 256 ? C / 8 : 256;
+  const int cg = ceil_div(C / 8, cols8);
+  long slabs = 1024 / cg;
+  if (slabs > (rows + 63) / 64) slabs = (rows + 63) / 64;
+  if (slabs < 1) slabs = 1;
+  *rpb = (rows + slabs - 1) / slabs;
+  *nslab = (int)((rows + *rpb - 1) / *rpb);
+}
+
+int jtsm_channel_sum_planes_multi(const uint16_t* const* hi, const uint16_t* const* lo, float* const* outs,
+                                  const long* rows, int count, int C, int shift, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(count >= 1 && count <= kCsumMulti && hi && outs && rows, "channel_sum_planes: 1..8 gradients per call");
+  JTSM_REQUIRE(C > 0 && C % 8 == 0, "channel_sum_planes: C must be a positive multiple of 8");
   JTSM_REQUIRE(shift >= 0 && shift <= 24, "channel_sum_planes: shift must be in 0..24");
   hipStream_t st = as_stream(stream);
-  if (rows == 0) {
-    JTSM_CHECK_HIP(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
-    return JTSM_OK;
+  CsumPlanes q = {};
+  int max_slab = 0;
+  for (int i = 0; i < count; ++i) {
+    JTSM_REQUIRE(rows[i] >= 0 && outs[i], "channel_sum_planes: bad entry %d", i);
+    if (rows[i] == 0) {
+      JTSM_CHECK_HIP(hipMemsetAsync(outs[i], 0, (size_t)C * sizeof(float), st));
+      continue;
+    }
+    JTSM_REQUIRE(hi[i] && ((uintptr_t)hi[i] & 15) == 0 && (!lo || ((uintptr_t)lo[i] & 15) == 0),
+                 "channel_sum_planes: planes must be non-null and 16-byte aligned");
+    const int k = q.n++;
+    q.hi[k] = hi[i]; q.lo[k] = lo ? lo[i] : nullptr; q.out[k] = outs[i]; q.rows[k] = rows[i];
+    csum_planes_plan(rows[i], C, &q.rows_per_block[k], &q.nslab[k]);
+    if (q.nslab[k] > max_slab) max_slab = q.nslab[k];
   }
-  JTSM_REQUIRE(hi && ((uintptr_t)hi & 15) == 0 && ((uintptr_t)lo & 15) == 0, "channel_sum_planes: planes must be 16-byte aligned");
-  const int cg = ceil_div(C / 8, 64);
-  long slabs = 1024 / cg;
-  if (slabs > (rows + 31) / 32) slabs = (rows + 31) / 32;
-  if (slabs < 1) slabs = 1;
-  const long rpb = (rows + slabs - 1) / slabs;
-  const int nslab = (int)((rows + rpb - 1) / rpb);
-  JTSM_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)nslab * C * sizeof(float),
-               "channel_sum_planes: workspace of %zu bytes needed (1024 x C floats always suffice)",
-               (size_t)nslab * C * sizeof(float));
+  if (q.n == 0) return JTSM_OK;
+  const size_t need = (size_t)q.n * max_slab * C * sizeof(float);
+  JTSM_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= need,
+               "channel_sum_planes: workspace of %zu bytes needed (count x 1024 x C floats always suffice)", need);
   float* part = reinterpret_cast<float*>(workspace);
+  const int cols8 = C / 8 < 256 ? C / 8 : 256;
+  const int cg = ceil_div(C / 8, cols8);
   const float unshift = __builtin_ldexpf(1.f, -shift);
-  hipLaunchKernelGGL(channel_sum_planes_kernel, dim3(cg, (unsigned)nslab), dim3(256), 0, st, hi, lo, part, rows, C / 8,
-                     rpb, unshift);
-  hipLaunchKernelGGL(channel_sum_fold_kernel, dim3(ceil_div(C, 16)), dim3(256), 0, st, part, out, C, nslab);
+  hipLaunchKernelGGL(channel_sum_planes_kernel, dim3(cg, (unsigned)max_slab, (unsigned)q.n), dim3(256), 0, st, q, part,
+                     max_slab, C / 8, unshift, cols8);
+  hipLaunchKernelGGL(channel_sum_fold_multi_kernel, dim3(ceil_div(C, 16), (unsigned)q.n), dim3(256), 0, st, q, part,
+                     max_slab, C);
   JTSM_CHECK_LAUNCH("channel_sum_planes");
   return JTSM_OK;
+}
+
+int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, long rows, int C, int shift,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  return jtsm_channel_sum_planes_multi(&hi, lo ? &lo : nullptr, &out, &rows, 1, C, shift, workspace, workspace_bytes,
+                                       stream);
 }
 
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream) {

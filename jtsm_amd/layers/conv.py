@@ -800,6 +800,27 @@ def planes_channel_sum(g, grad=True):
     return out
 
 
+def planes_channel_sum_multi(gs, grad=True):
+    """planes_channel_sum of up to 8 gradients of the same width in one launch (+ one fold) -> list of (C,) tensors."""
+    if not gs:
+        return []
+    ch = gs[0].shape[1]
+    assert all(g.shape[1] == ch for g in gs) and len(gs) <= 8
+    n = len(gs)
+    outs = torch.empty((n, ch), dtype=torch.float32, device=gs[0].device)
+    nbytes = 4 * 1024 * ch * n
+    ws = _scratch(nbytes, gs[0].device)
+    his = (C.c_void_p * n)(*[g.buf.data_ptr() for g in gs])
+    los = None if MATH == "f16" else (C.c_void_p * n)(*[g.buf.data_ptr() + g.buf.numel() for g in gs])
+    optr = (C.c_void_p * n)(*[outs[i].data_ptr() for i in range(n)])
+    rows = (C.c_long * n)(*[g.numel // ch for g in gs])
+    L.note_bytes((2.0 if MATH == "f16" else 4.0) * sum(g.numel for g in gs))
+    L.check(L.lib().jtsm_channel_sum_planes_multi(his, los, optr, rows, n, ch,
+                                                  GRAD_SHIFT if (grad and MATH == "f16") else 0, L.ptr(ws),
+                                                  C.c_size_t(nbytes), L.stream()), "channel_sum_planes_multi")
+    return [outs[i] for i in range(n)]
+
+
 def planes_conv_transpose2x2_forward(x, w, bias=None, relu=False, fp32=False):
     """conv_transpose2x2_forward on a PlaneTensor -> PlaneTensor of y (or the fp32 y with fp32=True)."""
     n, i, h, wd = x.shape

@@ -206,11 +206,12 @@ class _MaskTowerFn(Function):
             gu = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up, accumulate=du)
         else:
             gu = K.PlaneTensor(relu_backward_planes(du, up), up.shape)
-        # ---- transposed convolution
+        # ---- transposed convolution (bias gradients: all layers' gradient planes are summed in ONE launch at the end)
+        bias_of = []                                   # (slot in grads, gradient planes)
         if need[2 * k]:
             grads[2 * k] = K.planes_conv_transpose2x2_backward_weight(gu, hs[k], wd)
         if need[2 * k + 1]:
-            grads[2 * k + 1] = K.planes_channel_sum(gu)
+            bias_of.append((2 * k + 1, gu))
         g = K.planes_conv_transpose2x2_backward_data(gu, wd, gate=hs[k] if k > 0 else None)
         # ---- the 3x3 tower, last layer first
         dx = None
@@ -219,13 +220,21 @@ class _MaskTowerFn(Function):
             if need[2 * j]:
                 grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1)
             if need[2 * j + 1]:
-                grads[2 * j + 1] = K.planes_channel_sum(g)
+                bias_of.append((2 * j + 1, g))
             if j > 0:
                 g = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j])
             elif ctx.needs_input_grad[0]:
                 dx = K.planes_backward_data(g, w, ctx.xshape, 1, 1, 1, fp32=True)
         if k == 0 and ctx.needs_input_grad[0]:
             raise NotImplementedError("mask tower without 3x3 layers")   # (mask_tower_ok requires k >= 1)
+        by_width = {}
+        for slot, gp in bias_of:
+            by_width.setdefault(gp.shape[1], []).append((slot, gp))
+        for group in by_width.values():
+            for i0 in range(0, len(group), 8):
+                part = group[i0:i0 + 8]
+                for (slot, _), db in zip(part, K.planes_channel_sum_multi([gp for _, gp in part])):
+                    grads[slot] = db
         return (dx, None) + tuple(grads)
 
 
