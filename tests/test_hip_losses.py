@@ -260,3 +260,33 @@ def test_mask_bce_matches_torch(cuda, classes, pad):
     gd = zd.grad.cpu()
     assert torch.allclose(gd[:, :classes], z0.grad, rtol=1e-5, atol=1e-9)
     assert float(gd[:, classes:].abs().sum()) == 0.0
+
+
+def test_paste_crop_targets_bit_exact_vs_paste_then_roi_align(cuda):
+    """The mask refinery's targets (get_pgt_mask, roi_heads_jtsm.py:1997-2022): class probability pasted into the image
+    at the box, cropped back at 28x28 by BitMasks.crop_and_resize.  The kernel evaluates the pasted image analytically
+    at every ROIAlign tap (nothing is rasterised); the oracle rasterises the full-size paste (oracle/inference.py:
+    paste_masks_in_image) and runs the C restatement of ROIAlign over it.  Bits must agree exactly — boxes inside,
+    across and partly outside the image, tiny and large."""
+    from jtsm_amd.layers.mining import paste_crop_targets
+    from oracle import pooling as P
+    from oracle.inference import paste_masks_in_image
+
+    g = torch.Generator().manual_seed(21)
+    H, W, n = 700, 820, 24
+    prob = torch.rand(n, 28, 28, generator=g)
+    prob[3] = 1.0
+    prob[4] = 0.0
+    cx, cy = torch.rand(n, generator=g) * W, torch.rand(n, generator=g) * H
+    bw, bh = torch.rand(n, generator=g) * 260 + 3, torch.rand(n, generator=g) * 260 + 3
+    boxes = torch.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1)
+    boxes[0] = torch.tensor([-40.0, -30.0, 90.5, 120.25])          # partly outside
+    boxes[1] = torch.tensor([5.0, 6.0, 7.5, 9.0])                  # tiny
+    boxes[2] = torch.tensor([10.0, 12.0, 800.0, 690.0])            # nearly the whole image
+    got = paste_crop_targets(prob.to(cuda), boxes.to(cuda), 28, H, W, 0.5).cpu()
+    pasted = paste_masks_in_image(prob, boxes, (H, W), 0.5).to(torch.float32)
+    rr = torch.cat([torch.arange(n, dtype=torch.float32)[:, None], boxes], 1)
+    want = torch.from_numpy(P.roi_align_forward(pasted[:, None].numpy(), rr.numpy(), 1.0, 28, 28, 0, True))[:, 0] >= 0.5
+    assert got.shape == want.shape and got.dtype == torch.bool
+    assert torch.equal(got, want), int((got != want).sum())
+    assert 0.2 < float(want.float().mean()) < 0.8

@@ -43,6 +43,11 @@ def linear_stock(x, w, bias=None, relu=False, bias_needs_grad=True):
     return F.relu(y) if relu else y
 
 
+def linear_split_stock(x, weights, biases, relu=False):
+    """The predictors as the reference runs them: one F.linear per head."""
+    return tuple(linear_stock(x, w, b, relu) for w, b in zip(weights, biases))
+
+
 def mil_stock(cls_logits, det_logits, bag_offsets, labels, mean_loss=True, max_bag_rows=None):
     off = bag_offsets.tolist()
     counts = [b - a for a, b in zip(off[:-1], off[1:])]
@@ -80,8 +85,18 @@ def patch_to_stock():
     import jtsm_amd.modeling.roi_heads.fast_rcnn_tsm as tsm
     import jtsm_amd.modeling.roi_heads.roi_heads_jtsm as rh
 
+    import jtsm_amd.layers.fused_blocks as fb
+
+    # every fused autograd node of this repo (bottleneck, mask tower, FC stack) calls the contraction kernels directly:
+    # switch them off so each layer goes through conv2d_fused / linear_fused below.  (Before round 2's fix this file
+    # left the bottleneck node on, i.e. the "stock" backbone ran this repo's kernels: the figures of round 1 —
+    # 11.9-16.5 images/sec — and the first half of round 2 were therefore too HIGH, see profiles/.)
+    fb.ENABLED = False
+    fb.MASK_TOWER = False
+    wr.conv_transpose2x2_ok = lambda x, w: False       # ConvTranspose2d: the GEMM (stock below) + torch pixel shuffle
     conv.conv2d_fused = wr.conv2d_fused = conv2d_stock
     conv.linear_fused = wr.linear_fused = rh.linear_fused = linear_stock
+    conv.linear_fused_split = rh.linear_fused_split = linear_split_stock
     resnet.max_pool_3x3_s2 = lambda x: F.max_pool2d(x, 3, 2, 1)
     fpn.upsample2_add = lambda top, lat: lat + F.interpolate(top, scale_factor=2.0, mode="nearest")
     fpn.subsample2 = lambda x: F.max_pool2d(x, 1, 2, 0)
@@ -124,6 +139,15 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # self-check: one step with the contraction log on must record NO launch of this repo's contraction kernels
+    import jtsm_amd.layers.conv as conv
+    conv.LAUNCH_LOG = []
+    step()
+    torch.cuda.synchronize()
+    leaked, conv.LAUNCH_LOG = conv.LAUNCH_LOG, None
+    if leaked:
+        raise SystemExit("stock_baseline: %d contraction launches of libjtsm_hip.so in the 'stock' step (first: %s)"
+                         % (len(leaked), leaked[0][0]))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = step()
