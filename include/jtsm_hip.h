@@ -416,6 +416,19 @@ int jtsm_channel_sum_planes(const uint16_t* hi, const uint16_t* lo, float* out, 
 int jtsm_channel_sum_planes_multi(const uint16_t* const* hi, const uint16_t* const* lo, float* const* outs,
                                   const long* rows, int count, int C, int shift, void* workspace,
                                   size_t workspace_bytes, void* stream);
+/* The weight gradient AND the bias gradient db[out_c] = sum over output pixels of dy (ATen convolution_backward's
+ * third result / nn.Linear's bias gradient) in one contraction: the workgroups of the first column tile run one extra
+ * matrix instruction per dy fragment against an all-ones fragment, so dy is not read a second time.  db comes from the
+ * same planes as dW (hi + lo, or the fp16 plane times 2^-grad_shift).  Workspace:
+ * jtsm_conv_bf16x3_wgrad_bias_workspace_bytes (the slabs of jtsm_conv_bf16x3_wgrad_workspace_bytes + the bias partials). */
+size_t jtsm_conv_bf16x3_wgrad_bias_workspace_bytes(const jtsm_conv_shape* s);
+int jtsm_conv2d_backward_weight_bias_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
+                                            const uint16_t* x_lo, float* dw, float* db, const jtsm_conv_shape* s,
+                                            const float* row_scale, int zero_dw, void* workspace,
+                                            size_t workspace_bytes, void* stream);
+int jtsm_conv2d_backward_weight_bias_f16(const uint16_t* dy_h, const uint16_t* x_h, float* dw, float* db,
+                                         const jtsm_conv_shape* s, const float* row_scale, int zero_dw, int grad_shift,
+                                         void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */
 int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
                                  void* stream);

@@ -35,7 +35,7 @@ def lib():
         _lib.jtsm_moi_pool_workspace_bytes.restype = C.c_size_t
         for name in ("jtsm_mil_workspace_bytes", "jtsm_oicr_workspace_bytes", "jtsm_conv_workspace_bytes", "jtsm_conv_transpose2x2_workspace_bytes",
                      "jtsm_group_norm_workspace_bytes", "jtsm_semseg_ce_workspace_bytes",
-                     "jtsm_conv_bf16x3_wgrad_workspace_bytes", "jtsm_moi_pool_levels_workspace_bytes",
+                     "jtsm_conv_bf16x3_wgrad_workspace_bytes", "jtsm_conv_bf16x3_wgrad_bias_workspace_bytes", "jtsm_moi_pool_levels_workspace_bytes",
                      "jtsm_paint_sem_seg_workspace_bytes", "jtsm_mask_bce_workspace_bytes",
                      "jtsm_moi_pool_backward_levels_workspace_bytes", "jtsm_channel_sum_workspace_bytes",
                      "jtsm_pool_f16_workspace_bytes", "jtsm_moi_pool_f16_workspace_bytes"):

@@ -90,6 +90,10 @@ struct Params {
   // (C == null: the fp32 result is not stored at all; needs out_hi).
   const unsigned short* mask_plane;
   int scale_rows;   // FWD / DGRAD: e.scale holds one factor per output ROW (pixel / roi), not per column
+  // WGRAD: bias gradient computed beside dW (conv_x3.h: x3_bias_mma): per-slice partial sums bias_slab[slice][M]
+  // (the result itself when there is one slice), folded into bias_out[M] by the finishing pass.
+  float* bias_slab;
+  float* bias_out;
   ConvShape s;
   Epilogue e;
 };
@@ -1008,6 +1012,18 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // LDS; with one thread per piece those launches were a few thousand threads each walking 64-256 dependent loads.
 template <int VEC, int G = 1>
 __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
+  if (p.bias_out) {   // the weight gradient's bias partials: 32 lanes per output channel, a fixed reduction tree
+    const int r = threadIdx.x >> 5, l = threadIdx.x & 31;
+    for (int mb = blockIdx.x; mb * 8 < p.M; mb += gridDim.x) {
+      const int m = mb * 8 + r;
+      float t = 0.f;
+      if (m < p.M)
+        for (int s = l; s < splits; s += 32) t = __fadd_rn(t, p.bias_slab[(size_t)s * p.M + m]);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) t = __fadd_rn(t, __shfl_xor(t, o, 32));
+      if (l == 0 && m < p.M) p.bias_out[m] = t;
+    }
+  }
   const int nv = p.N / VEC;
   const long total = (long)p.M * nv;
   const Epilogue& e = p.e;
@@ -1571,6 +1587,20 @@ static int x3_wgrad_splits(const Params& p) {
   return kps > 0 ? ceil_div(ktiles, kps) : 1;
 }
 
+extern "C" size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s);
+extern "C" size_t jtsm_conv_bf16x3_wgrad_bias_workspace_bytes(const jtsm_conv_shape* s) {
+  if (!s || check_shape(s)) return 0;
+  Params p = {};
+  p.s = to_shape(s);
+  if (p.s.Ho <= 0 || p.s.Wo <= 0) return 0;
+  p.M = p.s.Cout; p.N = p.s.KH * p.s.KW * p.s.Cin; p.K = p.s.Bn * p.s.Ho * p.s.Wo;
+  if (p.K == 0) return 0;
+  const int splits = x3_wgrad_splits(p);
+  if (splits <= 1) return 0;
+  const size_t main_bytes = ((size_t)splits * p.M * p.N * sizeof(float) + 15) & ~(size_t)15;
+  return main_bytes + (size_t)splits * p.M * sizeof(float);
+}
+
 extern "C" size_t jtsm_conv_bf16x3_wgrad_workspace_bytes(const jtsm_conv_shape* s) {
   if (!s || check_shape(s)) return 0;
   Params p = {};
@@ -1586,7 +1616,7 @@ template <int NP>
 static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
                               const uint16_t* x_lo, float* dw, const jtsm_conv_shape* s,
                               const float* row_scale, int zero_dw, int grad_shift, void* workspace,
-                              size_t workspace_bytes, void* stream) {
+                              size_t workspace_bytes, void* stream, float* bias_grad = nullptr) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1601,6 +1631,7 @@ static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, cons
   hipStream_t st = as_stream(stream);
   if (p.K == 0) {
     if (zero_dw) JTSM_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)p.M * p.N * sizeof(float), st));
+    if (bias_grad) JTSM_CHECK_HIP(hipMemsetAsync(bias_grad, 0, (size_t)p.M * sizeof(float), st));
     return JTSM_OK;
   }
   JTSM_REQUIRE(dy_hi && x_hi && (NP == 1 || (dy_lo && x_lo)), "conv backward-weight bf16x3 / f16: null pointer");
@@ -1625,12 +1656,30 @@ static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, cons
   p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   p.wide = 1;   // N = taps * in_c is a multiple of 8, dw / slab 16-byte aligned
   const bool halo = x3_wgrad_halo(p);
-  const bool fused = use_fused_finish(p, halo ? ceil_div(p.M, 128) * (p.s.Cin / 32) : ntiles, splits, st);
+  if (bias_grad) {   // db beside dW: per-slice partials behind the slabs, folded by the finishing pass
+    if (splits > 1) {
+      const size_t off = (need + 15) & ~(size_t)15;
+      JTSM_REQUIRE(workspace_bytes >= off + (size_t)splits * p.M * sizeof(float),
+                   "conv backward-weight bf16x3: workspace too small for the bias partials "
+                   "(jtsm_conv_bf16x3_wgrad_bias_workspace_bytes)");
+      p.bias_slab = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + off);
+      p.bias_out = bias_grad;
+    } else {
+      p.bias_slab = bias_grad;
+    }
+  }
+  const bool fused = !bias_grad && use_fused_finish(p, halo ? ceil_div(p.M, 128) * (p.s.Cin / 32) : ntiles, splits, st);
   if (halo) {
     const int halo_tiles = ceil_div(p.M, 128) * (p.s.Cin / 32);
-    hipLaunchKernelGGL(igemm_x3_wgrad_halo_kernel<NP>, dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
-  } else if (big) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2, NP>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
-  else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2, NP>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
+    if (bias_grad) hipLaunchKernelGGL((igemm_x3_wgrad_halo_kernel<NP, true>), dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
+    else hipLaunchKernelGGL((igemm_x3_wgrad_halo_kernel<NP, false>), dim3(halo_tiles, splits), dim3(256), 0, st, p, q);
+  } else if (big) {
+    if (bias_grad) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2, NP, true>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
+    else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<4, 2, 2, 4, 2, NP, false>), dim3(ntiles, splits), dim3(512), 0, st, p, q);
+  } else {
+    if (bias_grad) hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2, NP, true>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
+    else hipLaunchKernelGGL((igemm_x3_wgrad_kernel<2, 2, 2, 2, 2, NP, false>), dim3(ntiles, splits), dim3(256), 0, st, p, q);
+  }
   JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad");
   record_mid(st);
   if (splits > 1 && !fused) return finish_split(p, splits, st, 1);
@@ -1760,6 +1809,24 @@ int jtsm_conv2d_backward_data_ex_f16(const uint16_t* dy_h, const uint16_t* wt_h,
                                      size_t workspace_bytes, void* stream) {
   return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, relu_mask, grad_shift,
                              workspace, workspace_bytes, stream, gate_plane, row_scale);
+}
+
+// dW and db in one contraction (conv_x3.h: x3_bias_mma): db[out_c] = sum over pixels of dy, from the same planes.
+int jtsm_conv2d_backward_weight_bias_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* x_hi,
+                                            const uint16_t* x_lo, float* dw, float* db, const jtsm_conv_shape* s,
+                                            const float* row_scale, int zero_dw, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(db, "conv backward-weight+bias: null db");
+  return x3_backward_weight<2>(dy_hi, dy_lo, x_hi, x_lo, dw, s, row_scale, zero_dw, 0, workspace, workspace_bytes,
+                               stream, db);
+}
+
+int jtsm_conv2d_backward_weight_bias_f16(const uint16_t* dy_h, const uint16_t* x_h, float* dw, float* db,
+                                         const jtsm_conv_shape* s, const float* row_scale, int zero_dw, int grad_shift,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(db, "conv backward-weight+bias: null db");
+  return x3_backward_weight<1>(dy_h, nullptr, x_h, nullptr, dw, s, row_scale, zero_dw, grad_shift, workspace,
+                               workspace_bytes, stream, db);
 }
 
 int jtsm_conv2d_backward_data_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,

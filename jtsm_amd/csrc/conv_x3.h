@@ -35,6 +35,33 @@ __device__ __forceinline__ void x3_mma(f32x16& acc, const bf16x8& ah, const bf16
     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), __builtin_bit_cast(f16x8, bh), acc, 0, 0, 0);
   }
 }
+// Bias gradient inside the weight-gradient contraction: db[co] = sum_p dY[p][co] is dY^T times a column of ones, so the
+// workgroups of the FIRST column tile run one extra matrix instruction per dY fragment (two with hi + lo planes)
+// against an all-ones B fragment; every column of the 32x32 result holds the row sums.  The gradient is in LDS anyway:
+// no separate pass over it (round 2 start: 24 channel_sum launches, 0.8 ms per step).
+template <int NP>
+__device__ __forceinline__ void x3_bias_mma(f32x16& acc, const bf16x8& ah, const bf16x8& al) {
+  if (NP == 2) {
+    const __bf16 one = (__bf16)1.0f;
+    const bf16x8 ones = {one, one, one, one, one, one, one, one};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, acc, 0, 0, 0);
+  } else {
+    const _Float16 one = (_Float16)1.0f;
+    const f16x8 ones = {one, one, one, one, one, one, one, one};
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah), ones, acc, 0, 0, 0);
+  }
+}
+// rows of a 32x32 accumulator tile held by the lanes of column 0 -> out[m_base + row] (scaled by 2^-in_shift)
+__device__ __forceinline__ void x3_bias_store(const Params& p, const f32x16& acc, int m_base, int split, int lane) {
+  if ((lane & 31) != 0) return;
+  const float a = pow2i(-p.in_shift);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (m < p.M) p.bias_slab[(size_t)split * p.M + m] = acc[r] * a;
+  }
+}
 constexpr int x3_max(int a, int b) { return a > b ? a : b; }
 // epilogue bands through an LDS window of `kbytes` (the K-loop buffers) for a BM x BN fp32 tile
 constexpr int x3_passes(int kbytes, int BM, int BN, int TM) {
@@ -518,7 +545,7 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* lo_rows, const char* hi_ro
 
 // WM x WN wavefronts of TM x TN MFMA tiles, as in igemm_x3_kernel; operands wider than 128 channels are kept
 // as several 128-channel images (each with the swizzle above).
-template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2>
+template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2, bool BIAS = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const Params p, const X3Planes q) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
@@ -619,6 +646,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // (BIAS instantiations only: layers without a bias — every FrozenBN convolution of the backbone — keep the kernel
+  // without the extra accumulators)
+  const bool do_bias = BIAS && p.bias_slab != nullptr && n0 == 0 && wn == 0;   // wave-uniform
+  f32x16 bacc[BIAS ? TM : 1];
+#pragma unroll
+  for (int i = 0; i < (BIAS ? TM : 1); ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bacc[i][r] = 0.f;
 
   // ---- transposed fragment reads: lane = 32h + 16g + 4ql + pl supplies, for read r2 of step st, the address
   // of row 16st + 8h + 4r2 + ql, channels 32*tile + 16g + 4pl .. +3; it receives channel 16g + lane%16.
@@ -669,6 +704,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
         bh[u] = lds_tr8(Ss + b_rd[u][0], Ss + b_rd[u][1]);
         bl[u] = NP == 2 ? lds_tr8(Ss + PL + b_rd[u][0], Ss + PL + b_rd[u][1]) : bh[u];
       }
+      if (BIAS && do_bias) {
+#pragma unroll
+        for (int u = 0; u < (BIAS ? TM : 1); ++u) x3_bias_mma<NP>(bacc[u], ah[u], al[u]);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -688,6 +727,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
     if (more) advance_pix();
   }
   static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
+  if (BIAS && do_bias) {
+#pragma unroll
+    for (int u = 0; u < (BIAS ? TM : 1); ++u)
+      x3_bias_store(p, bacc[u], m0 + (wm * TM + u) * 32, gridDim.y > 1 ? split : 0, lane);
+  }
   if (p.wide)
     store_tile_wide<WGRAD, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds),
                                                        (const LinearRows*)nullptr, split, tile);
@@ -705,7 +749,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
 // never wrap); everything else keeps the generic kernel.
 // Halo image: [102 pixel rows][64 B] per plane, UNswizzled — a transposed read of 4 consecutive pixel rows x 32
 // channels is one contiguous 256-byte run (all 64 banks) wherever it starts.
-template <int NP = 2>
+template <int NP = 2, bool BIAS = false>
 __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Params p, const X3Planes q) {
   constexpr int SEG = 32, HPW = SEG + 2, HP = 3 * HPW;          // 102 halo pixels
   constexpr int A_PL = SEG * 256;                                 // dY stage plane: 32 px x 128 co
@@ -784,6 +828,10 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
   for (int t = 0; t < TAPS; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool do_bias = BIAS && p.bias_slab != nullptr && ci0 == 0;   // block-uniform: the first input-channel block's workgroups
+  f32x16 bacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) bacc[r] = 0.f;
 
   // transposed fragment reads (lane = 32h + 16g + 4ql + pl supplies row 8h + 4r2 + ql, receives column 16g + lane%16)
   const int h = lane >> 5, g = (lane >> 4) & 1, ql = (lane >> 2) & 3, pl = lane & 3;
@@ -809,6 +857,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       const char* As = St + ks * 16 * 256;
       const bf16x8 ah = lds_tr8(As + a_rd[0], As + a_rd[1]);
       const bf16x8 al = NP == 2 ? lds_tr8(As + A_PL + a_rd[0], As + A_PL + a_rd[1]) : ah;
+      if (BIAS && do_bias) x3_bias_mma<NP>(bacc, ah, al);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int kh = t / 3, kw = t % 3;
@@ -820,6 +869,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
     }
   }
 
+  if (BIAS && do_bias) x3_bias_store(p, bacc, m0 + wave * 32, gridDim.y > 1 ? blockIdx.y : 0, lane);
   // epilogue: tile t of this wavefront is dW[m0 + 32*wave + row][tap t][ci0 + col]
   const Epilogue& e = p.e;
   const int col = ci0 + (lane & 31);

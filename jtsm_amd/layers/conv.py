@@ -32,6 +32,9 @@ _MODES = ("f32", "bf16x3", "f16")
 # fp16 mode: gradient planes are stored times 2^GRAD_SHIFT (exact) so small gradients stay clear of fp16's
 # subnormal range; the kernels undo it in the accumulator (include/jtsm_hip.h, "fp16 contractions")
 GRAD_SHIFT = int(os.environ.get("JTSM_F16_GRAD_SHIFT", "12"))
+# bias gradients inside the weight-gradient contraction (csrc/conv_x3.h: x3_bias_mma); 0: separate channel-sum passes
+# (the A/B switch of tools/sweeps)
+BIAS_IN_WGRAD = os.environ.get("JTSM_BIAS_IN_WGRAD", "1") != "0"
 
 
 def planes_mode():
@@ -262,7 +265,7 @@ def grad_slot(w, params=None):
 # Per-shape launch facts (the ctypes shape struct, output size, FLOPs, workspace sizes, bf16x3 eligibility)
 # are computed once: a training step calls the same ~90 shapes over and over.
 class _Plan(object):
-    __slots__ = ("s", "ref", "oh", "ow", "flops", "desc", "ws", "x3")
+    __slots__ = ("s", "ref", "oh", "ow", "flops", "desc", "ws", "x3", "wgrad_big")
 
 
 _PLANS = {}
@@ -274,6 +277,7 @@ def _plan(x_shape, w_shape, stride, pad, dil):
     if p is None:
         lib = L.lib()
         p = _Plan()
+        p.wgrad_big = None
         p.s = _shape(x_shape, w_shape, stride, pad, dil)
         p.ref = C.byref(p.s)
         p.oh, p.ow = out_hw(p.s)
@@ -281,7 +285,7 @@ def _plan(x_shape, w_shape, stride, pad, dil):
         p.desc = _desc(p.s)
         p.x3 = tuple(bool(lib.jtsm_conv_bf16x3_eligible(p.ref, r)) and p.s.batch > 0 for r in range(3))
         p.ws = (lib.jtsm_conv_workspace_bytes(p.ref, 0), lib.jtsm_conv_workspace_bytes(p.ref, 1),
-                lib.jtsm_conv_bf16x3_wgrad_workspace_bytes(p.ref))
+                lib.jtsm_conv_bf16x3_wgrad_workspace_bytes(p.ref), lib.jtsm_conv_bf16x3_wgrad_bias_workspace_bytes(p.ref))
         _PLANS[key] = p
     return p
 
@@ -525,9 +529,11 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
     return dx
 
 
-def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=None, out=None, w=None):
+def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=None, out=None, w=None, bias_out=None):
     """`out`: accumulate into this tensor.  `w`: the weight being differentiated — when the data-parallel exchange
-    has registered a gradient slot for it, the result is written there (a fresh result, not an accumulation)."""
+    has registered a gradient slot for it, the result is written there (a fresh result, not an accumulation).
+    `bias_out` (out_c,): also the bias gradient sum_pixels dy — inside the same contraction in the plane arithmetics
+    (no second pass over dy), by a channel_sum pass otherwise."""
     _check(dy, x, row_scale)
     dy, x = _cl(dy), _cl(x)
     pl = _plan(x.shape, w_shape, stride, pad, dil)
@@ -544,6 +550,12 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
         if fresh:   # deterministic slab kernel: writes every element, nothing to clear
             out = slot if slot is not None else torch.empty(tuple(w_shape), dtype=x.dtype, device=x.device,
                                                             memory_format=CL)
+        if bias_out is not None and BIAS_IN_WGRAD and _wgrad_bias_fits(pl):
+            _wgrad_bias_call(pl, gh, gl, xh, xl, out, bias_out, row_scale, fresh, x.device)
+            return out
+        if bias_out is not None:
+            from .elementwise import channel_sum
+            bias_out.copy_(channel_sum(dy))
         nbytes = pl.ws[2]
         ws = _scratch(nbytes, x.device)
         if MATH == "f16":
@@ -555,6 +567,9 @@ def conv2d_backward_weight(dy, x, w_shape, stride=1, pad=0, dil=1, row_scale=Non
                 gh, gl, xh, xl, L.ptr(out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws), C.c_size_t(nbytes),
                 L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_bf16x3")
         return out
+    if bias_out is not None:
+        from .elementwise import channel_sum
+        bias_out.copy_(channel_sum(dy))
     zero = False   # cleared here (not inside the timed launch) so per-launch timings are kernel-only
     if out is None:
         out = slot.zero_() if slot is not None else \
@@ -756,7 +771,7 @@ def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=
     return dx if fp32 else dp
 
 
-def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_scale=None):
+def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_scale=None, bias_out=None):
     """dW from the planes of the output gradient g and of the input x; written into the parameter's gradient slot when
     the data-parallel exchange registered one."""
     w_shape = tuple(w.shape) if w_shape is None else tuple(w_shape)
@@ -771,6 +786,11 @@ def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_sc
     out = slot if slot is not None else torch.empty(w_shape, dtype=torch.float32, device=x.device, memory_format=CL)
     gh, gl = _hl(g.buf)
     xh, xl = _hl(x.buf)
+    if bias_out is not None and BIAS_IN_WGRAD and _wgrad_bias_fits(pl):   # db beside dW, from the same gradient planes
+        _wgrad_bias_call(pl, gh, gl, xh, xl, out, bias_out, row_scale, True, x.device)
+        return out
+    if bias_out is not None:
+        bias_out.copy_(planes_channel_sum(g))
     nbytes = pl.ws[2]
     ws = _scratch(nbytes, x.device)
     lib = L.lib()
@@ -910,6 +930,42 @@ def conv_transpose2x2_fused(x, w, bias=None, relu=False):
     return _ConvTranspose2x2.apply(x, w, bias, relu)
 
 
+def _wgrad_bias_fits(pl):
+    """The bias gradient rides in the weight-gradient contraction on the 128x128-tile and 3x3-halo kernels; on the
+    256x256-tile kernel its extra accumulators cost the whole launch ~20 % (measured: 144 -> 173 us on the mask heads'
+    3x3 layers, 615 -> 760 us on fc1), more than a separate sum over the gradient's planes."""
+    big = getattr(pl, "wgrad_big", None)
+    if big is None:
+        v = [C.c_int() for _ in range(6)]
+        L.check(L.lib().jtsm_conv_bf16x3_plan(pl.ref, 2, *[C.byref(x) for x in v]), "conv_bf16x3_plan")
+        big = pl.wgrad_big = (v[0].value == 4 and v[4].value != 0)      # WM == 4: the 256x256 tile (nbuf 0 = halo)
+    return not big
+
+
+def wgrad_bias_fits(x_shape, w_shape, stride=1, pad=0, dil=1):
+    """Will (conv2d|planes)_backward_weight(..., bias_out=) compute the bias gradient inside the contraction?  (Callers
+    that can batch the separate sums — the mask tower — ask first.)"""
+    if MATH == "f32" or not BIAS_IN_WGRAD:
+        return False
+    pl = _plan(x_shape, w_shape, stride, pad, dil)
+    return bool(pl.x3[2]) and _wgrad_bias_fits(pl)
+
+
+def _wgrad_bias_call(pl, gh, gl, xh, xl, out, bias_out, row_scale, fresh, device):
+    """Weight gradient + bias gradient in one contraction (jtsm_conv2d_backward_weight_bias_*)."""
+    nbytes = max(pl.ws[3], pl.ws[2])
+    ws = _scratch(nbytes, device)
+    lib = L.lib()
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(pl.s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bias_f16(
+            gh, xh, L.ptr(out), L.ptr(bias_out), pl.ref, L.ptr(row_scale), int(fresh), GRAD_SHIFT, L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_bias_f16")
+    else:
+        L.check(_timed(_x3_variant(pl.s, 2), pl.flops, lambda: lib.jtsm_conv2d_backward_weight_bias_bf16x3(
+            gh, gl, xh, xl, L.ptr(out), L.ptr(bias_out), pl.ref, L.ptr(row_scale), int(fresh), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_bias_bf16x3")
+
+
 class _ConvFused(Function):
     """y = relu?(conv(x, w) * scale + bias + residual); scale/bias are constants of the op
     (FrozenBN statistics or a conv bias treated by the caller), residual gets dy * relu'."""
@@ -948,9 +1004,12 @@ class _ConvFused(Function):
             else:
                 w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
                 dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
+        want_db = bias_needs_grad and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
-            dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale, w=w)
-        if bias_needs_grad and ctx.needs_input_grad[3]:
+            if want_db:   # the bias gradient rides in the weight-gradient contraction
+                db = torch.empty(ws[0], dtype=g.dtype, device=g.device)
+            dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale, w=w, bias_out=db)
+        elif want_db:
             db = channel_sum(g)
         if dw is not None and dw.stride() != w.stride() and w.shape[2] == 1 and w.shape[3] == 1:
             # 1x1 weights: OHWI and OIHW are the same bytes; hand the gradient back with the parameter's own

@@ -199,9 +199,11 @@ class _MaskTowerFn(Function):
         if dlogits is not None:
             dl = dlogits.contiguous(memory_format=CL)
             gl = K.PlaneTensor.of(dl, grad=True)
-            if need[2 * k + 2]:
-                grads[2 * k + 2] = _same_strides(K.planes_backward_weight(gl, up, wp), wp)
-            if need[2 * k + 3]:
+            dbp = torch.empty(wp.shape[0], dtype=torch.float32, device=dl.device) if need[2 * k + 3] else None
+            if need[2 * k + 2]:     # (the predictor's bias gradient rides in its weight-gradient contraction)
+                grads[2 * k + 2] = _same_strides(K.planes_backward_weight(gl, up, wp, bias_out=dbp), wp)
+                grads[2 * k + 3] = dbp
+            elif dbp is not None:
                 grads[2 * k + 3] = channel_sum(dl)
             gu = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up, accumulate=du)
         else:
@@ -213,13 +215,17 @@ class _MaskTowerFn(Function):
         if need[2 * k + 1]:
             bias_of.append((2 * k + 1, gu))
         g = K.planes_conv_transpose2x2_backward_data(gu, wd, gate=hs[k] if k > 0 else None)
-        # ---- the 3x3 tower, last layer first
+        # ---- the 3x3 tower, last layer first (bias gradients inside the weight-gradient contractions)
         dx = None
+        x_device = gu.device
         for j in range(k - 1, -1, -1):
             w = ws[j]
+            inside = need[2 * j] and need[2 * j + 1] and K.wgrad_bias_fits(hs[j].shape, w.shape, 1, 1, 1)
             if need[2 * j]:
-                grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1)
-            if need[2 * j + 1]:
+                db = torch.empty(w.shape[0], dtype=torch.float32, device=x_device) if inside else None
+                grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1, bias_out=db)
+                grads[2 * j + 1] = db
+            if need[2 * j + 1] and not inside:      # (256x256-tile layers: one batched sum over the planes at the end)
                 bias_of.append((2 * j + 1, g))
             if j > 0:
                 g = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j])
@@ -324,8 +330,10 @@ class _FcStackFn(Function):
             g, gbuf = relu_backward_scaled(dy, ys[j], ctx.inv_keep)
             gp = K.PlaneTensor(gbuf, ys[j].shape)
             if need[4 + 2 * j]:
-                grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1).view(w.shape)
-            if need[5 + 2 * j]:
+                db = torch.empty(w.shape[0], dtype=torch.float32, device=g.device) if need[5 + 2 * j] else None
+                grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1, bias_out=db).view(w.shape)
+                grads[2 * j + 1] = db
+            elif need[5 + 2 * j]:
                 grads[2 * j + 1] = channel_sum(g.view(g.shape[0], -1))
             if j > 0:
                 dy = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, fp32=True)

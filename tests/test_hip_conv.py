@@ -110,6 +110,13 @@ def test_conv_backward_data_and_weight(cuda, case):
     dw = K.conv2d_backward_weight(dyd, xd, tuple(w.shape), s, p, d, row_scale=scale.to(cuda))
     assert dw.is_contiguous(memory_format=CL)
     close(dw, w.grad, "wgrad")
+    # the bias gradient beside dW (in the plane arithmetics: inside the same contraction, x3_bias_mma) — every case
+    # crosses a different kernel / slice plan: generic 128 and 256 tiles, the 3x3 halo kernel, one slice and many
+    db = torch.full((O,), float("nan"), device=cuda)
+    dw2 = K.conv2d_backward_weight(dyd, xd, tuple(w.shape), s, p, d, bias_out=db)
+    close(db, dy.double().sum((0, 2, 3)), "bias gradient")
+    close(dw2, w.grad / scale.view(-1, 1, 1, 1), "wgrad beside the bias gradient")
+    # row scale applied to the data gradient's rows (jtsm_conv2d_backward_data_ex_*) for the 1x1 cases
     # accumulate + relu gate epilogue of dgrad
     acc = torch.randn(x.shape, generator=g)
     gate = torch.randn(x.shape, generator=g)

@@ -36,10 +36,10 @@ def label(name):
     def np_suffix(v):
         return "" if v in (None, "2") else "," + v
 
-    m = re.search(r"igemm_x3_wgrad_halo_kernel(?:<(\d+)>)?", name)
+    m = re.search(r"igemm_x3_wgrad_halo_kernel(?:<(\d+)(?:, (?:true|false))?>)?", name)   # <NP, BIAS>
     if m:
         return "igemm_x3_wgrad_halo_kernel" + ("<1>" if m.group(1) == "1" else "")
-    m = re.search(r"igemm_x3_wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    m = re.search(r"igemm_x3_wgrad_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?(?:, (?:true|false))?>", name)
     if m:
         g = m.groups()
         return "igemm_x3_wgrad_kernel<%s,%s,%s,%s,%s%s>" % (g[:5] + (np_suffix(g[5]),))
