@@ -367,7 +367,8 @@ def main():
                          "on v_mfma_f32_32x32x16_bf16 with fp32 accumulate; measured error <= 6e-6 relative per layer "
                          "against fp64 (bar 1e-4); everything else fp32. JTSM_CONV_MATH=f32 selects exact fp32 MFMA "
                          "(see `exact_fp32`)") if conv_math != "f32" else "exact fp32 MFMA contractions",
-                "torch_device_ops": ["dropout", "sort / gather glue of the label path", "RCCL collectives (N > 1)"],
+                "torch_device_ops": ["autograd gradient-accumulation adds", "fill / copy / index / sort glue of the label path",
+                                     "RCCL collectives (N > 1)"],
                 "final_loss": round(loss_value, 5), "lr": 1e-7,
                 "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
             },

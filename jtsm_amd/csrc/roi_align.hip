@@ -380,22 +380,28 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
         for (int r = 0; r < kTile; ++r) wts[i][axis][sl][r] = w[r];
       }
       __syncthreads();
-      // ---- walk: wavefront wv takes staged rois wv, wv + 4, ...
+      // ---- walk: EVERY wavefront visits every staged roi and takes its bin rows wv, wv + 4, ... (the four register
+      // copies are added at the end, so any split of the work is exact).  Splitting the rows rather than the rois
+      // keeps all four wavefronts busy on a tile that one or two rois reach — the common case away from piles, where
+      // one wavefront used to walk a roi's ~12 rows (a dependent load each) while three idled.
       {
-        for (int i = wv; i < ns; i += 4) {
+        for (int i = 0; i < ns; ++i) {
           const int npw = nbin[i][1], nph = nbin[i][0];
-          if (npw == 0 || nph == 0) continue;
+          if (npw == 0 || nph <= wv) continue;
           const int pw0 = first_bin[i][1], ph0 = first_bin[i][0];
           const float inv = inv_cnt[i];
           const float* __restrict__ gro = grad + ((size_t)roi_list[sub + i] * nbins + (size_t)ph0 * PW + pw0) * C + c;
           float gk[kMaxBins], gnext[kMaxBins];
+          {
+            const float* __restrict__ grow = gro + (size_t)wv * PW * C;
 #pragma unroll
-          for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? gro[(size_t)k * C] : 0.f;
-          for (int a = 0; a < nph; ++a) {
+            for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? grow[(size_t)k * C] : 0.f;
+          }
+          for (int a = wv; a < nph; a += 4) {
 #pragma unroll
             for (int k = 0; k < kMaxBins; ++k) gk[k] = gnext[k];
-            if (a + 1 < nph) {   // the next bin row's gradients are on their way while this one is applied
-              const float* __restrict__ grow = gro + (size_t)(a + 1) * PW * C;
+            if (a + 4 < nph) {   // this wavefront's next bin row is on its way while this one is applied
+              const float* __restrict__ grow = gro + (size_t)(a + 4) * PW * C;
 #pragma unroll
               for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? grow[(size_t)k * C] : 0.f;
             }
