@@ -179,6 +179,7 @@ class _MaskTowerFn(Function):
             u, up = None, K.planes_conv_transpose2x2_forward(hs[-1], wd, bd, True)
         logits = K.planes_forward(up, wp, 1, 0, 1, bp, False, fp32=True)
         ctx.k, ctx.hs, ctx.up, ctx.xshape = k, hs, up, tuple(x.shape)
+        ctx.u = u                    # (fp32 features, when asked for: the gate of a gradient that arrives through them alone)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*params[0:2 * k:2], wd, wp)
         return logits, u
@@ -206,8 +207,8 @@ class _MaskTowerFn(Function):
             elif dbp is not None:
                 grads[2 * k + 3] = channel_sum(dl)
             gu = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up, accumulate=du)
-        else:
-            gu = K.PlaneTensor(relu_backward_planes(du, up), up.shape)
+        else:   # a gradient into the upsampled features only (the logits unused): the plain ReLU gate, with planes
+            gu = K.PlaneTensor.of(relu_backward(du.contiguous(memory_format=CL), ctx.u, emit_planes=True), grad=True)
         # ---- transposed convolution (bias gradients: all layers' gradient planes are summed in ONE launch at the end)
         bias_of = []                                   # (slot in grads, gradient planes)
         if need[2 * k]:
@@ -242,10 +243,6 @@ class _MaskTowerFn(Function):
                 for (slot, _), db in zip(part, K.planes_channel_sum_multi([gp for _, gp in part])):
                     grads[slot] = db
         return (dx, None) + tuple(grads)
-
-
-def relu_backward_planes(du, up):
-    raise NotImplementedError("a gradient into the upsampled features without one into the logits")
 
 
 def mask_tower_ok(x, convs, deconv, predictor):

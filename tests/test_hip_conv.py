@@ -397,6 +397,7 @@ def test_mask_tower_as_one_node_matches_layer_by_layer(cuda):
         head.predictor.weight.normal_(0, 0.1)
     x0 = torch.randn(9, 64, 14, 14, device=cuda).contiguous(memory_format=CL)
     dl = torch.randn(9, 8, 28, 28, device=cuda).contiguous(memory_format=CL)
+    dup = torch.randn(9, 64, 28, 28, device=cuda).contiguous(memory_format=CL)
     out = {}
     for fused in (False, True):
         fused_blocks.ENABLED = fused
@@ -415,6 +416,25 @@ def test_mask_tower_as_one_node_matches_layer_by_layer(cuda):
     for n, a, b in zip(names, out[True], out[False]):
         close(a, b, "mask tower " + n, chain=True)
     if K.MATH != "f32":
+        # gradients through BOTH outputs, and through the features alone (the logits unused)
+        for use_logits in (True, False):
+            res = {}
+            for fused in (False, True):
+                fused_blocks.ENABLED = fused
+                try:
+                    K.planes_clear()
+                    head.zero_grad(set_to_none=True)
+                    x = x0.clone().requires_grad_()
+                    logits, up = head.layers(x)
+                    loss = (up * dup).sum() + ((logits * dl).sum() if use_logits else 0.0)
+                    loss.backward()
+                    res[fused] = [x.grad] + [p.grad.clone() if p.grad is not None else None for p in head.parameters()]
+                finally:
+                    fused_blocks.ENABLED = True
+            for n, a, b in zip(names[2:], res[True], res[False]):
+                assert (a is None) == (b is None), n
+                if a is not None:
+                    close(a, b, "mask tower (features%s) %s" % (" + logits" if use_logits else " only", n), chain=True)
         # a caller that uses the logits only: the node writes no fp32 upsampled features at all
         head.return_features = False
         K.planes_clear()
