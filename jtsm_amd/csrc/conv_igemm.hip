@@ -1542,6 +1542,8 @@ static bool x3_wgrad_big(const Params& p) {
   constexpr long min_work = 2000;
   const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256);
   if (t256 < 4) return false;   // 1-2 tiles cannot fill 256 CUs even at the slice cap: take four times as many 128s
+  static const int force = [] { const char* e = getenv("JTSM_WGRAD_BIG"); return e ? atoi(e) : -1; }();   // sweeps only
+  if (force == 0) return false;
   return t256 * ceil_div(p.K, XBK) >= min_work;   // (tiles x stages: measured crossover, tools/sweeps/wgrad_sweep.py)
 }
 
