@@ -520,7 +520,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
           }
     }
     __syncthreads();
-#pragma unroll 4
+#pragma unroll 4   // (unroll 8 — twice the epilogue operands in flight — measured: no gain, tools/sweeps/ab_lib.sh)
     for (int it = 0; it < PIECES; ++it) {
       const int c = tid + NT * it;
       const int row = c / CPR, col = (c % CPR) * 4;
