@@ -1,94 +1,94 @@
-"""FrozenBatchNorm2d / get_norm — surface of detectron2/layers/batch_norm.py:14-153.
+"""FrozenBatchNorm2d / get_norm — the API of detectron2/layers/batch_norm.py:14-153 (class name, buffer names and
+state-dict versioning are fixed by the checkpoints; everything else is this repo's).
 
-In the MI355X path a FrozenBatchNorm2d that follows a Conv2d is never run as its own pass: the
-Conv2d wrapper reads ``scale_bias()`` and hands it to the convolution's epilogue.  ``forward`` is
-kept for stand-alone use and computes the same affine map with plain tensor ops.
+On the MI355X path a frozen norm behind a convolution never runs as its own pass: `Conv2d` asks for `scale_bias()`
+— the affine map y = x * scale + bias with scale = weight / sqrt(running_var + eps), bias = bias - running_mean * scale
+— and the contraction's epilogue applies it.  The pair is memoised on the buffers' version counters, so a frozen layer
+costs no launch per step.  `forward` exists for stand-alone use and applies the same map with tensor ops.
 """
 import torch
 from torch import nn
 
+_STATS = ("weight", "bias", "running_mean", "running_var")
+
 
 class FrozenBatchNorm2d(nn.Module):
-    """BatchNorm2d with fixed statistics and affine terms: y = x * scale + bias,
-    scale = weight * rsqrt(running_var + eps), bias = bias - running_mean * scale."""
-
-    _version = 3
+    _version = 3          # state-dict layout version, as the reference writes it into checkpoints' metadata
 
     def __init__(self, num_features, eps=1e-5):
         super().__init__()
-        self.num_features = num_features
-        self.eps = eps
-        self.register_buffer("weight", torch.ones(num_features))
-        self.register_buffer("bias", torch.zeros(num_features))
-        self.register_buffer("running_mean", torch.zeros(num_features))
-        self.register_buffer("running_var", torch.ones(num_features) - eps)
+        self.num_features, self.eps = num_features, eps
+        start = {"weight": 1.0, "bias": 0.0, "running_mean": 0.0, "running_var": 1.0 - eps}
+        for name in _STATS:
+            self.register_buffer(name, torch.full((num_features,), start[name]))
+        self._memo = None
+
+    # ---- the affine map -------------------------------------------------------------------------------------------
+    def _stamp(self):
+        return tuple(getattr(self, n)._version for n in _STATS) + (self.weight.data_ptr(), str(self.weight.device))
 
     def scale_bias(self):
-        """(scale, bias) of the affine map; cached until any of the four buffers is written
-        (tensor version counters), so a frozen layer costs no launches per step."""
-        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
-               self.weight.data_ptr(), self.weight.device)
-        cache = self.__dict__.get("_sb_cache")
-        if cache is None or cache[0] != key:
+        """(scale, bias), each (C,), recomputed only after one of the four buffers has been written or moved."""
+        stamp = self._stamp()
+        if self._memo is None or self._memo[0] != stamp:
             with torch.no_grad():
-                scale = self.weight * (self.running_var + self.eps).rsqrt()
-                cache = (key, scale, self.bias - self.running_mean * scale)
-            self.__dict__["_sb_cache"] = cache
-        return cache[1], cache[2]
+                scale = self.weight * torch.rsqrt(self.running_var + self.eps)
+                self._memo = (stamp, scale, self.bias - self.running_mean * scale)
+        return self._memo[1], self._memo[2]
 
     def forward(self, x):
-        scale, bias = self.scale_bias()
-        return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + bias.reshape(1, -1, 1, 1).to(x.dtype)
+        scale, bias = (t.to(x.dtype).view(1, -1, 1, 1) for t in self.scale_bias())
+        return x * scale + bias
 
-    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys,
-                              unexpected_keys, error_msgs):
-        version = local_metadata.get("version", None)
-        if version is None or version < 2:
-            # very old checkpoints have no running stats (batch_norm.py:77-85)
-            if prefix + "running_mean" not in state_dict:
-                state_dict[prefix + "running_mean"] = torch.zeros_like(self.running_mean)
-            if prefix + "running_var" not in state_dict:
-                state_dict[prefix + "running_var"] = torch.ones_like(self.running_var)
-        if version is not None and version < 3:
-            # versions < 3 stored var without the eps folded in (batch_norm.py:87-93)
-            state_dict[prefix + "running_var"] = state_dict[prefix + "running_var"] - self.eps
-        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys,
-                                      unexpected_keys, error_msgs)
+    def extra_repr(self):
+        return "num_features=%d, eps=%s" % (self.num_features, self.eps)
 
-    def __repr__(self):
-        return "FrozenBatchNorm2d(num_features=%d, eps=%s)" % (self.num_features, self.eps)
+    # ---- checkpoints of older layouts (batch_norm.py:77-93) ---------------------------------------------------------
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, *rest):
+        stored = local_metadata.get("version")
+        if stored is None or stored < 2:        # no running statistics in the file: identity statistics
+            state_dict.setdefault(prefix + "running_mean", torch.zeros_like(self.running_mean))
+            state_dict.setdefault(prefix + "running_var", torch.ones_like(self.running_var))
+        if stored is not None and stored < 3:   # the variance was stored WITH eps
+            key = prefix + "running_var"
+            state_dict[key] = state_dict[key] - self.eps
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, *rest)
+
+    # ---- freezing a trained BatchNorm ---------------------------------------------------------------------------------
+    @classmethod
+    def from_batchnorm(cls, bn):
+        frozen = cls(bn.num_features, bn.eps)
+        with torch.no_grad():
+            if bn.affine:
+                frozen.weight.copy_(bn.weight)
+                frozen.bias.copy_(bn.bias)
+            frozen.running_mean.copy_(bn.running_mean)
+            frozen.running_var.copy_(bn.running_var)
+        return frozen.to(bn.running_mean.device)
 
     @classmethod
     def convert_frozen_batchnorm(cls, module):
-        """Recursively replace BatchNorm2d/SyncBatchNorm by FrozenBatchNorm2d (same statistics)."""
-        bn = (nn.modules.batchnorm.BatchNorm2d, nn.modules.batchnorm.SyncBatchNorm)
-        res = module
-        if isinstance(module, bn):
-            res = cls(module.num_features)
-            if module.affine:
-                res.weight.data = module.weight.data.clone().detach()
-                res.bias.data = module.bias.data.clone().detach()
-            res.running_mean.data = module.running_mean.data
-            res.running_var.data = module.running_var.data
-            res.eps = module.eps
-        else:
-            for name, child in module.named_children():
-                new_child = cls.convert_frozen_batchnorm(child)
-                if new_child is not child:
-                    res.add_module(name, new_child)
-        return res
+        """`module` with every BatchNorm2d / SyncBatchNorm in it (or `module` itself) replaced by its frozen form."""
+        live = (nn.BatchNorm2d, nn.SyncBatchNorm)
+        if isinstance(module, live):
+            return cls.from_batchnorm(module)
+        for parent in list(module.modules()):
+            for name, child in list(parent.named_children()):
+                if isinstance(child, live):
+                    setattr(parent, name, cls.from_batchnorm(child))
+        return module
+
+
+_NORMS = {"FrozenBN": FrozenBatchNorm2d, "GN": lambda channels: nn.GroupNorm(32, channels)}
 
 
 def get_norm(norm, out_channels):
-    """norm: "", "FrozenBN", "GN" or a callable(out_channels) -> module (batch_norm.py:128-153).
-    BN/SyncBN/nnSyncBN are outside the JTSM path (every BASELINE config uses FrozenBN / GN / none)."""
-    if norm is None:
+    """None / "" -> no norm; "FrozenBN" | "GN" (what the BASELINE configs use) or any callable(channels) -> module.
+    The trainable batch norms of batch_norm.py:128-153 (BN, SyncBN, nnSyncBN) are outside the JTSM path."""
+    if not norm:
         return None
-    if isinstance(norm, str):
-        if len(norm) == 0:
-            return None
-        table = {"FrozenBN": FrozenBatchNorm2d, "GN": lambda c: nn.GroupNorm(32, c)}
-        if norm not in table:
-            raise KeyError("jtsm_amd supports norm in %s on the JTSM path, got '%s'" % (sorted(table), norm))
-        norm = table[norm]
-    return norm(out_channels)
+    if callable(norm):
+        return norm(out_channels)
+    if norm not in _NORMS:
+        raise KeyError("jtsm_amd supports norm in %s on the JTSM path, got '%s'" % (sorted(_NORMS), norm))
+    return _NORMS[norm](out_channels)

@@ -38,38 +38,42 @@ def build_sem_seg_head(cfg, input_shape):
     return SEM_SEG_HEADS_REGISTRY.get(cfg.MODEL.SEM_SEG_HEAD.NAME)(cfg, input_shape)
 
 
+def _scale_head(in_channels, width, stride, common_stride, norm):
+    """One pyramid level's branch: log2(stride / common_stride) rounds (at least one) of conv3x3 -> norm -> ReLU, each
+    followed by a x2 bilinear up-sampling while the level is coarser than the common stride.  The Sequential's
+    positions (convolutions at 0, 2, 4, ... when up-sampling sits between them) are the checkpoint's key names."""
+    rounds = max(1, int(round(np.log2(stride / common_stride))))
+    ops = []
+    for k in range(rounds):
+        conv = Conv2d(in_channels if k == 0 else width, width, kernel_size=3, stride=1, padding=1, bias=not norm,
+                      norm=nn.GroupNorm(32, width) if norm == "GN" else None, activation=F.relu)
+        nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+        if conv.bias is not None:
+            nn.init.zeros_(conv.bias)
+        ops.append(conv)
+        if stride != common_stride:
+            ops.append(UpsampleBilinear2x())
+    return nn.Sequential(*ops)
+
+
 @SEM_SEG_HEADS_REGISTRY.register()
 class SemSegFPNHead(nn.Module):
     def __init__(self, cfg, input_shape: Dict[str, ShapeSpec]):
         super().__init__()
-        self.in_features = cfg.MODEL.SEM_SEG_HEAD.IN_FEATURES
-        feature_strides = {k: v.stride for k, v in input_shape.items()}
-        feature_channels = {k: v.channels for k, v in input_shape.items()}
-        self.ignore_value = cfg.MODEL.SEM_SEG_HEAD.IGNORE_VALUE
-        num_classes = cfg.MODEL.SEM_SEG_HEAD.NUM_CLASSES
-        conv_dims = cfg.MODEL.SEM_SEG_HEAD.CONVS_DIM
-        self.common_stride = cfg.MODEL.SEM_SEG_HEAD.COMMON_STRIDE
-        norm = cfg.MODEL.SEM_SEG_HEAD.NORM
-        self.loss_weight = cfg.MODEL.SEM_SEG_HEAD.LOSS_WEIGHT
+        head = cfg.MODEL.SEM_SEG_HEAD
+        if head.NORM not in ("", "GN"):
+            raise NotImplementedError("SemSegFPNHead norm '%s' is not used on the JTSM path" % head.NORM)
+        self.in_features = head.IN_FEATURES
+        self.ignore_value, self.common_stride, self.loss_weight = head.IGNORE_VALUE, head.COMMON_STRIDE, head.LOSS_WEIGHT
         self.scale_heads = []
-        for in_feature in self.in_features:
-            head_ops = []
-            head_length = max(1, int(np.log2(feature_strides[in_feature]) - np.log2(self.common_stride)))
-            for k in range(head_length):
-                conv = Conv2d(feature_channels[in_feature] if k == 0 else conv_dims, conv_dims, kernel_size=3,
-                              stride=1, padding=1, bias=not norm,
-                              norm=nn.GroupNorm(32, conv_dims) if norm == "GN" else None, activation=F.relu)
-                nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
-                if conv.bias is not None:
-                    nn.init.constant_(conv.bias, 0)
-                head_ops.append(conv)
-                if feature_strides[in_feature] != self.common_stride:
-                    head_ops.append(UpsampleBilinear2x())
-            self.scale_heads.append(nn.Sequential(*head_ops))
-            self.add_module(in_feature, self.scale_heads[-1])
-        self.predictor = Conv2d(conv_dims, num_classes, kernel_size=1, stride=1, padding=0)
+        for name in self.in_features:          # registered under the level's own name ("p2" .. "p5"), as in checkpoints
+            branch = _scale_head(input_shape[name].channels, head.CONVS_DIM, input_shape[name].stride,
+                                 self.common_stride, head.NORM)
+            self.add_module(name, branch)
+            self.scale_heads.append(branch)
+        self.predictor = Conv2d(head.CONVS_DIM, head.NUM_CLASSES, kernel_size=1, stride=1, padding=0)
         nn.init.kaiming_normal_(self.predictor.weight, mode="fan_out", nonlinearity="relu")
-        nn.init.constant_(self.predictor.bias, 0)
+        nn.init.zeros_(self.predictor.bias)
 
     def forward(self, features, targets=None):
         x = self.layers(features)

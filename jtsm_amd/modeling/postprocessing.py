@@ -9,22 +9,21 @@ from ..structures import Instances
 
 @torch.no_grad()
 def detector_postprocess(results: Instances, output_height: int, output_width: int, mask_threshold: float = 0.5):
-    """Rescale boxes to the output resolution, clip, drop empty ones, paste the (N,1,M,M) masks."""
-    scale_x, scale_y = output_width / results.image_size[1], output_height / results.image_size[0]
-    results = Instances((output_height, output_width), **results.get_fields())
-    if results.has("pred_boxes"):
-        output_boxes = results.pred_boxes
-    elif results.has("proposal_boxes"):
-        output_boxes = results.proposal_boxes
-    else:
+    """One image's detections at the requested output resolution: boxes rescaled and clipped, empty ones dropped,
+    the (N, 1, M, M) mask probabilities pasted into (N, oh, ow) bitmaps."""
+    in_h, in_w = results.image_size
+    out = Instances((output_height, output_width), **results.get_fields())
+    field = next((f for f in ("pred_boxes", "proposal_boxes") if out.has(f)), None)
+    if field is None:
         raise AssertionError("Predictions must contain boxes!")
-    output_boxes.scale(scale_x, scale_y)
-    output_boxes.clip(results.image_size)
-    results = results[output_boxes.nonempty()]
-    if results.has("pred_masks"):
-        results.pred_masks = paste_masks_in_image(results.pred_masks[:, 0, :, :], results.pred_boxes,
-                                                  results.image_size, threshold=mask_threshold)
-    return results
+    boxes = out.get(field)
+    boxes.scale(output_width / in_w, output_height / in_h)
+    boxes.clip(out.image_size)
+    out = out[boxes.nonempty()]
+    if out.has("pred_masks"):
+        out.pred_masks = paste_masks_in_image(out.pred_masks[:, 0], out.pred_boxes, out.image_size,
+                                              threshold=mask_threshold)
+    return out
 
 
 @torch.no_grad()

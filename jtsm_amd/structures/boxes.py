@@ -1,79 +1,86 @@
-"""Boxes / pairwise_iou — surface of detectron2/structures/boxes.py:143-392 (XYXY_ABS only)."""
-from typing import List
-
+"""Boxes / pairwise_iou — the part of detectron2/structures/boxes.py:143-392 the JTSM path uses: a thin wrapper of an
+(N, 4) float32 tensor of absolute (x0, y0, x1, y1) corners.  Method names are the reference's (every caller in
+`modeling/` is written against them); the bodies are this repo's."""
 import torch
 
 
-class Boxes:
+def _as_corners(data):
+    """Anything tensor-like -> (N, 4) float32 on its own device; empty input -> (0, 4)."""
+    t = data if isinstance(data, torch.Tensor) else torch.as_tensor(data, dtype=torch.float32)
+    t = t.to(torch.float32)
+    if t.numel() == 0:
+        return t.new_zeros((0, 4))
+    if t.dim() != 2 or t.shape[1] != 4:
+        raise ValueError("Boxes wants an (N, 4) tensor, got %s" % (tuple(t.shape),))
+    return t
+
+
+class Boxes(object):
+    __slots__ = ("tensor",)
+
     def __init__(self, tensor):
-        device = tensor.device if isinstance(tensor, torch.Tensor) else torch.device("cpu")
-        tensor = torch.as_tensor(tensor, dtype=torch.float32, device=device)
-        if tensor.numel() == 0:
-            tensor = tensor.reshape((0, 4)).to(dtype=torch.float32, device=device)
-        assert tensor.dim() == 2 and tensor.size(-1) == 4, tensor.size()
-        self.tensor = tensor
+        self.tensor = _as_corners(tensor)
 
-    def clone(self):
-        return Boxes(self.tensor.clone())
-
-    def to(self, device):
-        return Boxes(self.tensor.to(device=device))
-
-    def area(self):
-        b = self.tensor
-        return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-
-    def clip(self, box_size):
-        h, w = box_size
-        self.tensor[:, 0].clamp_(min=0, max=w)
-        self.tensor[:, 1].clamp_(min=0, max=h)
-        self.tensor[:, 2].clamp_(min=0, max=w)
-        self.tensor[:, 3].clamp_(min=0, max=h)
-
-    def scale(self, scale_x, scale_y):
-        self.tensor[:, 0::2] *= scale_x
-        self.tensor[:, 1::2] *= scale_y
-
-    def nonempty(self, threshold=0.0):
-        b = self.tensor
-        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
-
-    def __getitem__(self, item):
-        if isinstance(item, int):
-            return Boxes(self.tensor[item].view(1, -1))
-        b = self.tensor[item]
-        assert b.dim() == 2, "Indexing on Boxes with {} failed to return a matrix!".format(item)
-        return Boxes(b)
-
+    # ---- container behaviour
     def __len__(self):
         return self.tensor.shape[0]
 
+    def __iter__(self):
+        return iter(self.tensor)
+
+    def __getitem__(self, index):
+        """An int picks one box (still a Boxes of length 1); slices / masks / index tensors pick a subset."""
+        rows = self.tensor[index]
+        if rows.dim() == 1:
+            rows = rows.unsqueeze(0)
+        return Boxes(rows)
+
     def __repr__(self):
-        return "Boxes(" + str(self.tensor) + ")"
-
-    def get_centers(self):
-        return (self.tensor[:, :2] + self.tensor[:, 2:]) / 2
-
-    @classmethod
-    def cat(cls, boxes_list: List["Boxes"]):
-        assert isinstance(boxes_list, (list, tuple))
-        if len(boxes_list) == 0:
-            return cls(torch.empty(0))
-        return cls(torch.cat([b.tensor for b in boxes_list], dim=0))
+        return "Boxes(%s)" % (self.tensor,)
 
     @property
     def device(self):
         return self.tensor.device
 
-    def __iter__(self):
-        yield from self.tensor
+    def to(self, device):
+        return Boxes(self.tensor.to(device=device))
+
+    def clone(self):
+        return Boxes(self.tensor.clone())
+
+    @classmethod
+    def cat(cls, boxes_list):
+        rows = [b.tensor for b in boxes_list]
+        return cls(torch.cat(rows, dim=0) if rows else torch.empty(0))
+
+    # ---- geometry
+    def _wh(self):
+        return self.tensor[:, 2:] - self.tensor[:, :2]
+
+    def area(self):
+        return self._wh().prod(dim=1)
+
+    def get_centers(self):
+        return self.tensor.reshape(-1, 2, 2).mean(dim=1)
+
+    def nonempty(self, threshold=0.0):
+        """Mask of the boxes whose width AND height exceed `threshold`."""
+        return (self._wh() > threshold).all(dim=1)
+
+    def clip(self, box_size):
+        """In place: corners limited to the image [0, w] x [0, h]; `box_size` is (h, w)."""
+        h, w = box_size
+        limit = self.tensor.new_tensor([w, h, w, h])
+        torch.minimum(self.tensor.clamp_(min=0), limit, out=self.tensor)
+
+    def scale(self, scale_x, scale_y):
+        """In place: x coordinates times scale_x, y coordinates times scale_y."""
+        self.tensor.mul_(self.tensor.new_tensor([scale_x, scale_y, scale_x, scale_y]))
 
 
-def pairwise_iou(boxes1: Boxes, boxes2: Boxes) -> torch.Tensor:
-    """(N,M) IoU; 0 where the boxes do not intersect (boxes.py:345-392)."""
-    a, b = boxes1.tensor, boxes2.tensor
-    area1, area2 = boxes1.area(), boxes2.area()
-    wh = (torch.min(a[:, None, 2:], b[:, 2:]) - torch.max(a[:, None, :2], b[:, :2])).clamp_(min=0)
-    inter = wh.prod(dim=2)
-    return torch.where(inter > 0, inter / (area1[:, None] + area2 - inter),
-                       torch.zeros(1, dtype=inter.dtype, device=inter.device))
+def pairwise_iou(boxes1, boxes2):
+    """(N, M) intersection over union; 0 where two boxes do not meet (boxes.py:345-392)."""
+    a, b = boxes1.tensor[:, None, :], boxes2.tensor[None, :, :]
+    overlap = (torch.minimum(a[..., 2:], b[..., 2:]) - torch.maximum(a[..., :2], b[..., :2])).clamp_(min=0).prod(dim=2)
+    union = boxes1.area()[:, None] + boxes2.area()[None, :] - overlap
+    return torch.where(overlap > 0, overlap / union, overlap.new_zeros(()))
