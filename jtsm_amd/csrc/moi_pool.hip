@@ -149,13 +149,17 @@ __device__ __forceinline__ void moi_pool_wave(
     // mask word -> ballot -> feature row -> compare).  Comparison order = cell order (first maximum wins).
     constexpr int kAhead = 4;
     const int bwid = q.we - q.ws, ncell = (q.he - q.hs) * bwid;
+    // (the walk keeps its own (h, w) counters: the kernel is bound by instruction issue — rocprofv3 counted 850 vector
+    // and 370 scalar instructions per wavefront for ~6 cells — and two integer divisions per cell were a large part)
+    int ch = q.hs, cw = q.ws;
     for (int i0 = 0; i0 < ncell; i0 += kAhead) {
       int cell[kAhead];
       unsigned hb[kAhead];
 #pragma unroll
       for (int u = 0; u < kAhead; ++u) {
         const int idx = i0 + u;
-        const int h = q.hs + idx / max(bwid, 1), w = q.ws + idx % max(bwid, 1);
+        const int h = ch, w = cw;
+        if (++cw >= q.we) { cw = q.ws; ++ch; }
         // inside the bin and the rounded (inclusive) box?  wave-uniform
         const bool in = idx < ncell && w >= r.x0 && w <= r.x1 && h >= r.y0 && h <= r.y1;
         cell[u] = in ? h * W + w : -1;
@@ -343,6 +347,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 cells][256 channels]
   __shared__ int roi_list[256];
+  __shared__ IBox roi_box[256];          // their rounded boxes (rounded once per roi, not once per (roi, bin))
   __shared__ int pair_list[kPairCap];   // (roi * nbins + bin) rows whose bin range touches the tile, in order
   __shared__ int wave_count[4];
   const int t = threadIdx.x;
@@ -366,6 +371,12 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   for (int i = t; i < kTile * kTile * 64; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int np = 0;   // uniform
 
+  // a / W by multiply-high (exact for a * W < 2^32: a is a cell index of one map): the drain runs it once per
+  // (pair, channel) and is bound by instruction issue, not by its loads (rocprofv3: 60 M vector instructions per launch
+  // against 3 M loads; an integer division is ~25 of them)
+  const unsigned magicW = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);
+  const unsigned magic_bins = (unsigned)((0x100000000ull + (unsigned)nbins - 1) / (unsigned)nbins);   // k < 256 * nbins
+  const unsigned magic_pw = (unsigned)((0x100000000ull + (unsigned)PW - 1) / (unsigned)PW);
   constexpr int kDepth = 16;
   auto drain = [&]() {   // add the listed rows' gradients into the tile: kDepth rows' loads in flight per thread
     __syncthreads();
@@ -381,7 +392,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
 #pragma unroll
       for (int u = 0; u < kDepth; ++u) {
         if (a[u] < 0) continue;
-        const int ay = a[u] / W, ax = a[u] - ay * W;
+        const int ay = (int)__umulhi((unsigned)a[u], magicW), ax = a[u] - ay * W;
         if (ay >= y0 && ay <= y1 && ax >= x0 && ax <= x1) acc[((ay - y0) * kTile + (ax - x0)) * 256 + t] += g[u];
       }
     }
@@ -400,7 +411,10 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     }
     int nroi;
     const int slot = compact256(hit, wave_count, nroi);
-    if (hit) roi_list[slot] = n;
+    if (hit) {
+      roi_list[slot] = n;
+      roi_box[slot] = round_box(rois + (size_t)n * 5, scale);
+    }
     __syncthreads();
     // ---- their bins whose cell range touches the tile, in (roi, bin) order
     const int ncombo = nroi * nbins;
@@ -410,9 +424,10 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
       bool bh = false;
       int row = 0;
       if (k < ncombo) {
-        const int i = k / nbins, bin = k - i * nbins, m = roi_list[i];
-        const IBox r = round_box(rois + (size_t)m * 5, scale);
-        const BinRange q = bin_range(r, bin / PW, bin % PW, PH, PW, H, W);
+        const int i = (int)__umulhi((unsigned)k, magic_bins), bin = k - i * nbins, m = roi_list[i];
+        const IBox r = roi_box[i];
+        const int ph = (int)__umulhi((unsigned)bin, magic_pw);
+        const BinRange q = bin_range(r, ph, bin - ph * PW, PH, PW, H, W);
         bh = q.he > q.hs && q.we > q.ws && q.hs <= y1 && q.he > y0 && q.ws <= x1 && q.we > x0;
         row = m * nbins + bin;
       }
