@@ -218,10 +218,15 @@ struct AlignLevels {
 
 __global__ __launch_bounds__(256) void align_census_kernel(const float* __restrict__ rois, int M, int PH, int PW, int sr,
                                                            int aligned, const int* __restrict__ roi_level,
-                                                           const AlignLevels lv, int* __restrict__ census) {
+                                                           const AlignLevels lv, int* __restrict__ census,
+                                                           int4* __restrict__ reach_out, int* __restrict__ meta_out) {
 #pragma clang fp contract(off)
+  // reach_out[n] = (ya, yz, xa, xz): the cells roi n's samples can touch; meta_out[n] = image | level entry << 16, or
+  // -1 (no level of this call / degenerate box).  The tile workgroups test these five integers instead of redoing the
+  // box geometry for every roi in every tile (a fifth of the gather's vector instructions were that).
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= M) return;
+  meta_out[n] = -1;
   int l = 0;
   if (roi_level) {
     const int id = roi_level[n];
@@ -234,6 +239,8 @@ __global__ __launch_bounds__(256) void align_census_kernel(const float* __restri
   if (g.gh <= 0 || g.gw <= 0) return;
   const int xa = max((int)floorf(g.x0), 0), xz = min((int)floorf(g.x0 + (float)PW * g.bw) + 1, W - 1);
   const int ya = max((int)floorf(g.y0), 0), yz = min((int)floorf(g.y0 + (float)PH * g.bh) + 1, H - 1);
+  reach_out[n] = make_int4(ya, yz, xa, xz);
+  meta_out[n] = g.b | (l << 16);
   if (xa > xz || ya > yz) return;
   for (int ty = ya / kTile; ty <= yz / kTile; ++ty) {
     const int oy = min(yz, ty * kTile + kTile - 1) - max(ya, ty * kTile) + 1;
@@ -263,7 +270,8 @@ constexpr int kMaxBins = 16;    // PH, PW <= 16 (7 and 14 on the JTSM path); wid
 __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__ grad, const float* __restrict__ rois,
                                                        const AlignLevels lv, int C, int M, int PH, int PW, int sr,
                                                        int aligned, const int* __restrict__ roi_level,
-                                                       const int* __restrict__ census_max, int census_lim) {
+                                                       const int* __restrict__ census_max, int census_lim,
+                                                       const int4* __restrict__ reach_in, const int* __restrict__ meta_in) {
 #pragma clang fp contract(off)
   int lvl = 0;
   while (lvl + 1 < lv.n && (int)blockIdx.x >= lv.first_tile[lvl + 1]) ++lvl;
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
   for (int r = 0; r < kTile; ++r)
 #pragma unroll
     for (int q = 0; q < kTile; ++q) acc[r][q] = 0.f;
+  bool touched = false;   // block-uniform: did any roi reach this tile?
 
   // cells a sample coordinate range [lo, hi] can touch: floor(lo) .. floor(hi) + 1, after the clamp to the map
   auto reach = [](float lo, float hi, int n, int& a, int& z) {
@@ -317,14 +326,9 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
   for (int base = 0; base < M; base += 256) {
     const int n = base + t;
     bool hit = false;
-    if (n < M && (!roi_level || roi_level[n] == level)) {
-      const RoiGeom<float> g = geom_box<float>(rois + (size_t)n * 5, scale, PH, PW, sr, aligned != 0);
-      if (g.b == b && g.gh > 0 && g.gw > 0) {
-        int ya, yz, xa, xz;
-        reach(g.y0, g.y0 + (float)PH * g.bh, H, ya, yz);
-        reach(g.x0, g.x0 + (float)PW * g.bw, W, xa, xz);
-        hit = ya <= y1 && yz >= y0 && xa <= x1 && xz >= x0;
-      }
+    if (n < M && meta_in[n] == (b | (lvl << 16))) {   // this level, this image, a box with samples (census kernel)
+      const int4 rc = reach_in[n];                     // (ya, yz, xa, xz)
+      hit = rc.x <= y1 && rc.y >= y0 && rc.z <= x1 && rc.w >= x0;
     }
     int nroi;
     const int slot = compact256(hit, wave_count, nroi);
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
       for (int q = 0; q < 5; ++q) roi_row[slot][q] = rois[(size_t)n * 5 + q];
     }
     __syncthreads();
+    touched = touched || nroi > 0;
     for (int sub = 0; sub < nroi; sub += kSub) {
       const int ns = min(kSub, nroi - sub);
       // ---- stage: bins of each axis that reach the tile, and their weights on the tile's eight lines
@@ -428,6 +433,13 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
       __syncthreads();                  // before the next batch overwrites the staged weights
     }
     __syncthreads();                    // before the next chunk overwrites roi_list / roi_row
+  }
+  if (!touched) {   // most tiles of a call: no roi reaches them — zeros straight from registers, no LDS round trip
+    for (int cell = wv; cell < kTile * kTile; cell += 4) {
+      const int y = y0 + cell / kTile, x = x0 + cell % kTile;
+      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
+    }
+    return;
   }
   // the four wavefronts' copies -> LDS (the weight pool is free now), added in a fixed order
   constexpr int SLAB = kTile * kTile * 64;
@@ -577,13 +589,16 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
   }
   lv.first_tile[lv.n] = ntile;
   int* census = nullptr;
-  JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), (size_t)(ntile + 1) * sizeof(int), st));
+  const size_t head = ((size_t)(ntile + 1) * sizeof(int) + 15) & ~(size_t)15;      // census + its maximum, then per roi:
+  JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), head + (size_t)M * (sizeof(int4) + sizeof(int)), st));
   JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
+  int4* reach = reinterpret_cast<int4*>(reinterpret_cast<char*>(census) + head);   // cell reach (16-byte aligned)
+  int* meta = reinterpret_cast<int*>(reach + M);                                    // image | level entry << 16
   hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, rois, M, PH, PW, sr, aligned,
-                     roi_level, lv, census);
+                     roi_level, lv, census, reach, meta);
   hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
   hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 0, st, grad, rois, lv, C, M, PH, PW, sr, aligned,
-                     roi_level, census + ntile, census_limit());
+                     roi_level, census + ntile, census_limit(), reach, meta);
   constexpr int V = WideVec<float>::value;
   const int blocks = ceil_div((long)M * PH * PW, 4);
   for (int l = 0; l < lv.n; ++l) {   // the scatter form, level by level (each returns at once unless the census says so)
