@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   // (pair, channel) and is bound by instruction issue, not by its loads (rocprofv3: 60 M vector instructions per launch
   // against 3 M loads; an integer division is ~25 of them)
   const unsigned magicW = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);
+  const bool magic_ok = (unsigned long long)H * W * W < 0xFFFFFFFFull;   // (maps beyond ~1600 x 1600 cells divide plainly)
   const unsigned magic_bins = (unsigned)((0x100000000ull + (unsigned)nbins - 1) / (unsigned)nbins);   // k < 256 * nbins
   const unsigned magic_pw = (unsigned)((0x100000000ull + (unsigned)PW - 1) / (unsigned)PW);
   constexpr int kDepth = 16;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
 #pragma unroll
       for (int u = 0; u < kDepth; ++u) {
         if (a[u] < 0) continue;
-        const int ay = (int)__umulhi((unsigned)a[u], magicW), ax = a[u] - ay * W;
+        const int ay = magic_ok ? (int)__umulhi((unsigned)a[u], magicW) : a[u] / W, ax = a[u] - ay * W;
         if (ay >= y0 && ay <= y1 && ax >= x0 && ax <= x1) acc[((ay - y0) * kTile + (ax - x0)) * 256 + t] += g[u];
       }
     }
