@@ -768,6 +768,34 @@ __device__ __forceinline__ float pasted_bit(const float* __restrict__ m, int M, 
   return acc >= threshold ? 1.f : 0.f;
 }
 
+// pasted_bit, separated by axis: everything pasted_bit derives from a pixel's row (or column) alone — the same
+// expressions, evaluated once per row / column of a sample instead of once per tap (two divisions and a floor each).
+struct PasteAxis { float w0, w1; int i0; bool any; };
+__device__ __forceinline__ PasteAxis paste_axis(int p, float lo, float hi, int M) {
+#pragma clang fp contract(off)
+  const float g = ((float)p + 0.5f - lo) / (hi - lo) * 2.f - 1.f;
+  const float i = ((g + 1.f) * (float)M - 1.f) / 2.f;
+  const float f = floorf(i);
+  PasteAxis a;
+  a.any = f >= -1.f && f < (float)M;
+  a.i0 = (int)f;
+  a.w1 = i - f;
+  a.w0 = (f + 1.f) - i;
+  return a;
+}
+__device__ __forceinline__ float pasted_bit_axes(const float* __restrict__ m, int M, const PasteAxis& ay,
+                                                 const PasteAxis& ax, float threshold) {
+#pragma clang fp contract(off)
+  float acc = 0.f;
+  if (ax.any && ay.any) {
+    acc += pc_tap(m, M, ay.i0, ax.i0) * (ax.w0 * ay.w0);
+    acc += pc_tap(m, M, ay.i0, ax.i0 + 1) * (ax.w1 * ay.w0);
+    acc += pc_tap(m, M, ay.i0 + 1, ax.i0) * (ax.w0 * ay.w1);
+    acc += pc_tap(m, M, ay.i0 + 1, ax.i0 + 1) * (ax.w1 * ay.w1);
+  }
+  return acc >= threshold ? 1.f : 0.f;
+}
+
 __global__ __launch_bounds__(256) void paste_crop_targets_kernel(const float* __restrict__ probs,   // (N, M, M)
                                                                  const float* __restrict__ rois,    // (N, 4)
                                                                  unsigned char* __restrict__ out, long total, int M,
@@ -782,18 +810,22 @@ __global__ __launch_bounds__(256) void paste_crop_targets_kernel(const float* __
     const float* m = probs + (size_t)n * M * M;
     const int cells = g.gh * g.gw;
     const float count = (float)(cells > 1 ? cells : 1);
+    // (the kernel is bound by instruction issue: per tap the first form spent an integer division to recover (y, x)
+    // and two float divisions + a floor per axis; a sample's four taps share two rows and two columns)
     float acc = 0.f;
     for (int iy = 0; iy < g.gh; ++iy)
       for (int ix = 0; ix < g.gw; ++ix) {
         const Tap<float> t = sample_tap<float, false>(g, H, W, ph, pw, iy, ix);
         if (t.pos[0] < 0) continue;
-        float v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int y = t.pos[k] / W, x = t.pos[k] - y * W;
-          v[k] = pasted_bit(m, M, x0, y0, x1, y1, x, y, threshold);
-        }
-        acc += t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3];
+        // make_tap: pos = {yl W + xl, yl W + xh, yh W + xl, yh W + xh} with yh in {yl, yl + 1}, xh in {xl, xl + 1}
+        const int yl = t.pos[0] / W, xl = t.pos[0] - yl * W;
+        const int xh = t.pos[1] - yl * W, yh = yl + (t.pos[2] != t.pos[0] ? 1 : 0);
+        const PasteAxis ayl = paste_axis(yl, y0, y1, M), axl = paste_axis(xl, x0, x1, M);
+        const PasteAxis ayh = yh == yl ? ayl : paste_axis(yh, y0, y1, M);
+        const PasteAxis axh = xh == xl ? axl : paste_axis(xh, x0, x1, M);
+        const float v0 = pasted_bit_axes(m, M, ayl, axl, threshold), v1 = pasted_bit_axes(m, M, ayl, axh, threshold);
+        const float v2 = pasted_bit_axes(m, M, ayh, axl, threshold), v3 = pasted_bit_axes(m, M, ayh, axh, threshold);
+        acc += t.w[0] * v0 + t.w[1] * v1 + t.w[2] * v2 + t.w[3] * v3;
       }
     out[idx] = (acc / count) >= 0.5f ? 1 : 0;
   }
