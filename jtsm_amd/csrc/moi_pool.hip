@@ -210,7 +210,9 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_nhwc(
     float* __restrict__ out, int* __restrict__ argmax, int C, int H, int W, int M, int words,
     float scale, int PH, int PW, const int* __restrict__ roi_level, int level) {
   const int nbins = PH * PW;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (readfirstlane: the wavefront index is uniform, but the compiler cannot see that through threadIdx — with it
+  // the roi / bin / address arithmetic below runs on the scalar unit instead of once per lane)
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave >= (long)M * nbins) return;
   if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level
   const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
@@ -234,7 +236,9 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_levels(
     float* __restrict__ out, int* __restrict__ argmax, int C, int M, int words, int PH, int PW,
     const int* __restrict__ roi_level, int nlevels) {
   const int nbins = PH * PW;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (readfirstlane: the wavefront index is uniform, but the compiler cannot see that through threadIdx — with it
+  // the roi / bin / address arithmetic below runs on the scalar unit instead of once per lane)
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave >= (long)M * nbins) return;
   const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
   const int l = roi_level[n];
@@ -250,7 +254,8 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_levels(
     const int* __restrict__ census_max, int census_limit) {
   if (census_max && *census_max <= census_limit) return;   // the gather form took this call
   const int lane = threadIdx.x & 63;
-  for (long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6); wave < (long)M * nbins; wave += (long)gridDim.x * 4) {
+  for (long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); wave < (long)M * nbins;
+       wave += (long)gridDim.x * 4) {
     const int n = (int)(wave / nbins);
     const int l = roi_level[n];
     if ((unsigned)l >= (unsigned)nlevels) continue;

@@ -65,7 +65,9 @@ __global__ __launch_bounds__(256) void align_fwd_nhwc(const T* __restrict__ in,
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63;
   const int nbins = PH * PW;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (readfirstlane: the wavefront index is uniform, but the compiler cannot see that through threadIdx — with it
+  // the roi / bin / address arithmetic below runs on the scalar unit instead of once per lane)
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave >= (long)M * nbins) return;
   if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level  // whole wave leaves together
   const int n = (int)(wave / nbins);
@@ -135,7 +137,9 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
   if (census_max && *census_max <= census_limit) return;   // the gather form (align_bwd_tiled) took this call
   const int lane = threadIdx.x & 63;
   const int nbins = PH * PW;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (readfirstlane: the wavefront index is uniform, but the compiler cannot see that through threadIdx — with it
+  // the roi / bin / address arithmetic below runs on the scalar unit instead of once per lane)
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave >= (long)M * nbins) return;
   if (roi_level && roi_level[wave / nbins] != level) return;  // FPN: this roi lives on another level
   const int n = (int)(wave / nbins);
