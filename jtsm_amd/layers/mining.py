@@ -32,10 +32,10 @@ def mine_top1(scores, proposals, bag_offsets, classes, counts, img_probs, lse=No
     assert scores.stride(1) == 1 and (deltas is None or deltas.stride(1) == 1)
     B, G = classes.shape
     dev = scores.device
-    out = dict(idx=torch.zeros((B, G), dtype=torch.int32, device=dev),
-               boxes=torch.zeros((B, G, 4), dtype=torch.float32, device=dev),
-               scores=torch.zeros((B, G), dtype=torch.float32, device=dev),
-               weights=torch.zeros((B, G), dtype=torch.float32, device=dev))
+    # one zero-filled allocation (one fill launch, not four) carved into the four outputs: 7 words per (image, class)
+    words = torch.zeros((7, B, G), dtype=torch.int32, device=dev)
+    out = dict(idx=words[0], boxes=words[1:5].view(torch.float32).view(B, G, 4), scores=words[5].view(torch.float32),
+               weights=words[6].view(torch.float32))
     proposals = proposals.contiguous()
     img_probs = img_probs.contiguous()
     L.check(L.lib().jtsm_mine_top1_f32(

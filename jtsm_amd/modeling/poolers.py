@@ -208,7 +208,8 @@ class ROIPooler(nn.Module):
             sp = superpixels.tensor if hasattr(superpixels, "tensor") else superpixels
             sp = sp.to(torch.int32).contiguous()
             max_len = max(l.size(1) for l in oh_labels_list)
-            labels = cat([torch.nn.functional.pad(l.to(torch.int32), (0, max_len - l.size(1))) for l in oh_labels_list])
+            labels = cat([l.to(torch.int32) if l.size(1) == max_len else
+                          torch.nn.functional.pad(l.to(torch.int32), (0, max_len - l.size(1))) for l in oh_labels_list])
             labels = labels.contiguous()
             # kept for the mask branch's superpixel-evidence targets (same rows as the concatenated boxes)
             self.last_oh_labels, self.last_superpixels = labels, sp
