@@ -1906,6 +1906,7 @@ int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, 
     const int c = x3_tile_choice(p);
     if (c == 1) { cfg[0] = 4; cfg[1] = 1; }
     if (c == 2) { cfg[0] = 4; cfg[1] = 2; cfg[2] = 2; cfg[3] = 4; }
+    if (c == 3 && !x3_halo_ok(role, p)) { cfg[2] = 1; cfg[3] = 1; }   // 64 x 64 (the halo kernels have their own shapes)
     if (x3_halo_ok(role, p)) {   // reported as NBUF = 0: igemm_x3_halo_kernel<role, TH, WM, WN, TN, HP16>
       const bool big = c == 2;
       const int OH = role == FWD ? p.s.Ho : p.s.H, OW = role == FWD ? p.s.Wo : p.s.W;

@@ -1132,14 +1132,20 @@ inline int x3_tile_choice(const Params& p) {
   // tiles x stages (measured crossover, tools/sweeps/x3_sweep.py + layer timings; JTSM_X3_MIN_WORK overrides for sweeps)
   static const long min_work = [] { const char* e = getenv("JTSM_X3_MIN_WORK"); return e ? atol(e) : 9216L; }();
   if (p.N >= 192 && t256 * ktiles >= min_work && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
+  // 64 x 64 tiles for the small layers (res4 / res5 1x1 convolutions on 64 x 64 and 32 x 32 maps): at 128 x 128 they
+  // are <= 128 tiles and need 4-8 K slices to fill the chip — each slice writes a slab and a finishing launch folds
+  // them; four times as many small tiles fill it with 1-2 slices.
+  static const bool tile64 = [] { const char* e = getenv("JTSM_X3_TILE64"); return !e || atoi(e) != 0; }();
+  const long t128 = (long)ceil_div(p.N, 128) * ceil_div(p.M, 128);
+  if (tile64 && t128 <= 128 && ktiles >= 8 && p.N >= 64 && p.M >= 64) return 3;
   return 0;
 }
 
 // K slices the launcher will want for this problem (before the workspace clamp).
 inline int x3_wanted_splits(const Params& p) {
   const int c = x3_tile_choice(p);
-  const int bm = c == 0 ? 128 : 256, bn = c == 0 ? 128 : (c == 1 ? 64 : 256);
-  return plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ceil_div(p.K, XBK), c == 2 ? 256 : 512);
+  const int bm = c == 0 ? 128 : (c == 3 ? 64 : 256), bn = c == 0 ? 128 : (c == 1 || c == 3 ? 64 : 256);
+  return plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ceil_div(p.K, XBK), c == 2 ? 256 : (c == 3 ? 1024 : 512));
 }
 
 // The halo kernel serves k x k (k > 1), stride-1, undilated layers whose contracted channels come in blocks of 32
@@ -1198,6 +1204,7 @@ int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t worksp
   switch (x3_tile_choice(p)) {
     case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2, NP>(p, q, workspace, workspace_bytes, 512, st);
     case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4, NP>(p, q, workspace, workspace_bytes, 256, st);
+    case 3: return launch_x3_cfg<ROLE, 2, 2, 1, 1, NP>(p, q, workspace, workspace_bytes, 1024, st);
     default: return launch_x3_cfg<ROLE, 2, 2, 2, 2, NP>(p, q, workspace, workspace_bytes, 512, st);
   }
 }
