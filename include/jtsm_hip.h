@@ -273,10 +273,21 @@ int jtsm_conv2d_backward_weight_f32(const float* dy, const float* x, float* dw,
  *   jtsm_split_bf16_transposed_f32  w [out_c][taps][in_c] -> planes of [in_c][taps][out_c] (what the
  *                                   data gradient contracts against); row_scale (nullable, [out_c])
  *                                   multiplies row o first — the FrozenBN scale of the layer
+ *   jtsm_split_bf16_paired_f32      src [rows][k] (k % 32 == 0) -> PAIRED planes: per row, blocks of [32 k of hi]
+ *                                   [32 k of lo], i.e. element (row, j) has hi at row*2k + (j/32)*64 + j%32 and lo 32
+ *                                   elements behind it; `planes` holds 2*rows*k elements.  One K stage of a contraction
+ *                                   (32 k of both planes) is then ONE whole 128-byte line per row instead of half a line
+ *                                   of each of two arrays.  The WEIGHT operand (w_hi, w_lo / wt_hi, wt_lo) of every
+ *                                   bf16x3 forward / backward-data entry point may be given in this layout: it is
+ *                                   recognised by w_lo == w_hi + 32 elements (separate planes are at least a whole plane
+ *                                   apart; keep them more than 32 elements apart).  jtsm_split_bf16_transposed_f32 and the
+ *                                   records of jtsm_split_bf16_multi_f32 write paired planes when given such a pair
+ *                                   (taps * out_c % 32 == 0; a straight record then carries its row length k in `in_c`)
  *   jtsm_conv_bf16x3_eligible       1 when a shape can take this path in `role` (0 forward, 1 backward-
  *                                   data; 2 see below): the contracted channel count is a multiple of 32, or the kernel
  *                                   is 1x1 and it is a multiple of 8 */
 int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, void* stream);
+int jtsm_split_bf16_paired_f32(const float* src, uint16_t* planes, long rows, int k, void* stream);
 int jtsm_split_bf16_transposed_f32(const float* w, const float* row_scale, uint16_t* hi, uint16_t* lo,
                                    int out_c, int taps, int in_c, void* stream);
 /* The same two splits for MANY weights in one launch.  table: device array of `entries` records of eight

@@ -1410,11 +1410,27 @@ int jtsm_split_bf16_f32(const float* src, uint16_t* hi, uint16_t* lo, long n, vo
   return JTSM_OK;
 }
 
+int jtsm_split_bf16_paired_f32(const float* src, uint16_t* planes, long rows, int k, void* stream) {
+  JTSM_REQUIRE(rows >= 0 && k >= 0, "split_bf16_paired: negative size");
+  if (rows == 0 || k == 0) return JTSM_OK;
+  JTSM_REQUIRE(k % 32 == 0, "split_bf16_paired: the row length must be a multiple of 32");
+  JTSM_REQUIRE(src && planes, "split_bf16_paired: null pointer");
+  JTSM_REQUIRE(aligned16(src) && aligned16(planes), "split_bf16_paired: pointers must be 16-byte aligned");
+  const long n = rows * k, n8 = n >> 3;
+  const int blocks = (int)(n8 / 256 + 1 < 8192 ? n8 / 256 + 1 : 8192);
+  hipLaunchKernelGGL(split_bf16_paired_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src,
+                     reinterpret_cast<__bf16*>(planes), n, k);
+  JTSM_CHECK_LAUNCH("split_bf16_paired");
+  return JTSM_OK;
+}
+
 int jtsm_split_bf16_transposed_f32(const float* w, const float* row_scale, uint16_t* hi, uint16_t* lo, int out_c,
                                    int taps, int in_c, void* stream) {
   JTSM_REQUIRE(out_c >= 0 && taps > 0 && in_c >= 0 && taps <= 65535, "split_bf16_transposed: bad sizes");
   if (out_c == 0 || in_c == 0) return JTSM_OK;
   JTSM_REQUIRE(w && hi && lo, "split_bf16_transposed: null pointer");
+  JTSM_REQUIRE(!x3_paired(hi, lo, 2) || ((long)taps * out_c) % 32 == 0 || (long)taps * out_c * in_c == 32,
+               "split_bf16_transposed: paired planes (lo == hi + 32) need taps * out_c %% 32 == 0");
   hipLaunchKernelGGL(split_bf16_transposed_kernel, dim3(ceil_div(in_c, 32), ceil_div(out_c, 32), taps), dim3(256), 0,
                      as_stream(stream), w, row_scale, reinterpret_cast<__bf16*>(hi), reinterpret_cast<__bf16*>(lo), out_c,
                      taps, in_c);

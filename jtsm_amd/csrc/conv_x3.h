@@ -87,6 +87,31 @@ struct X3Planes {
   const __bf16* B_hi; const __bf16* B_lo;
 };
 
+// PAIRED planes (weights).  A K stage takes 32 k = 64 bytes per row and plane.  With the planes in two arrays that is
+// HALF a 128-byte line from each: the line's other half belongs to the next stage, by which time the 64 KiB that passed
+// through the CU's 32 KiB L1 have evicted it — every line crosses L2 -> L1 twice, and that fill path (64 B/clk per CU),
+// not the matrix pipes, bounded the forward / data-gradient kernels (measured by fetching the lo chunk from the other
+// half of the hi chunk's line, wrong values: 12-25 % shorter launches).  A paired operand stores, per row, blocks of
+// [32 k of hi][32 k of lo]: one stage = one whole line per row.  Element (row, k) of an operand with K % 32 == 0:
+//     hi at row * 2K + (k / 32) * 64 + k % 32,   lo 32 elements behind it.
+// The pair of pointers says which layout it is: lo == hi + 32 elements <=> paired (with separate planes lo is at least
+// one whole plane away; a 32-element plane is the same bytes in both layouts).
+__host__ __device__ __forceinline__ bool x3_paired(const void* hi, const void* lo, int np) {
+  return np == 2 && lo && reinterpret_cast<const char*>(lo) - reinterpret_cast<const char*>(hi) == 64;
+}
+__host__ __device__ __forceinline__ size_t x3_paired_index(size_t row, size_t k, size_t K) {
+  return row * 2 * K + (k >> 5) * 64 + (k & 31);
+}
+
+// Address of the zero page that out-of-range rows are fetched from, made opaque once per kernel: left to itself the
+// compiler re-derives it through the GOT (s_getpc + s_load_dwordx2 + s_waitcnt lgkmcnt(0)) in front of EVERY
+// direct-to-LDS load of the K loop — a scalar-memory round trip per piece that also drains the outstanding ds_reads.
+__device__ __forceinline__ const void* zero_page_address() {
+  const void* z = g_zero_page;
+  asm volatile("" : "+s"(z));
+  return z;
+}
+
 __device__ __forceinline__ void dma16b(const void* g, void* lds_uniform_base) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)lds_uniform_base, 16, 0, 0);
@@ -111,6 +136,7 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
   __shared__ __attribute__((aligned(16))) char lds[LDSB];
 
   const ConvShape& s = p.s;
+  const void* const zero_page = zero_page_address();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, li = lane & 31;
@@ -176,11 +202,12 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
     a_mh[j] = arow[j].ok ? mh : 0u;
     a_mw[j] = mw;
   }
+  const int b_mul = x3_paired(q.B_hi, q.B_lo, NP) ? 2 : 1;
   int b_off[B_INS], b_chunk[B_INS];
 #pragma unroll
   for (int j = 0; j < B_INS; ++j) {
     const int r = (wave * B_INS + j) * 16 + (lane >> 2);
-    b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
+    b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K * b_mul : -1;
     b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
   }
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;   // the lo plane sits at a fixed distance
@@ -209,12 +236,12 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
         off = ((r.b * s.Ho + oh) * s.Wo + ow) * s.Cout + t_c + a_chunk[j];
       }
       const __bf16* src = q.A_hi + off + (lo ? lo_delta_a : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + lo * A_PL + (wave * A_INS + j) * 1024);
+      dma16b(ok ? (const void*)src : zero_page, St + lo * A_PL + (wave * A_INS + j) * 1024);
     } else {
       const int j = (idx - NP * A_INS) / NP, lo = (idx - NP * A_INS) % NP;
       const bool ok = b_off[j] >= 0 && (k0 + b_chunk[j]) < klim;
-      const __bf16* src = q.B_hi + (b_off[j] + k0 + b_chunk[j]) + (lo ? lo_delta_b : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + NP * A_PL + lo * B_PL + (wave * B_INS + j) * 1024);
+      const __bf16* src = q.B_hi + (b_off[j] + k0 * b_mul + b_chunk[j]) + (lo ? lo_delta_b : 0);
+      dma16b(ok ? (const void*)src : zero_page, St + NP * A_PL + lo * B_PL + (wave * B_INS + j) * 1024);
     }
   };
   auto advance_tap = [&]() {   // next stage: the next tap of this channel block, then the next block
@@ -336,6 +363,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
   char* const Bbase = lds + 2 * A_BUF;
 
   const ConvShape& s = p.s;
+  const void* const zero_page = zero_page_address();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int half = lane >> 5, li = lane & 31;
@@ -384,11 +412,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
     a_ok[j] = T < HP16 && hp < HP && (unsigned)y < (unsigned)SH && (unsigned)x < (unsigned)SW;
     a_base[j] = ((b * SH + y) * SW + x) * Cdim + 8 * ((lane & 3) ^ ((hp >> 2) & 3));
   }
+  const int b_mul = x3_paired(q.B_hi, q.B_lo, NP) ? 2 : 1;
   int b_off[B_J], b_chunk[B_J];
 #pragma unroll
   for (int j = 0; j < B_J; ++j) {
     const int r = (wave * B_J + j) * 16 + (lane >> 2);
-    b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K : -1;
+    b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K * b_mul : -1;
     b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
   }
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;
@@ -399,12 +428,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_halo_kernel(const Pa
     const int T = wave + NW * j;
     if (T >= HP16) return;   // wave-uniform
     const __bf16* src = q.A_hi + (a_base[j] + cb * XBK) + (lo ? lo_delta_a : 0);
-    dma16b(a_ok[j] ? (const void*)src : (const void*)g_zero_page, Abase + buf * A_BUF + lo * A_PL + T * 1024);
+    dma16b(a_ok[j] ? (const void*)src : zero_page, Abase + buf * A_BUF + lo * A_PL + T * 1024);
   };
   auto issue_b_piece = [&](int idx, int cb, int tap, int buf) {
     const int j = idx / NP, lo = idx % NP;
-    const __bf16* src = q.B_hi + (b_off[j] + tap * Cdim + cb * XBK + b_chunk[j]) + (lo ? lo_delta_b : 0);
-    dma16b(b_off[j] >= 0 ? (const void*)src : (const void*)g_zero_page,
+    const __bf16* src = q.B_hi + (b_off[j] + (tap * Cdim + cb * XBK) * b_mul + b_chunk[j]) + (lo ? lo_delta_b : 0);
+    dma16b(b_off[j] >= 0 ? (const void*)src : zero_page,
            Bbase + buf * B_BUF + lo * B_PL + (wave * B_J + j) * 1024);
   };
 
@@ -559,6 +588,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
   __shared__ __attribute__((aligned(16))) char lds[LDSB];
 
   const ConvShape& s = p.s;
+  const void* const zero_page = zero_page_address();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
 
@@ -619,14 +649,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
       const int k = k0 + row_k[j];
       const bool ok = a_ok[j][u] && k < kend;
       const __bf16* src = q.A_hi + ((long)k * s.Cout + a_col[j][u]) + (lo ? lo_delta_a : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (u * NP + lo) * PL + dst);
+      dma16b(ok ? (const void*)src : zero_page, St + (u * NP + lo) * PL + dst);
     } else {
       const int u = (w - NP * ASUB) / NP, lo = (w - NP * ASUB) % NP;
       const PixState& px = bpix[j];
       const int ih = px.oh * s.stride - s.pad + b_kh[j][u] * s.dil, iw = px.ow * s.stride - s.pad + b_kw[j][u] * s.dil;
       const bool ok = b_ok[j][u] && px.k < kend && (unsigned)ih < (unsigned)s.H && (unsigned)iw < (unsigned)s.W;
       const __bf16* src = q.B_hi + (((long)(px.b * s.H + ih) * s.W + iw) * s.Cin + b_ci[j][u]) + (lo ? lo_delta_b : 0);
-      dma16b(ok ? (const void*)src : (const void*)g_zero_page, St + (NP * ASUB + u * NP + lo) * PL + dst);
+      dma16b(ok ? (const void*)src : zero_page, St + (NP * ASUB + u * NP + lo) * PL + dst);
     }
   };
   auto advance_pix = [&]() {
@@ -759,6 +789,7 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
 
   const ConvShape& s = p.s;
+  const void* const zero_page = zero_page_address();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncb = s.Cin / 32;
   const int tile = blockIdx.x;
@@ -806,8 +837,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
     for (int j = 0; j < 2; ++j) {
       const long aoff = (long)(k0 + a_rowk[j]) * s.Cout + a_col[j];
       const int dst = (wave * 2 + j) * 1024;
-      dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff) : (const void*)g_zero_page, St + dst);
-      if (NP == 2) dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff + lo_delta_a) : (const void*)g_zero_page, St + A_PL + dst);
+      dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff) : zero_page, St + dst);
+      if (NP == 2) dma16b(a_ok[j] ? (const void*)(q.A_hi + aoff + lo_delta_a) : zero_page, St + A_PL + dst);
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -816,8 +847,8 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
       const int y = sy * s.stride + b_ry[j], x = sx * s.stride + b_rx[j];
       const bool ok = b_in[j] && (unsigned)y < (unsigned)s.H && (unsigned)x < (unsigned)s.W;
       const long boff = ((long)(sb * s.H + y) * s.W + x) * s.Cin + b_c[j];
-      dma16b(ok ? (const void*)(q.B_hi + boff) : (const void*)g_zero_page, St + NP * A_PL + T * 1024);
-      if (NP == 2) dma16b(ok ? (const void*)(q.B_hi + boff + lo_delta_b) : (const void*)g_zero_page, St + NP * A_PL + B_PL + T * 1024);
+      dma16b(ok ? (const void*)(q.B_hi + boff) : zero_page, St + NP * A_PL + T * 1024);
+      if (NP == 2) dma16b(ok ? (const void*)(q.B_hi + boff + lo_delta_b) : zero_page, St + NP * A_PL + B_PL + T * 1024);
     }
     sx += SEG;   // next segment (the output width is a multiple of 32)
     if (sx >= s.Wo) { sx = 0; if (++sy == s.Ho) { sy = 0; ++sb; } }
@@ -949,6 +980,27 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
+// The same into PAIRED planes (x3_paired_index): src is [rows][K], K % 32 == 0, n = rows * K.
+__global__ __launch_bounds__(256) void split_bf16_paired_kernel(const float* __restrict__ src, __bf16* __restrict__ dst,
+                                                                long n, int K) {
+  const long n8 = n >> 3;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(src)[2 * i], b = reinterpret_cast<const float4*>(src)[2 * i + 1];
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    bf16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      __bf16 hh, ll;
+      split1(v[e], hh, ll);
+      h[e] = hh; l[e] = ll;
+    }
+    const long row = (i << 3) / K, k = (i << 3) - row * K;
+    __bf16* o = dst + x3_paired_index(row, k, K);
+    *reinterpret_cast<bf16x8*>(o) = h;
+    *reinterpret_cast<bf16x8*>(o + 32) = l;
+  }
+}
+
 // fp16 path: ONE plane h[i] = fp16(src[i] * 2^shift) (shift: the gradient-plane exponent offset, 0 for activations
 // and weights).
 __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ h, long n,
@@ -988,7 +1040,8 @@ __global__ __launch_bounds__(256) void split_bf16_transposed_kernel(const float*
   for (int r = ty; r < 32; r += 8) {
     const int ci = ci0 + r, co = co0 + tx;
     if (ci < Cin && co < Cout) {
-      const size_t o = ((size_t)ci * taps + tap) * Cout + co;
+      const size_t o = x3_paired(hi, lo, 2) ? x3_paired_index(ci, (size_t)tap * Cout + co, (size_t)taps * Cout)
+                                            : ((size_t)ci * taps + tap) * Cout + co;
       if (lo) split1(tile[tx][r], hi[o], lo[o]);
       else reinterpret_cast<_Float16*>(hi)[o] = (_Float16)tile[tx][r];
     }
@@ -1040,6 +1093,13 @@ __global__ __launch_bounds__(256) void split_bf16_multi_kernel(const SplitEntry*
       split1(v[k], hh, ll);
       h[k] = hh; l[k] = ll;
     }
+    if (x3_paired(t.hi, t.lo, 2)) {   // paired planes: the record's `cin` word is the row length K (K % 32 == 0)
+      const long row = base / t.cin, k = base - row * t.cin;
+      __bf16* o = t.hi + x3_paired_index(row, k, t.cin);
+      *reinterpret_cast<bf16x8*>(o) = h;
+      *reinterpret_cast<bf16x8*>(o + 32) = l;
+      return;
+    }
     *reinterpret_cast<bf16x8*>(t.hi + base) = h;
     *reinterpret_cast<bf16x8*>(t.lo + base) = l;
   } else {
@@ -1073,7 +1133,8 @@ __global__ __launch_bounds__(256) void split_bf16_transposed_multi_kernel(const 
   for (int rr = ty; rr < 32; rr += 8) {
     const int ci = ci0 + rr, co = co0 + tx;
     if (ci < Cin && co < Cout) {
-      const size_t o = ((size_t)ci * taps + tap) * Cout + co;
+      const size_t o = x3_paired(t.hi, t.lo, 2) ? x3_paired_index(ci, (size_t)tap * Cout + co, (size_t)taps * Cout)
+                                                : ((size_t)ci * taps + tap) * Cout + co;
       if (t.lo) split1(tile[tx][rr], t.hi[o], t.lo[o]);
       else reinterpret_cast<_Float16*>(t.hi)[o] = (_Float16)tile[tx][rr];
     }

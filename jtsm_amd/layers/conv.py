@@ -52,20 +52,36 @@ def set_math(mode):
 
 
 def _planes_buf(n, device):
-    n8 = (n + 7) // 8 * 8
+    n8 = max((n + 7) // 8 * 8, 64)   # (separate planes stay more than 32 elements apart: lo == hi + 32 means PAIRED)
     if MATH == "f16":
         return torch.empty(n8, dtype=torch.int16, device=device)   # one fp16 plane
     return torch.empty(2 * n8, dtype=torch.int16, device=device)   # hi plane, then lo plane (16-byte aligned)
 
 
 def _hl(buf):
-    """(hi, lo) device pointers of a planes buffer (lo is None for the single fp16 plane)."""
+    """(hi, lo) device pointers of a planes buffer (lo is None for the single fp16 plane).  A PAIRED buffer (weights,
+    `_paired_ok`: per row, blocks of 32 hi values followed by their 32 lo values) is named by lo == hi + 64 bytes."""
     if buf is None:
         return None, None
     p = buf.data_ptr()
     if MATH == "f16":
         return C.c_void_p(p), None
+    if getattr(buf, "_paired", False):
+        return C.c_void_p(p), C.c_void_p(p + 64)
     return C.c_void_p(p), C.c_void_p(p + buf.numel())   # lo starts numel/2 int16 = numel bytes in
+
+
+# Weights as PAIRED planes (csrc/conv_x3.h `x3_paired`): one K stage of a contraction is one whole 128-byte line per
+# weight row instead of half a line from each of two arrays.  JTSM_W_PAIRED=0 keeps separate planes (sweeps).
+W_PAIRED = os.environ.get("JTSM_W_PAIRED", "1") != "0"
+
+
+def _paired_ok(w, transposed):
+    """Row length of the weight operand ([out][taps*in], transposed: [in][taps*out]) when it can be paired, else 0."""
+    if not W_PAIRED or MATH != "bf16x3" or w.numel() == 0:
+        return 0
+    k = w.numel() // w.shape[1 if transposed else 0]
+    return k if k % 32 == 0 else 0
 
 
 def _split(t, grad=False):
@@ -90,8 +106,21 @@ def split_bf16(t):
     return buf[:t.numel()], buf[n8:n8 + t.numel()]
 
 
-def _split_transposed_into(buf, w, row_scale):
+def _split_paired(w):
+    """Paired planes of a weight [out][taps][in] in its storage order (rows of k = taps * in)."""
+    k = _paired_ok(w, False)
+    buf = _planes_buf(w.numel(), w.device)
+    buf._paired = True
+    L.note_bytes(8.0 * w.numel())
+    L.check(L.lib().jtsm_split_bf16_paired_f32(L.ptr(w), C.c_void_p(buf.data_ptr()), C.c_long(w.numel() // k), k,
+                                               L.stream()), "split_bf16_paired")
+    return buf
+
+
+def _split_transposed_into(buf, w, row_scale, paired=True):
     o, i, kh, kw = w.shape
+    if paired and _paired_ok(w, True):
+        buf._paired = True
     hi, lo = _hl(buf)
     if MATH == "f16":
         L.check(L.lib().jtsm_split_f16_transposed_f32(L.ptr(w), L.ptr(row_scale), hi, o, kh * kw, i, L.stream()),
@@ -102,14 +131,14 @@ def _split_transposed_into(buf, w, row_scale):
     return buf
 
 
-def _split_transposed(w, row_scale=None):
-    return _split_transposed_into(_planes_buf(w.numel(), w.device), w, row_scale)
+def _split_transposed(w, row_scale=None, paired=True):
+    return _split_transposed_into(_planes_buf(w.numel(), w.device), w, row_scale, paired)
 
 
 def split_bf16_transposed(w, row_scale=None):
     """Planes of W^T [in][taps][out] of a channels_last (out, in, kh, kw) weight, rows pre-multiplied by
     row_scale[out] when given."""
-    buf = _split_transposed(w, row_scale)
+    buf = _split_transposed(w, row_scale, paired=False)   # (two separate planes: what this helper's callers index)
     n8 = buf.numel() // 2
     return buf[:w.numel()], buf[n8:n8 + w.numel()]
 
@@ -182,7 +211,9 @@ def _cacheable_weight(w):
 def _weight_planes(w, transposed=False, scale=None):
     """Planes of a weight ([out][taps][in], or transposed+row-scaled for the data gradient), cached by version."""
     if not _cacheable_weight(w):
-        return _split_transposed(w, scale) if transposed else _split(w)
+        if transposed:
+            return _split_transposed(w, scale)
+        return _split_paired(w) if _paired_ok(w, False) else _split(w)
     key = (w.data_ptr(), w.numel(), transposed, scale.data_ptr() if scale is not None else 0)
     e = _WPLANES.get(key)
     if e is not None and e.version == w._version:
@@ -194,11 +225,15 @@ def _weight_planes(w, transposed=False, scale=None):
         e = _WEntry()
         e.w, e.scale, e.transposed = w.detach(), scale, transposed
         e.buf = _planes_buf(w.numel(), w.device)
+        e.buf._paired = bool(_paired_ok(w, transposed))
         _WPLANES[key] = e
     hi, lo = _hl(e.buf)
     lib = L.lib()
     if transposed:
         _split_transposed_into(e.buf, w, scale)
+    elif e.buf._paired:
+        L.check(lib.jtsm_split_bf16_paired_f32(L.ptr(w), hi, C.c_long(w.shape[0]), w.numel() // w.shape[0], L.stream()),
+                "split_bf16_paired")
     elif MATH == "f16":
         L.check(lib.jtsm_split_f16_f32(L.ptr(w), hi, C.c_long(w.numel()), 0, L.stream()), "split_f16")
     else:
@@ -222,6 +257,9 @@ def refresh_weight_planes():
             for _, e in stale:
                 hi = e.buf.data_ptr()
                 lo = 0 if MATH == "f16" else hi + e.buf.numel()   # lo == 0: the record's fp16 plane goes to hi
+                paired = getattr(e.buf, "_paired", False)
+                if paired:
+                    lo = hi + 64
                 if transposed:
                     o, i, kh, kw = e.w.shape
                     nb = ((i + 31) // 32) * ((o + 31) // 32) * kh * kw
@@ -229,7 +267,8 @@ def refresh_weight_planes():
                                  kh * kw, i])
                 else:
                     nb = (e.w.numel() + 2047) // 2048
-                    rows.append([e.w.data_ptr(), hi, lo, 0, blocks, e.w.numel(), 0, 0])
+                    rows.append([e.w.data_ptr(), hi, lo, 0, blocks, e.w.numel(), 0,
+                                 e.w.numel() // e.w.shape[0] if paired else 0])
                 blocks += nb
             dev = stale[0][1].w.device
             tab = (torch.tensor(rows, dtype=torch.int64).to(dev), blocks)

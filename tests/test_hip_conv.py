@@ -575,3 +575,47 @@ def test_splitk_finishing_inside_the_kernel_is_bit_identical_to_the_separate_pas
                         assert torch.equal(a, b), ((n, c, h, w, o, k), what, float((a.float() - b.float()).abs().max()))
     finally:
         lib.jtsm_conv_set_splitk_fused(-1)
+
+
+def test_paired_weight_planes_are_the_separate_planes_rearranged(cuda, conv_math):
+    """Weights go to the contractions as PAIRED planes (csrc/conv_x3.h `x3_paired`: per row, blocks of 32 hi values
+    followed by their 32 lo values).  Bit for bit the same numbers as the two separate planes, for the straight split,
+    the transposing split, and the one-launch re-split of every cached weight after an update."""
+    if conv_math != "bf16x3":
+        pytest.skip("paired planes exist in the split-bf16 arithmetic only")
+    assert K.W_PAIRED
+
+    def unpair(buf, rows, k):
+        b = buf[:2 * rows * k].view(rows, k // 32, 2, 32)
+        return b[:, :, 0].reshape(rows, k), b[:, :, 1].reshape(rows, k)
+
+    g = torch.Generator().manual_seed(5)
+    for (o, i, kh) in [(48, 64, 3), (80, 256, 1), (256, 32, 1), (8, 96, 3)]:
+        w = torch.nn.Parameter(torch.randn(o, i, kh, kh, generator=g).cuda().contiguous(memory_format=CL))
+        hi, lo = K.split_bf16(w.detach())                                           # [out][taps][in], separate planes
+        buf = K._weight_planes(w)
+        assert getattr(buf, "_paired", False)
+        ph, pl = unpair(buf, o, kh * kh * i)
+        assert torch.equal(ph.reshape(-1), hi) and torch.equal(pl.reshape(-1), lo)
+        scale = torch.rand(o, generator=g).cuda() + 0.5
+        th, tl = K.split_bf16_transposed(w.detach(), scale)                         # [in][taps][out], separate planes
+        tbuf = K._weight_planes(w, True, scale)
+        if (kh * kh * o) % 32 == 0:
+            assert getattr(tbuf, "_paired", False)
+            ph, pl = unpair(tbuf, i, kh * kh * o)
+            assert torch.equal(ph.reshape(-1), th) and torch.equal(pl.reshape(-1), tl)
+        else:
+            assert not getattr(tbuf, "_paired", False)
+        # an update, then the table-driven re-split of all stale entries
+        with torch.no_grad():
+            w.mul_(1.7)
+        K.refresh_weight_planes()
+        hi2, lo2 = K.split_bf16(w.detach())
+        ph, pl = unpair(K._weight_planes(w), o, kh * kh * i)
+        assert torch.equal(ph.reshape(-1), hi2) and torch.equal(pl.reshape(-1), lo2)
+        th2, tl2 = K.split_bf16_transposed(w.detach(), scale)
+        tb2 = K._weight_planes(w, True, scale)
+        if getattr(tb2, "_paired", False):
+            ph, pl = unpair(tb2, i, kh * kh * o)
+            assert torch.equal(ph.reshape(-1), th2) and torch.equal(pl.reshape(-1), tl2)
+        assert not torch.equal(hi2, hi)
