@@ -453,15 +453,18 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
   constexpr int CPR = BN / 4;                 // float4 pieces per tile row
   constexpr int PIECES = ROWS * CPR / NT;     // per thread per band
   const bool raw = gridDim.y > 1;             // split-K: raw partial into this slice's slab
-  // the fused epilogue of one finished float4 piece at output row m, column n
-  auto finish_piece = [&](int m, int n, float4 v) {
+  const bool has_map = map != nullptr;
+  const MAP rows = has_map ? *map : MAP();    // by value: the closures below keep it in registers, not on the stack
+  auto row_m = [&](int r) -> int { return has_map ? rows(r) : m0 + r; };
+  // where output row m, column n lives (o) and which column the per-column epilogue operands are read at (nb)
+  auto locate = [&](int m, int n, int& nb) -> size_t {
     size_t o = (size_t)m * p.ldc + n;
+    nb = n;
     if (ROLE == DGRAD && p.scatter) {
       const int ow = m % p.sc_Wo, t = m / p.sc_Wo;
       const int oh = t % p.sc_Ho, b = t / p.sc_Ho;
       o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
     }
-    int nb = n;   // column of the per-column epilogue operands
     if (ROLE == FWD && p.shuffle_c) {
       const int ph = n / p.shuffle_c;
       nb = n - ph * p.shuffle_c;
@@ -469,40 +472,98 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
       const int y = t % p.shuffle_h, b = t / p.shuffle_h;
       o = (((size_t)(b * 2 * p.shuffle_h + 2 * y + (ph >> 1)) * (2 * p.shuffle_w)) + 2 * x + (ph & 1)) * p.shuffle_c + nb;
     }
+    return o;
+  };
+  // the arithmetic of the fused epilogue on one float4 piece, operands already in registers.  Every step is
+  // individually rounded — no FMA contraction — so that the direct epilogue, the in-kernel split-K finishing and the
+  // separate splitk_finish pass produce the same bits.
+  auto chain = [&](float4 v, bool has_scale, const float4& sc, const float4& bi, const float4& rr, const float4& mk,
+                   const short4& mp) -> float4 {   // (mk: the fp32 gate; mp: the gate read from a 16-bit plane)
     if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
-    if (ROLE == WGRAD) {
-      if (e.scale) {
-        const float sc = e.scale[m];
-        v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
-      }
-    } else if (e.scale && p.scale_rows) {
-      const float sc = e.scale[m];
-      v.x = __fmul_rn(v.x, sc); v.y = __fmul_rn(v.y, sc); v.z = __fmul_rn(v.z, sc); v.w = __fmul_rn(v.w, sc);
-    } else if (e.scale) {
-      const float4 sc = *reinterpret_cast<const float4*>(e.scale + nb);
+    if (has_scale) {
       v.x = __fmul_rn(v.x, sc.x); v.y = __fmul_rn(v.y, sc.y); v.z = __fmul_rn(v.z, sc.z); v.w = __fmul_rn(v.w, sc.w);
     }
-    // (every step individually rounded — no FMA contraction — so that the direct epilogue, the in-kernel split-K
-    // finishing and the separate splitk_finish pass produce the same bits)
     if (e.bias) {
-      const float4 bi = *reinterpret_cast<const float4*>(e.bias + nb);
       v.x = __fadd_rn(v.x, bi.x); v.y = __fadd_rn(v.y, bi.y); v.z = __fadd_rn(v.z, bi.z); v.w = __fadd_rn(v.w, bi.w);
     }
     if (e.residual) {
-      const float4 rr = *reinterpret_cast<const float4*>(e.residual + o);
       v.x = __fadd_rn(v.x, rr.x); v.y = __fadd_rn(v.y, rr.y); v.z = __fadd_rn(v.z, rr.z); v.w = __fadd_rn(v.w, rr.w);
     }
     if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
     if (e.mask) {
-      const float4 mk = *reinterpret_cast<const float4*>(e.mask + o);
       v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f; v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
     }
     if (p.mask_plane) {
-      const short4 mk = *reinterpret_cast<const short4*>(p.mask_plane + o);
-      v.x = mk.x > 0 ? v.x : 0.f; v.y = mk.y > 0 ? v.y : 0.f; v.z = mk.z > 0 ? v.z : 0.f; v.w = mk.w > 0 ? v.w : 0.f;
+      v.x = mp.x > 0 ? v.x : 0.f; v.y = mp.y > 0 ? v.y : 0.f; v.z = mp.z > 0 ? v.z : 0.f; v.w = mp.w > 0 ? v.w : 0.f;
     }
+    return v;
+  };
+  const bool row_scale = e.scale && (ROLE == WGRAD || p.scale_rows);
+  // one finished float4 piece at output row m, column n, operands fetched on the spot (the in-kernel split-K fold)
+  auto finish_piece = [&](int m, int n, float4 v) {
+    int nb;
+    const size_t o = locate(m, n, nb);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), bi = sc, rr = sc, mk = sc;
+    short4 mp = make_short4(0, 0, 0, 0);
+    if (row_scale) { const float r = e.scale[m]; sc = make_float4(r, r, r, r); }
+    else if (e.scale) sc = *reinterpret_cast<const float4*>(e.scale + nb);
+    if (e.bias) bi = *reinterpret_cast<const float4*>(e.bias + nb);
+    if (e.residual) rr = *reinterpret_cast<const float4*>(e.residual + o);
+    if (e.mask) mk = *reinterpret_cast<const float4*>(e.mask + o);
+    if (p.mask_plane) mp = *reinterpret_cast<const short4*>(p.mask_plane + o);
+    v = chain(v, e.scale != nullptr, sc, bi, rr, mk, mp);
     if (p.C) *reinterpret_cast<float4*>(p.C + o) = v;
     if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
+  };
+  // ---- the streaming loop.  A thread's pieces all sit in the SAME four columns (NT is a multiple of the pieces per
+  // row), so the per-column operands are fetched once; the per-piece operands (residual, gate) of U pieces travel
+  // together, and the NEXT group's are requested before this group's results are stored: on gfx9 stores count in
+  // vmcnt like loads and the counter retires in order, so a load issued behind a store also waits for that store's
+  // acknowledgement.  (The first form of this loop fetched scale, bias, residual and gate one after the other, each
+  // behind an s_waitcnt vmcnt(0) that also drained the previous piece's stores: three to four memory round trips
+  // per 16 bytes of output, which is what bounded the short-K layers.)
+  static_assert(NT % CPR == 0, "a thread keeps its columns from piece to piece");
+#ifndef JTSM_EPI_UMAX_BANDED
+#define JTSM_EPI_UMAX_BANDED 2
+#endif
+#ifndef JTSM_EPI_UMAX_BANDED8
+#define JTSM_EPI_UMAX_BANDED8 JTSM_EPI_UMAX_BANDED   // the eight-wave kernels (256 registers per wave)
+#endif
+  constexpr int UMAX = PASSES > 1 ? (NT == 512 ? JTSM_EPI_UMAX_BANDED8 : JTSM_EPI_UMAX_BANDED) : 4;   // (banded tiles: half the waves still hold their accumulators)
+  constexpr int U = PIECES % UMAX == 0 ? UMAX : (PIECES % 2 == 0 ? 2 : 1);
+  constexpr int NG = PIECES / U;
+  const int col = (tid % CPR) * 4, n = n0 + col;
+  const bool n_ok = n < p.N;
+  int nb_col = n;
+  if (ROLE == FWD && p.shuffle_c) nb_col = n - (n / p.shuffle_c) * p.shuffle_c;
+  float4 sc_col = make_float4(0.f, 0.f, 0.f, 0.f), bi_col = sc_col;
+  if (!raw && n_ok) {
+    if (e.scale && !row_scale) sc_col = *reinterpret_cast<const float4*>(e.scale + nb_col);
+    if (e.bias) bi_col = *reinterpret_cast<const float4*>(e.bias + nb_col);
+  }
+  const bool piped = !raw && (e.residual || e.mask || p.mask_plane);
+  int pm[U];
+  float4 prr[U], pmk[U];
+  float2 pmp[U];           // (four 16-bit gate words of a plane)
+  auto prefetch = [&](int pass, int g) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = (tid + NT * (g * U + u)) / CPR;
+      int m = row_m(pass * ROWS + row);
+      if (m >= p.M || !n_ok) m = -1;
+      pm[u] = m;
+      // a lane without a piece reads the operands' first bytes: no divergent region around the loads (the waits the
+      // compiler places at such a region's edges would serialise the pieces again)
+      int nb;
+      const size_t o = m >= 0 ? locate(m, n, nb) : 0;
+      if (e.residual) prr[u] = *reinterpret_cast<const float4*>(e.residual + o);
+      if (e.mask) pmk[u] = *reinterpret_cast<const float4*>(e.mask + o);
+      if (p.mask_plane) pmp[u] = *reinterpret_cast<const float2*>(p.mask_plane + o);
+    }
+  };
+  auto plane_gate = [&](const float2& w) -> short4 {
+    const int a = __float_as_int(w.x), b = __float_as_int(w.y);
+    return make_short4((short)(a & 0xffff), (short)(a >> 16), (short)(b & 0xffff), (short)(b >> 16));
   };
 #pragma unroll
   for (int pass = 0; pass < PASSES; ++pass) {
@@ -519,22 +580,63 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
             tile[row * BN + (wn * TN + j) * 32 + (lane & 31)] = acc[i][j][r];
           }
     }
+    if (piped && pass == 0) prefetch(0, 0);   // (behind the parking stores: the accumulators' registers are free)
     __syncthreads();
-#pragma unroll 4   // (unroll 8 — twice the epilogue operands in flight — measured: no gain, tools/sweeps/ab_lib.sh)
-    for (int it = 0; it < PIECES; ++it) {
-      const int c = tid + NT * it;
-      const int row = c / CPR, col = (c % CPR) * 4;
-      const int m = map ? (*map)(pass * ROWS + row) : m0 + pass * ROWS + row;
-      const int n = n0 + col;
-      if (m < 0 || m >= p.M || n >= p.N) continue;
-      float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
-      if (raw) {
+    if (!raw && !piped) {   // nothing to fetch per piece: LDS -> arithmetic -> stores, four pieces unrolled
+#pragma unroll 4
+      for (int it = 0; it < PIECES; ++it) {
+        const int row = (tid + NT * it) / CPR;
+        const int m = row_m(pass * ROWS + row);
+        if (m < 0 || m >= p.M || !n_ok) continue;
+        float4 sc = sc_col;
+        if (row_scale) { const float r = e.scale[m]; sc = make_float4(r, r, r, r); }
+        const float4 v = chain(*reinterpret_cast<const float4*>(tile + row * BN + col), e.scale != nullptr, sc, bi_col,
+                               sc_col, sc_col, make_short4(0, 0, 0, 0));
+        int nb;
+        const size_t o = locate(m, n, nb);
+        if (p.C) *reinterpret_cast<float4*>(p.C + o) = v;
+        if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
+      }
+      continue;
+    }
+    if (raw) {
+#pragma unroll 4
+      for (int it = 0; it < PIECES; ++it) {
+        const int row = (tid + NT * it) / CPR;
+        const int m = row_m(pass * ROWS + row);
+        if (m < 0 || m >= p.M || !n_ok) continue;
+        const float4 v = *reinterpret_cast<const float4*>(tile + row * BN + col);
         float* dst = p.slab + ((size_t)split * p.M + m) * p.ldc + n;
         if (p.tickets) st_sc1_x4(dst, v);
         else *reinterpret_cast<float4*>(dst) = v;
-        continue;
       }
-      finish_piece(m, n, v);
+      continue;
+    }
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+      float4 out[U];
+      int om[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {   // (no lane-dependent branch before the stores: see prefetch)
+        om[u] = pm[u];
+        const int row = (tid + NT * (g * U + u)) / CPR;
+        float4 sc = sc_col;
+        if (row_scale) { const float r = e.scale[om[u] < 0 ? 0 : om[u]]; sc = make_float4(r, r, r, r); }
+        short4 mp = make_short4(0, 0, 0, 0);
+        if (p.mask_plane) mp = plane_gate(pmp[u]);
+        out[u] = chain(*reinterpret_cast<const float4*>(tile + row * BN + col), e.scale != nullptr, sc, bi_col, prr[u],
+                       pmk[u], mp);
+      }
+      if (g + 1 < NG) prefetch(pass, g + 1);
+      else if (pass + 1 < PASSES) prefetch(pass + 1, 0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (om[u] < 0) continue;
+        int nb;
+        const size_t o = locate(om[u], n, nb);
+        if (p.C) *reinterpret_cast<float4*>(p.C + o) = out[u];
+        if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out[u], p.out_shift);
+      }
     }
   }
   if (!(raw && p.tickets)) return;
@@ -545,7 +647,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
   splitk_fold(p, NPIECE, [&](int k, int& m, int& n) {
     const int c = tid + NT * k;
     const int row = c / CPR, col = (c % CPR) * 4;
-    m = map ? (*map)(row) : m0 + row;
+    m = row_m(row);
     n = n0 + col;
     return m >= 0 && m < p.M && n < p.N;
   }, finish_piece);
@@ -1010,8 +1112,9 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 // G > 1 (many slices of a SMALL result — the weight gradients of narrow layers over 10^5 pixels): G threads share an
 // output piece, thread g adding slices g, g + G, ... and the G partial sums being added in order g = 0 .. G-1 through
 // LDS; with one thread per piece those launches were a few thousand threads each walking 64-256 dependent loads.
-template <int VEC, int G = 1>
-__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
+// G > 1: G threads share an output piece (the first form of the kernel, unchanged).
+template <int VEC, int G>
+__global__ __launch_bounds__(256) void splitk_finish_shared(const Params p, int splits, int scale_by_row) {
   if (p.bias_out) {   // the weight gradient's bias partials: 32 lanes per output channel, a fixed reduction tree
     const int r = threadIdx.x >> 5, l = threadIdx.x & 31;
     for (int mb = blockIdx.x; mb * 8 < p.M; mb += gridDim.x) {
@@ -1094,6 +1197,151 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
   }
 }
 
+// G == 1: one thread per output piece; the epilogue's operands and up to four slices' loads travel together.
+template <int VEC, int G = 1>
+__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
+  if (p.bias_out) {   // the weight gradient's bias partials: 32 lanes per output channel, a fixed reduction tree
+    const int r = threadIdx.x >> 5, l = threadIdx.x & 31;
+    for (int mb = blockIdx.x; mb * 8 < p.M; mb += gridDim.x) {
+      const int m = mb * 8 + r;
+      float t = 0.f;
+      if (m < p.M)
+        for (int s = l; s < splits; s += 32) t = __fadd_rn(t, p.bias_slab[(size_t)s * p.M + m]);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) t = __fadd_rn(t, __shfl_xor(t, o, 32));
+      if (l == 0 && m < p.M) p.bias_out[m] = t;
+    }
+  }
+  const int nv = p.N / VEC;
+  const long total = (long)p.M * nv;
+  const Epilogue& e = p.e;
+  const float alpha = pow2i(-p.in_shift);
+  constexpr int PPB = 256 / G;                       // output pieces per workgroup and trip
+  __shared__ float red[G > 1 ? 256 * VEC : 1];
+  const int pl = threadIdx.x % PPB, g = threadIdx.x / PPB;
+  for (long i0 = (long)blockIdx.x * PPB; i0 < total; i0 += (long)gridDim.x * PPB) {   // (trip count is block-uniform)
+    const long i = i0 + pl;
+    const bool live = i < total;
+    const int n = live ? (int)(i % nv) * VEC : 0;
+    const long m = live ? i / nv : 0;
+    float v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) v[j] = 0.f;
+    // the epilogue's own operands are requested first (by the thread that will apply them): they travel with the slabs
+    size_t o = (size_t)m * p.ldc + n;
+    if (p.scatter) {
+      const int ow = (int)(m % p.sc_Wo);
+      const long t = m / p.sc_Wo;
+      const int oh = (int)(t % p.sc_Ho), b = (int)(t / p.sc_Ho);
+      o = ((size_t)(b * p.sc_H + oh * p.sc_stride) * p.sc_W + ow * p.sc_stride) * p.ldc + n;
+    }
+    float e_sc[VEC], e_bi[VEC], e_rr[VEC], e_mk[VEC];
+    short e_mp[VEC];
+    if (G == 1 && live) {   // (G > 1 — many slices of a small result — fetches them after the fold: measured faster)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (e.scale) e_sc[j] = e.scale[scale_by_row ? m : n + j];
+        if (e.bias) e_bi[j] = e.bias[n + j];
+      }
+      if (VEC == 4) {   // (16-byte alignment of residual / mask and 8-byte alignment of the gate plane: finish_split)
+        if (e.residual) {
+          const float4 t = *reinterpret_cast<const float4*>(e.residual + o);
+          e_rr[0] = t.x; e_rr[1 % VEC] = t.y; e_rr[2 % VEC] = t.z; e_rr[3 % VEC] = t.w;
+        }
+        if (e.mask) {
+          const float4 t = *reinterpret_cast<const float4*>(e.mask + o);
+          e_mk[0] = t.x; e_mk[1 % VEC] = t.y; e_mk[2 % VEC] = t.z; e_mk[3 % VEC] = t.w;
+        }
+        if (p.mask_plane) {
+          const short4 t = *reinterpret_cast<const short4*>(p.mask_plane + o);
+          e_mp[0] = t.x; e_mp[1 % VEC] = t.y; e_mp[2 % VEC] = t.z; e_mp[3 % VEC] = t.w;
+        }
+      } else {
+        if (e.residual) e_rr[0] = e.residual[o];
+        if (e.mask) e_mk[0] = e.mask[o];
+        if (p.mask_plane) e_mp[0] = (short)p.mask_plane[o];
+      }
+    }
+    if (live) {
+      int s = g;
+      if (VEC == 4 && G == 1) {
+        // UF slices' loads travel together (left as one load behind an s_waitcnt per slice, the fold was a chain of
+        // memory round trips: ~3.5 TB/s of cache-resident slabs); the sums are still formed in slice order.
+        const size_t slab_stride = (size_t)p.M * p.ldc;
+        const float* src = p.slab + ((size_t)s * p.M + m) * p.ldc + n;
+        auto fold = [&](auto uf_c) {
+          constexpr int UF = decltype(uf_c)::value;
+          float4 t[UF];
+#pragma unroll
+          for (int u = 0; u < UF; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)u * G * slab_stride);
+#pragma unroll
+          for (int u = 0; u < UF; ++u) {
+            v[0] = __fadd_rn(v[0], t[u].x); v[1 % VEC] = __fadd_rn(v[1 % VEC], t[u].y);
+            v[2 % VEC] = __fadd_rn(v[2 % VEC], t[u].z); v[3 % VEC] = __fadd_rn(v[3 % VEC], t[u].w);
+          }
+          src += (size_t)UF * G * slab_stride;
+          s += UF * G;
+        };
+        while (s + 3 * G < splits) fold(std::integral_constant<int, 4>{});
+        if (s + G < splits) fold(std::integral_constant<int, 2>{});
+        if (s < splits) fold(std::integral_constant<int, 1>{});
+      } else if (VEC == 4) {   // (G threads per piece: a thread adds few slices; measured slower unrolled)
+        for (; s < splits; s += G) {
+          const float4 t = *reinterpret_cast<const float4*>(p.slab + ((size_t)s * p.M + m) * p.ldc + n);
+          v[0] = __fadd_rn(v[0], t.x); v[1 % VEC] = __fadd_rn(v[1 % VEC], t.y);
+          v[2 % VEC] = __fadd_rn(v[2 % VEC], t.z); v[3 % VEC] = __fadd_rn(v[3 % VEC], t.w);
+        }
+      } else {
+        for (; s < splits; s += G) v[0] += p.slab[((size_t)s * p.M + m) * p.ldc + n];
+      }
+    }
+    if (G > 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) red[(g * PPB + pl) * VEC + j] = v[j];
+      __syncthreads();
+      if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          float t = 0.f;
+          for (int k = 0; k < G; ++k) t = __fadd_rn(t, red[(k * PPB + pl) * VEC + j]);
+          v[j] = t;
+        }
+      }
+      __syncthreads();
+      if (g != 0) continue;
+    }
+    if (!live) continue;
+    if (G > 1) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        if (e.scale) e_sc[j] = e.scale[scale_by_row ? m : n + j];
+        if (e.bias) e_bi[j] = e.bias[n + j];
+        if (e.residual) e_rr[j] = e.residual[o + j];
+        if (e.mask) e_mk[j] = e.mask[o + j];
+        if (p.mask_plane) e_mp[j] = (short)p.mask_plane[o + j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float x = v[j] * alpha;                                   // (a power of two: exact)
+      if (e.scale) x = __fmul_rn(x, e_sc[j]);
+      if (e.bias) x = __fadd_rn(x, e_bi[j]);
+      if (e.residual) x = __fadd_rn(x, e_rr[j]);
+      if (e.relu) x = fmaxf(x, 0.f);
+      if (e.mask) x = e_mk[j] > 0.f ? x : 0.f;
+      if (p.mask_plane) x = e_mp[j] > 0 ? x : 0.f;
+      v[j] = x;
+    }
+    if (VEC == 4) {
+      const float4 out = make_float4(v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]);
+      if (p.C) *reinterpret_cast<float4*>(p.C + o) = out;
+      if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out, p.out_shift);
+    } else {
+      p.C[o] = v[0];
+    }
+  }
+}
+
 // How many K slices for an (ntiles, ktiles) problem: aim at >= 3 workgroups per CU, keep >= 4 K tiles
 // (128 k) per slice, at most 16 slices.
 inline int plan_splits(int ntiles, int ktiles, int target = 768) {
@@ -1159,11 +1407,12 @@ inline bool use_fused_finish(Params& p, int ntiles, int splits, hipStream_t st) 
 inline int finish_split(const Params& p, int splits, hipStream_t st, int scale_by_row = 0) {
   scale_by_row = scale_by_row || p.scale_rows;
   const bool vec = p.N % 4 == 0 && p.ldc % 4 == 0 && aligned16(p.C) && aligned16(p.slab) &&
-                   (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask));
+                   (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
+                   ((uintptr_t)p.mask_plane & 7) == 0;
   const long total = (long)p.M * (vec ? p.N / 4 : p.N);
   if (vec && splits >= 32 && total <= (1L << 18)) {   // many slices of a result below 4 MB: 16 threads per piece
     const long nb = (total + 15) / 16;
-    hipLaunchKernelGGL((splitk_finish<4, 16>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, st, p, splits,
+    hipLaunchKernelGGL((splitk_finish_shared<4, 16>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, st, p, splits,
                        scale_by_row);
     JTSM_CHECK_LAUNCH("splitk_finish");
     return JTSM_OK;
@@ -1939,7 +2188,7 @@ int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, 
       const int ktiles = ceil_div(p.K, XBK);
       const int kps = ceil_div(ktiles, sp);
       sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
-      if (c != 2 && ceil_div(ktiles, sp) <= 4) nb = 1;
+      if (c != 2 && ceil_div(ktiles, sp) <= x3_nbuf1_stages(role)) nb = 1;
     }
   }
   if (wm) *wm = cfg[0];

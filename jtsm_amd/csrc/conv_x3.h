@@ -121,8 +121,15 @@ __device__ __forceinline__ void dma16b(const void* g, void* lds_uniform_base) {
 // BM x BN = 32*WM*TM x 32*WN*TN outputs.  The loop is bound by how many operand bytes a CU can keep in
 // flight from L2 (measured: the same kernel without its MFMAs takes 67-90 % of the full time, and LDS limits
 // the bytes in flight), so the large layers use 256x256 (half the operand bytes per FLOP of 128x128).
+#ifndef JTSM_X3_NBUF1_WGS
+// Workgroups per CU the single-buffered four-wave kernels are compiled for.  3 (170 registers): the pipelined epilogue
+// (store_tile_wide) keeps its operands in registers; at 4 (128 registers) it spills into scratch and these
+// output-bound layers lose more than the fourth workgroup gives (measured, tools/sweeps/ab_libs.sh: 64 -> 256 channels
+// at 256 x 256: 79 us at 3, 137 us at 4 with spills, 121 us with the unpipelined epilogue at 4).
+#define JTSM_X3_NBUF1_WGS 3
+#endif
 template <int ROLE, int WM, int WN, int TM, int TN, int NBUF, int NP = 2>
-__global__ __launch_bounds__(64 * WM * WN, (NBUF == 1 && WM * WN == 4) ? 4 : (WM * WN == 4 ? 2 : 2))
+__global__ __launch_bounds__(64 * WM * WN, (NBUF == 1 && WM * WN == 4) ? JTSM_X3_NBUF1_WGS : (WM * WN == 4 ? 2 : 2))
 void igemm_x3_kernel(const Params p, const X3Planes q) {
   static_assert(ROLE == FWD || ROLE == DGRAD, "bf16x3: forward and data-gradient roles");
   constexpr int NW = WM * WN, NT = 64 * NW;
@@ -1149,6 +1156,13 @@ inline bool x3_eligible(int role, const ConvShape& s) {
   return c % XBK == 0 || (taps == 1 && c % 8 == 0);
 }
 
+// Longest K sweep (in stages) the single-buffered four-wave kernels take (see launch_x3_cfg; env overrides for sweeps).
+inline int x3_nbuf1_stages(int role) {
+  static const int fwd = [] { const char* e = getenv("JTSM_X3_NBUF1_STAGES_FWD"); return e ? atoi(e) : 2; }();
+  static const int dgrad = [] { const char* e = getenv("JTSM_X3_NBUF1_STAGES_DGRAD"); return e ? atoi(e) : 2; }();
+  return role == FWD ? fwd : dgrad;
+}
+
 // Launch one tile configuration, with its split-K plan.
 template <int ROLE, int WM, int WN, int TM, int TN, int NP>
 int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, int round_blocks,
@@ -1172,9 +1186,12 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
                "conv bf16x3: a gate plane, a row scale or a planes-only result needs N %% 4 == 0 and 16-byte aligned tensors");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
   const bool fused = use_fused_finish(p, ntiles, splits, st);
-  if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= 4)
-    // A sweep of <= 4 stages is bound by its output / residual traffic, not by the matrix pipes: the
-    // single-buffered instantiation (32-40 KiB of LDS, four workgroups per CU) keeps more of it in flight.
+  if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= x3_nbuf1_stages(ROLE))
+    // A sweep of one or two stages is bound by its output / residual traffic, not by the matrix pipes: the
+    // single-buffered instantiation (32-40 KiB of LDS, three workgroups per CU) keeps more of it in flight.
+    // (Up to round 2 this was <= 4 stages at four workgroups per CU; with the pipelined epilogue the four-stage
+    // layers run faster double-buffered — 128 -> 512 channels at 128 x 128: 56 us against 65 us — sweeps:
+    // JTSM_X3_NBUF1_STAGES_FWD / _DGRAD.)
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 1, NP>), grid, dim3(NT), 0, st, p, q);
   else
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2, NP>), grid, dim3(NT), 0, st, p, q);
