@@ -1233,9 +1233,17 @@ inline bool x3_halo_ok(int role, const Params& p) {
   const int c = role == FWD ? s.Cin : s.Cout;
   const int OH = role == FWD ? s.Ho : s.H, OW = role == FWD ? s.Wo : s.W;
   // maps below 32 x 32 waste too much of the 8 x 16 patches; layers large enough for 256 x 256 tiles stay there
-  // (measured equal or better, tools/sweeps/x3_sweep.py)
+  // (measured equal or better, tools/sweeps/x3_sweep.py).
+  // Measured alternative, default off (JTSM_X3_HALO_SMALL=1) — pooled roi maps (the mask heads' 14 x 14): ONE 16 x 16
+  // patch of the 256-channel kernel holds a whole image, its 16 x 16 input (the map and its zero border) IS the halo, so
+  // the activations travel to LDS once per 32 channels instead of once per tap and the launch has one workgroup per
+  // roi.  But a quarter of the patch rows are computed for nothing, and this kernel is the one closest to the matrix
+  // pipes' limit (55 % busy): 172 / 176 us against 157 / 169 us (forward / data gradient, 255 rois) on the generic
+  // 256 x 256 tiling.
+  static const bool small_maps = [] { const char* e = getenv("JTSM_X3_HALO_SMALL"); return e && atoi(e) != 0; }();
+  const bool whole_image = small_maps && OH <= 16 && OW <= 16 && OH * OW >= 160 && x3_tile_choice(p) == 2;
   return !p.scatter && s.KH == 3 && s.KW == 3 && s.stride == 1 && s.dil == 1 && c % XBK == 0 && p.N > 64 &&
-         OH >= 32 && OW >= 32;
+         ((OH >= 32 && OW >= 32) || whole_image);
 }
 
 template <int ROLE, bool BIG, int NP>

@@ -518,7 +518,8 @@ def test_fc_stack_as_one_node_matches_layer_by_layer(cuda):
     (2, 256, 64, 64, 256, 3, 1, 1),        # res4 3x3
     (2, 512, 128, 128, 1024, 1, 2, 0),     # strided 1x1 shortcut (scatter data gradient)
     (4000, 12544, 1, 1, 2048, 1, 1, 0),    # DAN fc1 at BASELINE size
-], ids=["p2_3x3", "res4_1x1", "res4_3x3", "shortcut_s2", "dan_fc1"])
+    (300, 256, 14, 14, 256, 3, 1, 1),      # mask-head 3x3 on 300 pooled rois
+], ids=["p2_3x3", "res4_1x1", "res4_3x3", "shortcut_s2", "dan_fc1", "mask_3x3"])
 def test_full_size_adjointness(cuda, shape):
     """BASELINE-size layers, no oracle needed: forward, data gradient and weight gradient are three views of one
     trilinear form, so <conv(x,w), dy> = <x, dgrad(dy,w)> = <w, wgrad(dy,x)> (dots accumulated in fp64)."""
@@ -537,6 +538,27 @@ def test_full_size_adjointness(cuda, shape):
     # and the forward is linear in x
     y2 = K.conv2d_forward(x * 0.5, w, s, p, 1)
     assert float((y2 - 0.5 * y).abs().max()) <= REL * float(y.abs().max())
+
+
+def test_mask_head_3x3_on_many_pooled_rois(cuda, conv_math):
+    """The mask heads' 3x3 convolutions on 14 x 14 pooled maps at a BASELINE-like roi count (the 256 x 256 tiling; with
+    JTSM_X3_HALO_SMALL=1 the whole-image halo patches, csrc/conv_x3.h: x3_halo_ok).  Forward (fused epilogue) and data
+    gradient (accumulate + gate) against the torch-CPU oracle."""
+    N, C_, O = 176, 256, 256
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C_, 14, 14, generator=g)
+    w = torch.randn(O, C_, 3, 3, generator=g) * (2.0 / (C_ * 9)) ** 0.5
+    bias = torch.randn(O, generator=g)
+    xd, wd = x.to(cuda).contiguous(memory_format=CL), w.to(cuda).contiguous(memory_format=CL)
+    y = K.conv2d_forward(xd, wd, 1, 1, 1, None, bias.to(cuda), None, True)
+    close(y, nnref.conv_bn_act(x, w, 1, 1, 1, None, bias, None, True), "forward")
+    dy = torch.randn(y.shape, generator=g)
+    acc, gate = torch.randn(x.shape, generator=g), torch.randn(x.shape, generator=g)
+    xr = x.clone().requires_grad_(True)
+    nnref.conv_bn_act(xr, w, 1, 1, 1).backward(dy)
+    dyd = dy.to(cuda).contiguous(memory_format=CL)
+    dx = K.conv2d_backward_data(dyd, wd, tuple(x.shape), 1, 1, 1, accumulate=acc.to(cuda), relu_mask=gate.to(cuda))
+    close(dx, (xr.grad + acc) * (gate > 0), "dgrad+acc+gate")
 
 
 def test_splitk_finishing_inside_the_kernel_is_bit_identical_to_the_separate_pass(cuda, conv_math):
