@@ -779,6 +779,10 @@ int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const floa
 int jtsm_preprocess_images_u8(const uint8_t* const* images, const int32_t* heights, const int32_t* widths, int B,
                               int C, const float* mean, const float* stdv, float pad_value, int Hp, int Wp,
                               float* out, void* stream);
+/* The same for images that arrive as float32 planes (the reference accepts any dtype: `(x - mean) / std` promotes). */
+int jtsm_preprocess_images_f32(const float* const* images, const int32_t* heights, const int32_t* widths, int B,
+                               int C, const float* mean, const float* stdv, float pad_value, int Hp, int Wp,
+                               float* out, void* stream);
 
 #ifdef __cplusplus
 }

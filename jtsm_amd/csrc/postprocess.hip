@@ -962,13 +962,14 @@ namespace jtsm {
 namespace {
 constexpr int kMaxImages = 16;
 struct ImageTable {
-  const uint8_t* p[kMaxImages];
+  const void* p[kMaxImages];
   int h[kMaxImages], w[kMaxImages];
 };
 
-__global__ __launch_bounds__(256) void preprocess_u8_kernel(ImageTable t, int C, int Hp, int Wp, float m0, float m1, float m2,
-                                                            float s0, float s1, float s2, float pad,
-                                                            float* __restrict__ out) {
+template <typename SRC>   // uint8_t (the mappers' planes) or float (images that arrive as floating point)
+__global__ __launch_bounds__(256) void preprocess_kernel(ImageTable t, int C, int Hp, int Wp, float m0, float m1, float m2,
+                                                         float s0, float s1, float s2, float pad,
+                                                         float* __restrict__ out) {
 #pragma clang fp contract(off)
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
   if (x >= Wp) return;
@@ -976,7 +977,7 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(ImageTable t, int C,
   float* o = out + (((size_t)b * Hp + y) * Wp + x) * C;
   const float mean[3] = {m0, m1, m2}, stdv[3] = {s0, s1, s2};
   if (y < h && x < w) {
-    const uint8_t* src = t.p[b] + (size_t)y * w + x;
+    const SRC* src = static_cast<const SRC*>(t.p[b]) + (size_t)y * w + x;
     for (int c = 0; c < C; ++c) o[c] = ((float)src[(size_t)c * h * w] - mean[c]) / stdv[c];
   } else {
     for (int c = 0; c < C; ++c) o[c] = pad;
@@ -985,26 +986,41 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(ImageTable t, int C,
 }  // namespace
 }  // namespace jtsm
 
-extern "C" int jtsm_preprocess_images_u8(const uint8_t* const* images, const int32_t* heights, const int32_t* widths,
-                                         int B, int C, const float* mean, const float* stdv, float pad_value, int Hp,
-                                         int Wp, float* out, void* stream) {
+namespace jtsm {
+namespace {
+template <typename SRC>
+int preprocess_images(const SRC* const* images, const int32_t* heights, const int32_t* widths, int B, int C,
+                      const float* mean, const float* stdv, float pad_value, int Hp, int Wp, float* out, void* stream) {
   JTSM_REQUIRE(B >= 0 && (C == 1 || C == 3) && Hp >= 1 && Wp >= 1, "preprocess_images: bad sizes (C must be 1 or 3)");
   if (B == 0) return JTSM_OK;
   JTSM_REQUIRE(images && heights && widths && mean && stdv && out, "preprocess_images: null pointer");
   JTSM_REQUIRE(Hp <= 65535, "preprocess_images: at most 65535 rows");
-  for (int b0 = 0; b0 < B; b0 += jtsm::kMaxImages) {
-    const int nb = std::min(jtsm::kMaxImages, B - b0);
-    jtsm::ImageTable t = {};
+  for (int b0 = 0; b0 < B; b0 += kMaxImages) {
+    const int nb = std::min(kMaxImages, B - b0);
+    ImageTable t = {};
     for (int i = 0; i < nb; ++i) {
       JTSM_REQUIRE(images[b0 + i] && heights[b0 + i] >= 0 && widths[b0 + i] >= 0 && heights[b0 + i] <= Hp &&
                        widths[b0 + i] <= Wp, "preprocess_images: image %d does not fit the batch shape", b0 + i);
       t.p[i] = images[b0 + i]; t.h[i] = heights[b0 + i]; t.w[i] = widths[b0 + i];
     }
-    hipLaunchKernelGGL(jtsm::preprocess_u8_kernel, dim3(jtsm::ceil_div(Wp, 256), Hp, nb), dim3(256), 0,
-                       jtsm::as_stream(stream), t, C, Hp, Wp, mean[0], C > 1 ? mean[1] : 0.f, C > 1 ? mean[2] : 0.f,
-                       stdv[0], C > 1 ? stdv[1] : 1.f, C > 1 ? stdv[2] : 1.f, pad_value,
-                       out + (size_t)b0 * Hp * Wp * C);
+    hipLaunchKernelGGL(preprocess_kernel<SRC>, dim3(ceil_div(Wp, 256), Hp, nb), dim3(256), 0, as_stream(stream), t, C,
+                       Hp, Wp, mean[0], C > 1 ? mean[1] : 0.f, C > 1 ? mean[2] : 0.f, stdv[0], C > 1 ? stdv[1] : 1.f,
+                       C > 1 ? stdv[2] : 1.f, pad_value, out + (size_t)b0 * Hp * Wp * C);
     JTSM_CHECK_LAUNCH("preprocess_images");
   }
   return JTSM_OK;
+}
+}  // namespace
+}  // namespace jtsm
+
+extern "C" int jtsm_preprocess_images_u8(const uint8_t* const* images, const int32_t* heights, const int32_t* widths,
+                                         int B, int C, const float* mean, const float* stdv, float pad_value, int Hp,
+                                         int Wp, float* out, void* stream) {
+  return jtsm::preprocess_images<uint8_t>(images, heights, widths, B, C, mean, stdv, pad_value, Hp, Wp, out, stream);
+}
+
+extern "C" int jtsm_preprocess_images_f32(const float* const* images, const int32_t* heights, const int32_t* widths,
+                                          int B, int C, const float* mean, const float* stdv, float pad_value, int Hp,
+                                          int Wp, float* out, void* stream) {
+  return jtsm::preprocess_images<float>(images, heights, widths, B, C, mean, stdv, pad_value, Hp, Wp, out, stream);
 }

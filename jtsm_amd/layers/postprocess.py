@@ -195,10 +195,13 @@ def panoptic_combine(masks, scores, classes, sem, num_sem_classes, overlap_thres
 
 @torch.no_grad()
 def preprocess_images_u8(images, mean, std, size_divisibility=0, pad_value=0.0):
-    """uint8 (C, h, w) device images -> ((B, C, Hp, Wp) float32 in channels-last storage, image_sizes):
+    """uint8 (or float32) (C, h, w) device images -> ((B, C, Hp, Wp) float32 in channels-last storage, image_sizes):
     (x - mean) / std, zero padding, one launch (mcnn.py:303-318 + ImageList.from_tensors)."""
     L.require_gpu(*images)
     images = [im.contiguous() for im in images]
+    if any(im.dtype != images[0].dtype for im in images) or images[0].dtype not in (torch.uint8, torch.float32):
+        raise TypeError("preprocess_images: uint8 or float32 planes, one dtype per batch")
+    entry = L.lib().jtsm_preprocess_images_u8 if images[0].dtype == torch.uint8 else L.lib().jtsm_preprocess_images_f32
     Cc = images[0].shape[0]
     sizes = [(int(im.shape[-2]), int(im.shape[-1])) for im in images]
     hp, wp = max(s[0] for s in sizes), max(s[1] for s in sizes)
@@ -211,9 +214,12 @@ def preprocess_images_u8(images, mean, std, size_divisibility=0, pad_value=0.0):
     ws = (C.c_int32 * B)(*[s[1] for s in sizes])
     m = (C.c_float * Cc)(*[float(v) for v in mean])
     sd = (C.c_float * Cc)(*[float(v) for v in std])
-    L.check(L.lib().jtsm_preprocess_images_u8(_ptr_array(images), hs, ws, B, Cc, m, sd, L.f32(pad_value), hp, wp,
-                                              L.ptr(out), L.stream()), "preprocess_images")
+    L.check(entry(_ptr_array(images), hs, ws, B, Cc, m, sd, L.f32(pad_value), hp, wp, L.ptr(out), L.stream()),
+            "preprocess_images")
     return out, sizes
+
+
+preprocess_images = preprocess_images_u8   # (either source dtype)
 
 
 @torch.no_grad()

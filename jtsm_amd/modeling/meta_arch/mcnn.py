@@ -48,8 +48,10 @@ class GeneralizedMCNNWSL(nn.Module):
 
     def preprocess_image(self, batched_inputs):
         images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
-        if images[0].dtype == torch.uint8 and images[0].is_cuda:
-            # the mappers' uint8 planes: normalise + pad + channels-last in one launch (csrc/postprocess.hip)
+        if images[0].is_cuda and images[0].dim() == 3 and images[0].shape[0] in (1, 3) and \
+                all(im.dtype == images[0].dtype for im in images) and images[0].dtype in (torch.uint8, torch.float32):
+            # the mappers' uint8 planes (or float32 images): normalise + pad + channels-last in one launch
+            # (csrc/postprocess.hip), the very bits of `(x - mean) / std` + ImageList.from_tensors
             mean, std = self._pixel_stats()
             tensor, sizes = preprocess_images_u8(images, mean, std, self.backbone.size_divisibility)
             return ImageList(tensor, sizes)

@@ -130,6 +130,23 @@ def test_preprocess_images_u8_is_bit_exact(cuda):
 
 
 @pytest.mark.gpu
+def test_preprocess_images_f32_is_bit_exact(cuda):
+    """Float32 images through the same launch: the bits of `(x - mean) / std` + ImageList.from_tensors."""
+    from jtsm_amd.layers.postprocess import preprocess_images
+    from jtsm_amd.structures import ImageList
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.rand(3, h, w, generator=g) * 255 for h, w in ((37, 61), (64, 40), (1, 1))]
+    mean, std = [102.9801, 115.9465, 122.7717], [1.0, 57.375, 58.395]
+    out, sizes = preprocess_images([i.cuda() for i in imgs], mean, std, size_divisibility=32)
+    m, s = torch.tensor(mean).view(3, 1, 1), torch.tensor(std).view(3, 1, 1)
+    want = ImageList.from_tensors([(im - m) / s for im in imgs], 32, channels_last=True)
+    assert sizes == want.image_sizes and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out.cpu(), want.tensor)
+    with pytest.raises(TypeError):
+        preprocess_images([imgs[0].cuda().double()], mean, std)
+
+
+@pytest.mark.gpu
 def test_prefetcher_delivers_identical_batches_and_model_trains(cuda):
     import sys
     sys.path.insert(0, os.path.dirname(__file__))
