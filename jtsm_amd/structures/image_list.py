@@ -37,6 +37,12 @@ class ImageList:
             max_h = (max_h + size_divisibility - 1) // size_divisibility * size_divisibility
             max_w = (max_w + size_divisibility - 1) // size_divisibility * size_divisibility
         batch_shape = [len(tensors)] + list(tensors[0].shape[:-2]) + [max_h, max_w]
+        if all(s == (max_h, max_w) for s in image_sizes):
+            # nothing to pad (equal sizes, already divisible): one gather instead of a fill and a copy per image
+            batched = torch.stack(list(tensors))
+            if channels_last and batched.dim() == 4:
+                batched = batched.contiguous(memory_format=torch.channels_last)
+            return ImageList(batched, image_sizes)
         if channels_last and len(batch_shape) == 4:
             batched = tensors[0].new_full(batch_shape, pad_value).contiguous(memory_format=torch.channels_last)
         else:
