@@ -1209,7 +1209,10 @@ inline int x3_tile_choice(const Params& p) {
   const int ktiles = ceil_div(p.K, XBK);
   // tiles x stages (measured crossover, tools/sweeps/x3_sweep.py + layer timings; JTSM_X3_MIN_WORK overrides for sweeps)
   static const long min_work = [] { const char* e = getenv("JTSM_X3_MIN_WORK"); return e ? atol(e) : 9216L; }();
-  if (p.N >= 192 && t256 * ktiles >= min_work && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
+  // (long sweeps pay earlier: 196 tiles x 32 stages — the 2x2 / stride-2 role of the mask heads' transposed convolution —
+  // 133 -> 116 us on 256-tiles, while 8-stage layers of the same tiles x stages lose 3 %: two thirds of the bar from 16 stages)
+  const long bar = ktiles >= 16 ? min_work * 2 / 3 : min_work;
+  if (p.N >= 192 && t256 * ktiles >= bar && (p.N % 256 == 0 || p.N % 256 > 128)) return 2;
   // 64 x 64 tiles for the small layers (res4 / res5 1x1 convolutions on 64 x 64 and 32 x 32 maps): at 128 x 128 they
   // are <= 128 tiles and need 4-8 K slices to fill the chip — each slice writes a slab and a finishing launch folds
   // them; four times as many small tiles fill it with 1-2 slices.
