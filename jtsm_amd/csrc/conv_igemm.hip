@@ -1396,7 +1396,10 @@ inline int* tickets_for(hipStream_t st) {
 // Decide how a split launch is finished: sets p.tickets (and returns true) when the kernel itself will do it.
 inline bool use_fused_finish(Params& p, int ntiles, int splits, hipStream_t st) {
   p.tickets = nullptr;
-  if (splits <= 1 || !p.wide || ntiles > kTicketCap || !splitk_fused_enabled()) return false;
+  // JTSM_SPLITK_FUSED_MAX_MB: finish inside the kernel only where all slabs together stay below this size (sweeps)
+  static const long fused_max_bytes = [] { const char* e = getenv("JTSM_SPLITK_FUSED_MAX_MB"); return e ? atol(e) << 20 : 0L; }();
+  const bool small = g_splitk_fused_override.load() < 0 && (long)splits * p.M * p.ldc * (long)sizeof(float) <= fused_max_bytes;
+  if (splits <= 1 || !p.wide || ntiles > kTicketCap || !(splitk_fused_enabled() || small)) return false;
   // (the separate pass adds 32+ slices of a small result in a different — still fixed — order: keep those on it, so
   // that the two ways of finishing stay bit-identical wherever both exist)
   if (splits >= 32 && (long)p.M * (p.N / 4) <= (1L << 18)) return false;
