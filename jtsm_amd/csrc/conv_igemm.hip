@@ -2192,6 +2192,7 @@ int jtsm_conv_bf16x3_plan(const jtsm_conv_shape* s, int role, int* wm, int* wn, 
       const int kps = ceil_div(ktiles, sp);
       sp = kps > 0 ? ceil_div(ktiles, kps) : 1;
       if (c != 2 && ceil_div(ktiles, sp) <= x3_nbuf1_stages(role)) nb = 1;
+      else if (c == 3 && x3_ring_enabled() && ceil_div(ktiles, sp) >= 4) nb = 4;   // the four-stage ring
     }
   }
   if (wm) *wm = cfg[0];

@@ -292,16 +292,41 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
   constexpr int SLOTS = 2 * TM * TN;                        // MFMA groups per stage (2 k-steps x TM x TN tiles)
   constexpr int PER_SLOT = (PIECES + SLOTS - 1) / SLOTS;    // loads placed behind each group
   if (NBUF == 2 && ntile_k > 0) issue(0);
+  if (NBUF > 2) {
+    // Ring of NBUF stages (the 64 x 64 tiles of the long-K 1x1 layers): a stage's six MFMA per wavefront (~0.1 us)
+    // cannot hide a load's latency (~1 us) with ONE stage in flight, so NBUF - 1 stages are kept in flight and a
+    // stage's loads are all issued right behind the barrier that frees its buffer.
+#pragma unroll
+    for (int i = 0; i < NBUF - 1; ++i)
+      if (i < ntile_k) issue(i);
+  }
   for (int t = 0; t < ntile_k; ++t) {
     if (NBUF == 1) {
       __syncthreads();
       issue(0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (NBUF > 2) {
+      // loads return in order: stage t has landed once at most the loads of the `ahead` later stages are outstanding
+      static_assert(NBUF <= 4 && 2 * PIECES <= 63, "ring: the vmcnt immediates below cover NBUF <= 4");
+      const int ahead = min(NBUF - 2, ntile_k - 1 - t);   // wave-uniform
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // A bare barrier: __syncthreads() carries a workgroup-scope fence, for which the compiler waits on EVERY
+      // outstanding load (s_waitcnt vmcnt(0)) — the ring's later stages included.  What the barrier must order here
+      // is covered without it: each wavefront has waited for its own stage-t loads (above) before it arrives, and
+      // its LDS reads of iteration t - 1 were consumed by that iteration's MFMAs.
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    // (buffer (t - 1) % NBUF was read during iteration t - 1: every wavefront is past those reads at this barrier)
+    if (NBUF > 2 && t + NBUF - 1 < ntile_k) issue((t + NBUF - 1) % NBUF);
     const bool more = NBUF == 2 && t + 1 < ntile_k;   // wave-uniform
     const int bnext = (t + 1) & 1;
-    const char* St = lds + (NBUF == 2 ? (t & 1) : 0) * STAGE;
+    const char* St = lds + (NBUF == 2 ? (t & 1) : (NBUF > 2 ? t % NBUF : 0)) * STAGE;
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
       const int c = 2 * st + half;
@@ -1163,6 +1188,11 @@ inline int x3_nbuf1_stages(int role) {
   return role == FWD ? fwd : dgrad;
 }
 
+inline bool x3_ring_enabled() {
+  static const bool on = [] { const char* e = getenv("JTSM_X3_RING"); return !e || atoi(e) != 0; }();
+  return on;
+}
+
 // Launch one tile configuration, with its split-K plan.
 template <int ROLE, int WM, int WN, int TM, int TN, int NP>
 int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, int round_blocks,
@@ -1193,6 +1223,12 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
     // layers run faster double-buffered — 128 -> 512 channels at 128 x 128: 56 us against 65 us — sweeps:
     // JTSM_X3_NBUF1_STAGES_FWD / _DGRAD.)
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 1, NP>), grid, dim3(NT), 0, st, p, q);
+  else if (BM == 64 && BN == 64 && x3_ring_enabled() && ceil_div(ktiles, splits > 1 ? splits : 1) >= 4)
+    // 64 x 64 tiles exist for the long-K 1x1 layers of res4 / res5 (16-64 stages per workgroup): a four-stage ring
+    // (64 KiB of LDS, still two workgroups per CU) keeps three stages of loads in flight.  JTSM_X3_RING=0: the
+    // double-buffered instantiation (sweeps).
+    hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, (BM == 64 && BN == 64) ? 4 : 2, NP>), grid, dim3(NT), 0, st,
+                       p, q);
   else
     hipLaunchKernelGGL((igemm_x3_kernel<ROLE, WM, WN, TM, TN, 2, NP>), grid, dim3(NT), 0, st, p, q);
   JTSM_CHECK_LAUNCH("igemm bf16x3");
@@ -1218,15 +1254,22 @@ inline int x3_tile_choice(const Params& p) {
   // them; four times as many small tiles fill it with 1-2 slices.
   static const bool tile64 = [] { const char* e = getenv("JTSM_X3_TILE64"); return !e || atoi(e) != 0; }();
   const long t128 = (long)ceil_div(p.N, 128) * ceil_div(p.M, 128);
-  if (tile64 && t128 <= 128 && ktiles >= 8 && p.N >= 64 && p.M >= 64) return 3;
+  static const long tile64_max = [] { const char* e = getenv("JTSM_X3_TILE64_MAX_T128"); return e ? atol(e) : 128L; }();   // (sweeps)
+  if (tile64 && t128 <= tile64_max && ktiles >= 8 && p.N >= 64 && p.M >= 64) return 3;
   return 0;
+}
+
+// Work-list length the 64 x 64 tiles' K slicing aims at (two workgroups per CU are resident: 512 per round).
+inline int x3_tile64_target() {
+  static const int v = [] { const char* e = getenv("JTSM_X3_TILE64_TARGET"); return e ? atoi(e) : 1024; }();   // (sweeps)
+  return v;
 }
 
 // K slices the launcher will want for this problem (before the workspace clamp).
 inline int x3_wanted_splits(const Params& p) {
   const int c = x3_tile_choice(p);
   const int bm = c == 0 ? 128 : (c == 3 ? 64 : 256), bn = c == 0 ? 128 : (c == 1 || c == 3 ? 64 : 256);
-  return plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ceil_div(p.K, XBK), c == 2 ? 256 : (c == 3 ? 1024 : 512));
+  return plan_splits(ceil_div(p.N, bn) * ceil_div(p.M, bm), ceil_div(p.K, XBK), c == 2 ? 256 : (c == 3 ? x3_tile64_target() : 512));
 }
 
 // The halo kernel serves k x k (k > 1), stride-1, undilated layers whose contracted channels come in blocks of 32
@@ -1293,7 +1336,7 @@ int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t worksp
   switch (x3_tile_choice(p)) {
     case 1: return launch_x3_cfg<ROLE, 4, 1, 2, 2, NP>(p, q, workspace, workspace_bytes, 512, st);
     case 2: return launch_x3_cfg<ROLE, 4, 2, 2, 4, NP>(p, q, workspace, workspace_bytes, 256, st);
-    case 3: return launch_x3_cfg<ROLE, 2, 2, 1, 1, NP>(p, q, workspace, workspace_bytes, 1024, st);
+    case 3: return launch_x3_cfg<ROLE, 2, 2, 1, 1, NP>(p, q, workspace, workspace_bytes, x3_tile64_target(), st);
     default: return launch_x3_cfg<ROLE, 2, 2, 2, 2, NP>(p, q, workspace, workspace_bytes, 512, st);
   }
 }

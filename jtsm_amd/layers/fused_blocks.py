@@ -22,6 +22,7 @@ CL = torch.channels_last
 # frozen-gates parity test, whose forward hooks need every convolution's output
 ENABLED = True
 MASK_TOWER = os.environ.get("JTSM_MASK_TOWER", "1") != "0"   # (A/B switch for the mask-head node alone)
+PREGATE = os.environ.get("JTSM_BLOCK_PREGATE", "1") != "0"   # (A/B switch: block-output gates in the next block's epilogue)
 
 
 def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=None, emit_planes=False):
@@ -31,6 +32,29 @@ def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=No
                                       relu_mask=relu_mask, emit_planes=emit_planes)
     w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
     return K.conv2d_backward_data(g, w_eff, x_shape, stride, pad, dil, accumulate=accumulate, relu_mask=relu_mask)
+
+
+# The last data gradient an identity block handed back ALREADY gated by its input's ReLU: (tensor, version).  Inside a
+# stage block k's input is block k-1's ReLU output, so the gate of block k-1's output gradient can ride in block k's
+# conv1 data-gradient epilogue (accumulate the shortcut path, gate, emit planes) instead of a separate
+# relu_backward pass over the stage's widest activation.  The gate is idempotent and linear, so handing a gated
+# term to a consumer that gates again is always correct; SKIPPING the second gate is correct only if the gradient
+# block k-1 receives is exactly that tensor.  Holding the tensor here keeps autograd from accumulating another
+# consumer's term into it in place (it adds into a fresh tensor instead, which then fails the identity check below
+# and is gated the ordinary way).
+_PREGATED = [None]
+
+
+def _hand_pregated(dx):
+    _PREGATED[0] = (dx, dx._version)
+
+
+def _take_pregated(dy):
+    m = _PREGATED[0]
+    if m is None:
+        return False
+    _PREGATED[0] = None
+    return m[0].data_ptr() == dy.data_ptr() and m[0].shape == dy.shape and m[1] == dy._version
 
 
 def _same_strides(dw, w):
@@ -45,8 +69,12 @@ class _BottleneckFn(Function):
     data-gradient epilogues.  The block input and output stay fp32 (the residual stream keeps full precision)."""
 
     @staticmethod
-    def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, ws, ss, bs, stride1, stride2, pad2, dil2, stride_s):
+    def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, ws, ss, bs, stride1, stride2, pad2, dil2, stride_s,
+                pregate=False):
         ctx.cfg = (stride1, stride2, pad2, dil2, stride_s)
+        # x is the ReLU output of the previous block's node (bottleneck_fused tags it): its gate goes into this
+        # block's conv1 data-gradient epilogue
+        ctx.pregate = bool(pregate) and ws is None
         ctx.planes = K.MATH != "f32" and _plane_block_ok(x, w1, w2, w3, ws)
         if ctx.planes:
             xp = K.PlaneTensor.of(x)
@@ -75,7 +103,8 @@ class _BottleneckFn(Function):
         need = ctx.needs_input_grad
         x3 = K.MATH != "f32"
         dx = dw1 = dw2 = dw3 = dws = None
-        g3 = relu_backward(dy, y3, emit_planes=x3)                       # the block's own output gate
+        # the block's own output gate (already applied by the next block's conv1 data gradient inside a stage)
+        g3 = dy if _take_pregated(dy) else relu_backward(dy, y3, emit_planes=x3)
         if need[7]:
             dw3 = K.conv2d_backward_weight(g3, y2, tuple(w3.shape), 1, 0, 1, row_scale=s3, w=w3)
         # gradient at conv2's output, gated by its ReLU in the epilogue
@@ -91,7 +120,11 @@ class _BottleneckFn(Function):
             xs = tuple(x.shape)
             if ws is None:
                 # identity shortcut: the block input receives g3 directly, added in conv1's data-gradient epilogue
-                dx = _dgrad(d1, w1, s1, xs, stride1, 0, 1, accumulate=g3)
+                if ctx.pregate:
+                    dx = _dgrad(d1, w1, s1, xs, stride1, 0, 1, accumulate=g3, relu_mask=x, emit_planes=x3)
+                    _hand_pregated(dx)
+                else:
+                    dx = _dgrad(d1, w1, s1, xs, stride1, 0, 1, accumulate=g3)
             elif stride1 == 1 and stride_s == 1:
                 dxs = _dgrad(g3, ws, ss, xs, stride_s, 0, 1)
                 dx = _dgrad(d1, w1, s1, xs, stride1, 0, 1, accumulate=dxs)
@@ -100,7 +133,8 @@ class _BottleneckFn(Function):
                 dx = _dgrad(d1, w1, s1, xs, stride1, 0, 1)
                 dx = dx.add_(_dgrad(g3, ws, ss, xs, stride_s, 0, 1))
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
-                None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None)
+                None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None,
+                None)
 
     @staticmethod
     def _backward_planes(ctx, dy):
@@ -109,7 +143,8 @@ class _BottleneckFn(Function):
         stride1, stride2, pad2, dil2, stride_s = ctx.cfg
         need = ctx.needs_input_grad
         dx = dw1 = dw2 = dw3 = dws = None
-        g3 = relu_backward(dy, y3, emit_planes=True)                      # the block's own output gate (fp32 + planes)
+        # the block's own output gate (fp32 + planes) — inside a stage the next block's conv1 data gradient applied it
+        g3 = dy if _take_pregated(dy) else relu_backward(dy, y3, emit_planes=True)
         g3p = K.PlaneTensor.of(g3, grad=True)
         if need[7]:
             dw3 = K.planes_backward_weight(g3p, y2, w3, 1, 0, 1, row_scale=s3)
@@ -124,7 +159,13 @@ class _BottleneckFn(Function):
         if need[0]:
             xs = tuple(x.shape)
             if ws is None:
-                dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=g3, kscale=s1)
+                if ctx.pregate:
+                    dx, dxp = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, both=True, accumulate=g3, kscale=s1,
+                                                     gate=xp)
+                    K.planes_put(dx, dxp.buf)
+                    _hand_pregated(dx)
+                else:
+                    dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=g3, kscale=s1)
             elif stride1 == 1 and stride_s == 1:
                 dxs = K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss)
                 dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=dxs, kscale=s1)
@@ -132,7 +173,8 @@ class _BottleneckFn(Function):
                 dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, kscale=s1)
                 dx = dx.add_(K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss))
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
-                None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None)
+                None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None,
+                None)
 
 
 def _plane_block_ok(x, w1, w2, w3, ws):
@@ -148,8 +190,11 @@ def _plane_block_ok(x, w1, w2, w3, ws):
 
 def bottleneck_fused(x, w1, sb1, w2, sb2, w3, sb3, ws, sbs, stride1, stride2, pad2, dil2, stride_s):
     ss, bs = sbs if sbs is not None else (None, None)
-    return _BottleneckFn.apply(x, w1, sb1[0], sb1[1], w2, sb2[0], sb2[1], w3, sb3[0], sb3[1], ws, ss, bs,
-                               stride1, stride2, pad2, dil2, stride_s)
+    pregate = PREGATE and ws is None and getattr(x, "_jtsm_block_relu_out", False)
+    y = _BottleneckFn.apply(x, w1, sb1[0], sb1[1], w2, sb2[0], sb2[1], w3, sb3[0], sb3[1], ws, ss, bs,
+                            stride1, stride2, pad2, dil2, stride_s, pregate)
+    y._jtsm_block_relu_out = True    # (a tag on this Python object: any op in between yields an untagged tensor)
+    return y
 
 
 class _MaskTowerFn(Function):

@@ -96,6 +96,36 @@ def test_conv_planning_host_logic_handles_empty_and_odd_shapes():
     assert b"in_c" in lib.jtsm_last_error()
 
 
+def test_bf16x3_plan_reports_the_ring_for_long_k_64_tiles():
+    """jtsm_conv_bf16x3_plan (host code): the res4 / res5 1x1 layers that run on 64 x 64 tiles take the four-stage
+    ring (NBUF = 4) from four stages per K slice; the GPU conv cases `ring_*` in tests/test_hip_conv.py are such
+    shapes; large layers stay double-buffered on 256 x 256 tiles."""
+    import ctypes as C
+    from jtsm_amd import _lib
+    from jtsm_amd.layers.conv import ConvShape
+
+    lib = _lib.lib()
+
+    def plan(shape, role):
+        v = [C.c_int() for _ in range(6)]
+        assert lib.jtsm_conv_bf16x3_plan(C.byref(ConvShape(*shape)), role, *[C.byref(x) for x in v]) == 0
+        return tuple(x.value for x in v)   # wm, wn, tm, tn, nbuf, splits
+
+    # BASELINE layers: res4 conv1 (1024 -> 256 on 2 x 64 x 64), res5 conv1 (2048 -> 512 on 2 x 32 x 32), forward
+    assert plan((2, 64, 64, 1024, 256, 1, 1, 1, 0, 1), 0) == (2, 2, 1, 1, 4, 1)
+    assert plan((2, 32, 32, 2048, 512, 1, 1, 1, 0, 1), 0) == (2, 2, 1, 1, 4, 4)
+    # data gradient of res4 conv3 (256 -> 1024): contracted over the 1024 output channels
+    assert plan((2, 64, 64, 256, 1024, 1, 1, 1, 0, 1), 1) == (2, 2, 1, 1, 4, 1)
+    # the GPU suite's ring cases
+    assert plan((2, 16, 16, 1024, 256, 1, 1, 1, 0, 1), 0) == (2, 2, 1, 1, 4, 8)
+    assert plan((1, 20, 20, 352, 128, 1, 1, 1, 0, 1), 0) == (2, 2, 1, 1, 4, 2)
+    assert plan((1, 12, 12, 64, 128, 3, 3, 1, 1, 1), 0) == (2, 2, 1, 1, 4, 4)
+    # FPN p2 output conv: the halo kernel (reported as NBUF = 0); a res2-sized 1x1 (8 stages, 2048 tiles): 128 x 128
+    # tiles, double-buffered
+    assert plan((2, 256, 256, 256, 256, 3, 3, 1, 1, 1), 0)[4] == 0
+    assert plan((2, 256, 256, 256, 256, 1, 1, 1, 0, 1), 0)[:5] == (2, 2, 2, 2, 2)
+
+
 def test_integration_doc_maps_every_declared_symbol():
     """INTEGRATION.md's symbol <-> reference-interface table names every entry point include/jtsm_hip.h declares
     (brace lists and trailing-* families expanded)."""

@@ -65,6 +65,11 @@ CASES = [
     ("ntail80",        3, 256, 14, 14, 80, 1, 1, 0, 1),
     ("ntail54",        1, 128, 32, 32, 54, 1, 1, 0, 1),
     ("small_k",        1, 8, 9, 9, 12, 3, 1, 1, 1),
+    # 64 x 64 tiles with the four-stage ring (csrc/conv_x3.h, NBUF = 4): whole rings, slices of 6 + 5 stages with a row
+    # tail, and a 3x3 layer on a small map (tap-permuted K order; slices of 5, 5, 5 and 3 stages — shorter than the ring)
+    ("ring_1x1",       2, 1024, 16, 16, 256, 1, 1, 0, 1),
+    ("ring_tail",      1, 352, 20, 20, 128, 1, 1, 0, 1),
+    ("ring_3x3",       1, 64, 12, 12, 128, 3, 1, 1, 1),
 ]
 
 
@@ -641,3 +646,59 @@ def test_paired_weight_planes_are_the_separate_planes_rearranged(cuda, conv_math
             ph, pl = unpair(tb2, i, kh * kh * o)
             assert torch.equal(ph.reshape(-1), th2) and torch.equal(pl.reshape(-1), tl2)
         assert not torch.equal(hi2, hi)
+
+
+@pytest.mark.parametrize("tap", [False, True], ids=["chain", "tapped"])
+def test_block_output_gate_rides_in_the_next_blocks_epilogue(cuda, monkeypatch, tap):
+    """Inside a stage the ReLU gate of block k-1's output gradient is applied by block k's conv1 data-gradient epilogue
+    (layers/fused_blocks.py: _PREGATED): same bits as the separate relu_backward pass, two passes fewer over a chain of
+    three blocks.  `tapped`: the middle activation has a second consumer, so the gradient block 0 receives is a SUM —
+    it must fail the identity check and be gated the ordinary way (gating twice is harmless, skipping it is not)."""
+    from jtsm_amd.layers import fused_blocks as FB
+    from jtsm_amd.modeling.backbone.resnet import BottleneckBlock
+    torch.manual_seed(5)
+    blocks = [BottleneckBlock(64, 64, bottleneck_channels=32, norm="FrozenBN").to(cuda) for _ in range(3)]
+    for b in blocks:   # FrozenBN away from the identity, so that pre-activations take both signs
+        for c in (b.conv1, b.conv2, b.conv3):
+            c.norm.bias.copy_(torch.randn_like(c.norm.bias) * 0.3)
+            c.norm.weight.copy_(torch.rand_like(c.norm.weight) + 0.5)
+    x0 = torch.randn(2, 64, 24, 20, device=cuda).contiguous(memory_format=CL)
+    wgt = torch.randn(2, 64, 24, 20, device=cuda).contiguous(memory_format=CL)
+    wgt2 = torch.randn(2, 64, 24, 20, device=cuda).contiguous(memory_format=CL)
+    real_relu_backward = FB.relu_backward
+
+    def run(pregate):
+        monkeypatch.setattr(FB, "PREGATE", pregate)
+        K.planes_clear()
+        for b in blocks:
+            b.zero_grad(set_to_none=True)
+        calls = []
+
+        def counted(*a, **k):
+            calls.append(1)
+            return real_relu_backward(*a, **k)
+
+        monkeypatch.setattr(FB, "relu_backward", counted)
+        x = x0.clone().requires_grad_()
+        y1 = blocks[0](x)
+        y2 = blocks[1](y1)
+        y3 = blocks[2](y2)
+        loss = (y3 * wgt).sum()
+        if tap:
+            loss = loss + (y1 * wgt2).sum()
+        loss.backward()
+        monkeypatch.setattr(FB, "relu_backward", real_relu_backward)
+        assert FB._PREGATED[0] is None or not pregate or tap      # every handed tensor was taken
+        grads = [x.grad.clone()] + [p.grad.clone() for b in blocks for p in b.parameters() if p.grad is not None]
+        return grads, len(calls)
+
+    ref, n_ref = run(False)
+    got, n_got = run(True)
+    assert n_ref == 3 and n_got == (2 if tap else 1), (n_ref, n_got)
+    assert len(ref) == len(got) == 1 + 9
+    assert torch.equal(got[0], ref[0]), float((got[0] - ref[0]).abs().max())     # the chain's data gradient: same bits
+    for a, b in zip(got[1:], ref[1:]):
+        if K.MATH == "f32":   # the exact-fp32 weight gradient folds its K slices with atomics: not reproducible to the bit
+            assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+        else:
+            assert torch.equal(a, b), float((a - b).abs().max())
