@@ -9,17 +9,17 @@ from jtsm_amd.layers import conv, elementwise
 from jtsm_amd.utils.synthetic import synthetic_inputs
 dev = torch.device('cuda:0')
 model = bench.build(dev)
-inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev)
+inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev, cluster=1.0, objects=40)
 opt = bench.make_optimizer(model)
 def step():
     l = model(inputs); sum(l.values()).backward(); opt.step(); opt.zero_grad(set_to_none=True)
 for _ in range(2): step()
 log = collections.Counter()
 orig = conv._split
-def spy(t):
+def spy(t, *a):
     fr = [f for f in traceback.extract_stack()[:-1] if 'jtsm_amd' in f.filename][-3:]
     log[(tuple(t.shape), " < ".join("%s:%d" % (os.path.basename(f.filename), f.lineno) for f in reversed(fr)))] += 1
-    return orig(t)
+    return orig(t, *a)
 conv._split = spy
 orig_r = elementwise.relu_backward
 rlog = collections.Counter()
@@ -30,6 +30,8 @@ def spy_r(dy, y, emit_planes=False):
 elementwise.relu_backward = spy_r
 import jtsm_amd.layers.conv as C2
 if hasattr(C2, 'relu_backward'): C2.relu_backward = spy_r
+import jtsm_amd.layers.fused_blocks as FB
+FB.relu_backward = spy_r
 step(); torch.cuda.synchronize()
 print("---- standalone splits")
 for (shape, where), n in sorted(log.items(), key=lambda kv: -torch.Size(kv[0][0]).numel() * kv[1]):
