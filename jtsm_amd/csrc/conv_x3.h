@@ -1254,14 +1254,19 @@ inline int x3_tile_choice(const Params& p) {
   // them; four times as many small tiles fill it with 1-2 slices.
   static const bool tile64 = [] { const char* e = getenv("JTSM_X3_TILE64"); return !e || atoi(e) != 0; }();
   const long t128 = (long)ceil_div(p.N, 128) * ceil_div(p.M, 128);
-  static const long tile64_max = [] { const char* e = getenv("JTSM_X3_TILE64_MAX_T128"); return e ? atol(e) : 128L; }();   // (sweeps)
+  // (with the four-stage ring the 64-tiles take layers of up to 256 128-tiles — res5 conv3 / shortcut, 512 -> 2048 on 32 x 32:
+  // 1024 small tiles unsplit instead of 256 x 2 slices + a finishing launch.  Same-box sweep, ms per step: 128: 25.14,
+  // 256: 24.99, 512: 25.17; together with the 512 work-list target below: 24.88.)
+  static const long tile64_max = [] { const char* e = getenv("JTSM_X3_TILE64_MAX_T128"); return e ? atol(e) : 256L; }();   // (sweeps)
   if (tile64 && t128 <= tile64_max && ktiles >= 8 && p.N >= 64 && p.M >= 64) return 3;
   return 0;
 }
 
 // Work-list length the 64 x 64 tiles' K slicing aims at (two workgroups per CU are resident: 512 per round).
 inline int x3_tile64_target() {
-  static const int v = [] { const char* e = getenv("JTSM_X3_TILE64_TARGET"); return e ? atoi(e) : 1024; }();   // (sweeps)
+  // (1024 — two rounds — up to the ring: long K sweeps were latency bound then and more, shorter slices paid; with three
+  // stages in flight one round of longer slices wins: half the slabs and finishing work.  Sweep: 25.14 -> 24.97 ms per step.)
+  static const int v = [] { const char* e = getenv("JTSM_X3_TILE64_TARGET"); return e ? atoi(e) : 512; }();   // (sweeps)
   return v;
 }
 

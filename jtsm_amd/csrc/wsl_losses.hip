@@ -450,6 +450,32 @@ __global__ __launch_bounds__(256) void mask_bce_bwd(const float* __restrict__ z,
   }
 }
 
+// The same result written 16 bytes per lane: blockIdx.y = roi (its class channel is block-uniform), a thread owns one
+// float4 piece of one pixel's row of `ld` logits.  The thread-per-pixel form above walks a 4 * ld-byte row per thread —
+// stores 320 bytes apart across a wavefront: 57 us for 74 MB on the 294-roi mask heads (1.3 TB/s).
+__global__ __launch_bounds__(256) void mask_bce_bwd_wide(const float* __restrict__ z, int ld, const long* __restrict__ cls,
+                                                         const unsigned char* __restrict__ target, long npix,
+                                                         int pix_per_roi, const float* __restrict__ upstream,
+                                                         float* __restrict__ dz) {
+  const float k = (upstream ? *upstream : 1.f) / (float)npix;
+  const int n = blockIdx.y;
+  const int c = cls ? (int)cls[n] : 0;
+  const unsigned q = (unsigned)ld >> 2, pieces = (unsigned)pix_per_roi * q;
+  const long base = (long)n * pix_per_roi;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < pieces; idx += gridDim.x * 256u) {
+    const unsigned px = idx / q, j = (idx - px * q) * 4u;
+    const long i = base + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)c - j < 4u) {
+      const float x = z[i * ld + c];
+      const float g = (1.f / (1.f + expf(-x)) - (target[i] ? 1.f : 0.f)) * k;
+      const unsigned e = (unsigned)c - j;
+      v.x = e == 0u ? g : 0.f; v.y = e == 1u ? g : 0.f; v.z = e == 2u ? g : 0.f; v.w = e == 3u ? g : 0.f;
+    }
+    *reinterpret_cast<float4*>(dz + i * ld + j) = v;
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -569,6 +595,14 @@ int jtsm_mask_bce_backward_f32(const float* logits, int ld, int num_classes, con
   if (N == 0) return JTSM_OK;
   JTSM_REQUIRE(logits && target && dlogits && (gt_classes || num_classes == 1), "mask_bce backward: null pointer");
   const long npix = (long)N * side * side;
+  const long pieces = (long)side * side * (ld / 4);
+  if (ld % 4 == 0 && (reinterpret_cast<uintptr_t>(dlogits) & 15) == 0 && N <= 65535 && pieces < (1L << 30)) {
+    const int bx = (int)((pieces + 255) / 256 < 64 ? (pieces + 255) / 256 : 64);
+    hipLaunchKernelGGL(mask_bce_bwd_wide, dim3(bx, N), dim3(256), 0, as_stream(stream), logits, ld,
+                       (const long*)gt_classes, target, npix, side * side, upstream, dlogits);
+    JTSM_CHECK_LAUNCH("mask_bce backward");
+    return JTSM_OK;
+  }
   const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
   hipLaunchKernelGGL(mask_bce_bwd, dim3(blocks), dim3(256), 0, as_stream(stream), logits, ld, (const long*)gt_classes,
                      target, npix, side * side, upstream, dlogits);
