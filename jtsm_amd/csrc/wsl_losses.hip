@@ -117,6 +117,38 @@ __device__ __forceinline__ void fold_colstats(const float2* __restrict__ part, i
   }
 }
 
+// The same fold, once per bag (thread = class), its result read by every workgroup of passes 2 and 3.  Those used to
+// fold the bag's slab partials themselves: 125 dependent steps for a 2000-row bag, each behind its own load — ~100 us
+// in front of 15 us of work, in every workgroup of both passes.  Here the loads of 16 slabs are requested together and
+// the recurrence (same expression, same slab order) runs from registers; folding the ONE folded entry through
+// fold_colstats reproduces it exactly (max(-FLT_MAX, m) = m; 0 * e + z * exp(0) = z).
+__global__ __launch_bounds__(64 * SLOTS) void mil_fold(const float2* __restrict__ part, int slabs_per_bag, int nc,
+                                                       float2* __restrict__ folded) {
+  const int c = threadIdx.x, bag = blockIdx.x;
+  if (c >= nc) return;
+  const float2* p = part + (size_t)bag * slabs_per_bag * nc + c;
+  float M = -FLT_MAX, Z = 0.f;
+  int s = 0;
+  for (; s + 16 <= slabs_per_bag; s += 16) {
+    float2 q[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = p[(size_t)(s + u) * nc];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const float mn = fmaxf(M, q[u].x);
+      Z = Z * __expf(M - mn) + q[u].y * __expf(q[u].x - mn);
+      M = mn;
+    }
+  }
+  for (; s < slabs_per_bag; ++s) {
+    const float2 q = p[(size_t)s * nc];
+    const float mn = fmaxf(M, q.x);
+    Z = Z * __expf(M - mn) + q.y * __expf(q.x - mn);
+    M = mn;
+  }
+  folded[(size_t)bag * nc + c] = make_float2(M, Z);
+}
+
 // Row softmax of C and bag-softmax of D for one row; returns a[], b[] per slot.
 __device__ __forceinline__ void mil_row(const float* __restrict__ Crow, const float* __restrict__ Drow,
                                         int nc, int lane, const float (&M)[SLOTS],
@@ -156,7 +188,7 @@ __global__ __launch_bounds__(256) void mil_scores(const float* __restrict__ C, c
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const SlabRange s = slab_of(bag_off, slabs_per_bag, rows_per_slab);
   float M[SLOTS], Z[SLOTS], acc[SLOTS];
-  fold_colstats(part, s.bag, slabs_per_bag, nc, lane, M, Z);
+  fold_colstats(part, s.bag, 1, nc, lane, M, Z);   // part: the per-bag result of mil_fold
 #pragma unroll
   for (int k = 0; k < SLOTS; ++k) acc[k] = 0.f;
   for (int r = s.r0 + wv; r < s.r1; r += WAVES) {
@@ -232,7 +264,7 @@ __global__ __launch_bounds__(256) void mil_backward(const float* __restrict__ C,
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const SlabRange s = slab_of(bag_off, slabs_per_bag, rows_per_slab);
   float M[SLOTS], Z[SLOTS], g[SLOTS], ps[SLOTS];
-  fold_colstats(part, s.bag, slabs_per_bag, nc, lane, M, Z);
+  fold_colstats(part, s.bag, 1, nc, lane, M, Z);   // part: the per-bag result of mil_fold
   const float up = upstream ? *upstream : 1.f;
 #pragma unroll
   for (int k = 0; k < SLOTS; ++k) {
@@ -385,7 +417,7 @@ inline void mil_plan(int max_bag_rows, int nbags, int* slabs_per_bag, int* rows_
   if (*slabs_per_bag < 1) *slabs_per_bag = 1;
 }
 
-struct MilWs { float2* part; float* psum_part; float* psum; float* gp; };
+struct MilWs { float2* part; float* psum_part; float* psum; float* gp; float2* folded; };
 inline size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
 inline MilWs mil_carve(void* ws, int nbags, int spb, int nc) {
   char* p = (char*)ws;
@@ -393,7 +425,8 @@ inline MilWs mil_carve(void* ws, int nbags, int spb, int nc) {
   k.part = (float2*)p; p += align16((size_t)nbags * spb * nc * sizeof(float2));
   k.psum_part = (float*)p; p += align16((size_t)nbags * spb * nc * sizeof(float));
   k.psum = (float*)p; p += align16((size_t)nbags * nc * sizeof(float));
-  k.gp = (float*)p;
+  k.gp = (float*)p; p += align16((size_t)nbags * nc * sizeof(float));
+  k.folded = (float2*)p;
   return k;
 }
 
@@ -488,7 +521,7 @@ size_t jtsm_mil_workspace_bytes(int nbags, int max_bag_rows, int nc) {
   int spb, rps;
   mil_plan(max_bag_rows, nbags, &spb, &rps);
   return align16((size_t)nbags * spb * nc * sizeof(float2)) + align16((size_t)nbags * spb * nc * sizeof(float)) +
-         2 * align16((size_t)nbags * nc * sizeof(float)) + 16;
+         2 * align16((size_t)nbags * nc * sizeof(float)) + align16((size_t)nbags * nc * sizeof(float2)) + 16;
 }
 
 int jtsm_mil_forward_f32(const float* cls_logits, const float* det_logits, int ld, int nc,
@@ -505,8 +538,9 @@ int jtsm_mil_forward_f32(const float* cls_logits, const float* det_logits, int l
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(mil_colstats, dim3(nbags * spb), dim3(256), 0, st, det_logits, ld, nc, bag_offsets, spb,
                      rps, k.part);
+  hipLaunchKernelGGL(mil_fold, dim3(nbags), dim3(64 * SLOTS), 0, st, k.part, spb, nc, k.folded);
   hipLaunchKernelGGL(mil_scores, dim3(nbags * spb), dim3(256), 0, st, cls_logits, det_logits, ld, nc,
-                     bag_offsets, spb, rps, k.part, scores, k.psum_part);
+                     bag_offsets, spb, rps, k.folded, scores, k.psum_part);
   hipLaunchKernelGGL(mil_finish, dim3(1), dim3(256), 0, st, k.psum_part, nbags, spb, nc, labels, mean_loss,
                      k.psum, img_probs, k.gp, loss);
   JTSM_CHECK_LAUNCH("mil forward");
@@ -522,7 +556,7 @@ int jtsm_mil_backward_f32(const float* cls_logits, const float* det_logits, int 
   mil_plan(max_bag_rows, nbags, &spb, &rps);
   const MilWs k = mil_carve(const_cast<void*>(workspace), nbags, spb, nc);
   hipLaunchKernelGGL(mil_backward, dim3(nbags * spb), dim3(256), 0, as_stream(stream), cls_logits, det_logits,
-                     ld, nc, bag_offsets, spb, rps, k.part, k.psum, k.gp, upstream, d_cls, d_det, ld_grad);
+                     ld, nc, bag_offsets, spb, rps, k.folded, k.psum, k.gp, upstream, d_cls, d_det, ld_grad);
   JTSM_CHECK_LAUNCH("mil backward");
   return JTSM_OK;
 }
