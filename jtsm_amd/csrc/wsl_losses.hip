@@ -230,8 +230,18 @@ __global__ __launch_bounds__(256) void mil_finish(const float* __restrict__ psum
   const float norm = mean_loss ? 1.f / ((float)nbags * nc) : 1.f / (float)nbags;
   for (int idx = threadIdx.x; idx < nbags * nc; idx += 256) {
     const int bag = idx / nc, c = idx - bag * nc;
+    // the slab partials in slab order, 16 loads in flight (one load per dependent add took 44 us for 125 slabs)
+    const float* pp = psum_part + (size_t)bag * slabs_per_bag * nc + c;
     float sum = 0.f;
-    for (int s = 0; s < slabs_per_bag; ++s) sum += psum_part[((size_t)bag * slabs_per_bag + s) * nc + c];
+    int s = 0;
+    for (; s + 16 <= slabs_per_bag; s += 16) {
+      float q[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) q[u] = pp[(size_t)(s + u) * nc];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sum += q[u];
+    }
+    for (; s < slabs_per_bag; ++s) sum += pp[(size_t)s * nc];
     const float p = fminf(fmaxf(sum, kTiny), 1.f - kTiny);
     const float y = labels[idx];
     // F.binary_cross_entropy clamps each log term at -100
@@ -351,7 +361,15 @@ __global__ __launch_bounds__(256) void oicr_forward(const float* __restrict__ Zl
 __global__ void oicr_finish(const float* __restrict__ partials, int nblocks, int R, float* __restrict__ out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float ce = 0.f, nv = 0.f, l1 = 0.f;
-    for (int b = 0; b < nblocks; ++b) { ce += partials[3 * b]; nv += partials[3 * b + 1]; l1 += partials[3 * b + 2]; }
+    int b = 0;
+    for (; b + 16 <= nblocks; b += 16) {   // block order kept; 48 loads in flight instead of one per add
+      float q[48];
+#pragma unroll
+      for (int i = 0; i < 48; ++i) q[i] = partials[3 * b + i];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { ce += q[3 * u]; nv += q[3 * u + 1]; l1 += q[3 * u + 2]; }
+    }
+    for (; b < nblocks; ++b) { ce += partials[3 * b]; nv += partials[3 * b + 1]; l1 += partials[3 * b + 2]; }
     out[0] = ce / nv;   // V == 0 gives 0/0 like the reference (no guard)
     out[1] = l1 / (float)R;
     out[2] = nv;
