@@ -686,6 +686,15 @@ size_t jtsm_paint_sem_seg_workspace_bytes(int B);
 int jtsm_paint_sem_seg(const float* boxes, const int32_t* classes, const float* scores, const int32_t* counts,
                        int B, int G, int class_base, int H, int W, float erode, int64_t* out, void* workspace,
                        void* stream);
+/* The same target painted from the reference's own masks (roi_heads_jtsm.py:2038-2069: get_pgt_top_k(need_mask=True)
+ * -> :1333-1334 object_evidence -> :1928-1994, superpixel branch): target j of image b is proposal row
+ * bag_offsets[b] + target_idx[b,j] of oh_labels (R, L) int32, and its mask is the union of the superpixels that row
+ * marks: mask_j(y,x) = oh_labels[row_j][superpixels[b,y,x]] != 0 (ids outside [0, L) belong to no mask).  Paint order,
+ * values and the second pass for classes left without a pixel as above.  superpixels (B,H,W) int32 at the OUTPUT size. */
+int jtsm_paint_sem_seg_evidence(const int32_t* target_idx, const int32_t* bag_offsets, const int32_t* oh_labels, int L,
+                                const int32_t* superpixels, const int32_t* classes, const float* scores,
+                                const int32_t* counts, int B, int G, int class_base, int H, int W, int64_t* out,
+                                void* workspace, void* stream);
 /* For every proposal: IoU against its image's pseudo boxes (first maximum wins), label = that box's
  * class if IoU >= iou_thresh else bg_label, plus the matched index / box / weight / (optional) score. */
 int jtsm_match_label_f32(const float* proposals, const int32_t* bag_offsets, int B, int R,

@@ -322,6 +322,78 @@ __global__ __launch_bounds__(256) void paint_missing_kernel(const float* __restr
   }
 }
 
+
+// ---- pseudo semantic target with the reference's masks (get_pgt_sem_seg :2038-2069 with need_mask=True ->
+// get_pgt_top_k :1333-1334 -> object_evidence :1928-1994, superpixel branch): target j's mask is the union of the
+// superpixels its oh_labels row marks, mask_j(y, x) = oh_labels[row_j][superpixels[y][x]] != 0 (a superpixel id outside
+// [0, L) belongs to no mask: the reference's `poses` loop covers range(L) only).  Same two passes as above; the
+// full-image masks are never rasterised.
+__global__ __launch_bounds__(256) void paint_top_evidence_kernel(
+    const int* __restrict__ target_idx, const int* __restrict__ bag_offsets, const int* __restrict__ oh_labels, int L,
+    const int* __restrict__ superpixels, const int* __restrict__ classes, const float* __restrict__ scores,
+    const int* __restrict__ counts, int G, int class_base, int H, int W, long* __restrict__ out,
+    int* __restrict__ value_counts) {
+  __shared__ int hist[kPaintValues];
+  __shared__ int srank[64], sval[64];
+  __shared__ long srow[64];
+  const int b = blockIdx.y, n = min(counts[b], 64);
+  if (threadIdx.x < kPaintValues) hist[threadIdx.x] = 0;
+  if (threadIdx.x < n) {
+    const int j = threadIdx.x;
+    const float sj = scores[b * G + j];
+    int r = 0;   // position of target j in ascending (score, index) order
+    for (int k = 0; k < n; ++k) {
+      const float sk = scores[b * G + k];
+      r += (sk < sj || (sk == sj && k < j)) ? 1 : 0;
+    }
+    srank[j] = r;
+    sval[j] = classes[b * G + j] - class_base;
+    srow[j] = ((long)bag_offsets[b] + target_idx[b * G + j]) * L;
+  }
+  __syncthreads();
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p < (long)H * W) {
+    const int s = superpixels[(size_t)b * H * W + p];
+    int best = -1, val = 0;
+    if (s >= 0 && s < L)
+      for (int j = 0; j < n; ++j)
+        if (srank[j] > best && oh_labels[srow[j] + s] != 0) { best = srank[j]; val = sval[j]; }
+    out[(size_t)b * H * W + p] = val;
+    atomicAdd(&hist[val & (kPaintValues - 1)], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < kPaintValues && hist[threadIdx.x]) atomicAdd(value_counts + b * kPaintValues + threadIdx.x, hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(1024) void paint_missing_evidence_kernel(
+    const int* __restrict__ target_idx, const int* __restrict__ bag_offsets, const int* __restrict__ oh_labels, int L,
+    const int* __restrict__ superpixels, const int* __restrict__ classes, const int* __restrict__ counts, int G,
+    int class_base, int H, int W, long* __restrict__ out, const int* __restrict__ value_counts) {
+  __shared__ int cnt[kPaintValues];
+  const int b = blockIdx.x, n = min(counts[b], 64);
+  if (threadIdx.x < kPaintValues) cnt[threadIdx.x] = value_counts[b * kPaintValues + threadIdx.x];
+  __syncthreads();
+  long* img = out + (size_t)b * H * W;
+  const int* sp = superpixels + (size_t)b * H * W;
+  for (int j = 0; j < n; ++j) {
+    const int v = (classes[b * G + j] - class_base) & (kPaintValues - 1);
+    const bool missing = cnt[v] == 0;   // uniform: read before anyone updates it in this round
+    __syncthreads();
+    if (missing) {
+      const int* row = oh_labels + ((long)bag_offsets[b] + target_idx[b * G + j]) * L;
+      for (long i = threadIdx.x; i < (long)H * W; i += 1024) {
+        const int s = sp[i];
+        if (s < 0 || s >= L || row[s] == 0) continue;
+        const long old = img[i];
+        img[i] = v;
+        atomicSub(&cnt[(int)old & (kPaintValues - 1)], 1);
+        atomicAdd(&cnt[v], 1);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -400,6 +472,28 @@ int jtsm_paint_sem_seg(const float* boxes, const int32_t* classes, const float* 
   hipLaunchKernelGGL(paint_missing_kernel, dim3(B), dim3(256), 0, st, boxes, classes, counts, G, class_base, H, W, erode,
                      reinterpret_cast<long*>(out), value_counts);
   JTSM_CHECK_LAUNCH("paint_sem_seg");
+  return JTSM_OK;
+}
+
+int jtsm_paint_sem_seg_evidence(const int32_t* target_idx, const int32_t* bag_offsets, const int32_t* oh_labels, int L,
+                                const int32_t* superpixels, const int32_t* classes, const float* scores,
+                                const int32_t* counts, int B, int G, int class_base, int H, int W, int64_t* out,
+                                void* workspace, void* stream) {
+  JTSM_REQUIRE(B >= 0 && G > 0 && G <= 64 && H > 0 && W > 0 && L > 0,
+               "paint_sem_seg_evidence: bad sizes (at most 64 targets per image)");
+  if (B == 0) return JTSM_OK;
+  JTSM_REQUIRE(target_idx && bag_offsets && oh_labels && superpixels && classes && scores && counts && out && workspace,
+               "paint_sem_seg_evidence: null pointer");
+  hipStream_t st = as_stream(stream);
+  int* value_counts = reinterpret_cast<int*>(workspace);
+  JTSM_CHECK_HIP(hipMemsetAsync(value_counts, 0, (size_t)B * kPaintValues * sizeof(int), st));
+  const long hw = (long)H * W;
+  hipLaunchKernelGGL(paint_top_evidence_kernel, dim3((unsigned)((hw + 255) / 256), B), dim3(256), 0, st, target_idx,
+                     bag_offsets, oh_labels, L, superpixels, classes, scores, counts, G, class_base, H, W,
+                     reinterpret_cast<long*>(out), value_counts);
+  hipLaunchKernelGGL(paint_missing_evidence_kernel, dim3(B), dim3(1024), 0, st, target_idx, bag_offsets, oh_labels, L,
+                     superpixels, classes, counts, G, class_base, H, W, reinterpret_cast<long*>(out), value_counts);
+  JTSM_CHECK_LAUNCH("paint_sem_seg_evidence");
   return JTSM_OK;
 }
 

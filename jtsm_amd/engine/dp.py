@@ -1,18 +1,27 @@
 """Data-parallel gradient exchange of the training step (the reference wraps its model in torch DDP,
-detectron2/engine/defaults.py:288-291; step: projects/WSL/tools/train_net.py:95-119).
+detectron2/engine/defaults.py:288-291,331-336; step: projects/WSL/tools/train_net.py:95-119).
 
 One process per GPU.  Each rank's losses are means over its own images and the ranks' gradients are AVERAGED
 (mean of means, exactly what DDP gives the reference).  This module owns the exchange instead of delegating it:
 
-  * flat fp32 gradient BUCKETS laid out in the order the backward produces them — heads, FPN, res5, res4, res3 — one
-    contiguous HBM buffer per bucket.  Every trainable parameter's `.grad` is a view into its bucket with the
-    parameter's own strides (channels_last weights included), so the fused SGD (solver/build.py) reads the averaged
-    gradients in place and nothing is copied or re-strided after the collective;
+  * at wrap time rank 0's parameters and buffers are broadcast (what DDP's constructor does), so identical weights do
+    not rest on every rank having seeded its generator the same way;
+  * flat fp32 gradient BUCKETS of at most JTSM_DP_BUCKET_MB (64) MB, one contiguous HBM buffer each.  Every trainable
+    parameter's `.grad` is a view into its bucket with the parameter's own strides (channels_last weights included),
+    so the fused SGD (solver/build.py) reads the averaged gradients in place and nothing is copied or re-strided after
+    the collective.  The first backward runs on a layout guessed from the parameter names (heads, FPN, res5, res4,
+    res3); the order in which the gradients ACTUALLY became ready in that backward — rank 0's, broadcast, so every
+    rank builds the same layout — then decides the final buckets (a big head bucket no longer waits for the last head
+    gradient: fc1's own bucket goes out while the mask heads' backward still runs);
   * the weight-gradient contraction kernels write STRAIGHT into the bucket (layers/conv.py: GRAD_SLOTS), so for the
     convolution / linear weights — 99 % of the bytes — there is no gradient copy at all; the few gradients that
-    autograd produces elsewhere (biases, concatenated predictor weights, GroupNorm terms) are copied in by the hook;
-  * a post-accumulate hook per parameter counts its bucket down; when a bucket is complete the compute stream
-    records an event and the bucket's collective starts on a side stream while the backward continues:
+    autograd produces elsewhere (biases, concatenated predictor weights, GroupNorm terms) are copied in by the hook.
+    Only the FIRST weight-gradient launch of a parameter in a backward gets the slot: a weight used several times in
+    one step (the RPN head runs on five pyramid levels) gets ordinary tensors for its later uses and autograd sums;
+  * a post-accumulate hook per parameter counts its bucket down; collectives are issued in BUCKET ORDER on every rank
+    (a bucket that completes early waits for its predecessors; the end of the backward issues whatever is left, also
+    buckets without any gradient on this rank, zero-filled) — the ranks' collective sequences can never diverge;
+  * a bucket's collective runs on a side stream behind an event of the compute stream while the backward continues:
     reduce-scatter (AVG) + all-gather in place — 2 x (N-1)/N x bytes over the xGMI links, each rank reducing 1/N of
     the bucket — or, on backends without reduce-scatter (gloo: the CPU / single-GPU rehearsal), all-reduce;
   * the end of the backward pass (autograd engine callback) makes the compute stream wait for the side stream.
@@ -20,12 +29,14 @@ One process per GPU.  Each rank's losses are means over its own images and the r
 Backend "nccl" is RCCL on ROCm.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
 
-# bucket i takes the parameters whose name starts with one of these prefixes (checked in order; first match wins):
-# the order the backward reaches them.  Anything unmatched joins the first bucket.
+# the first backward's layout: bucket group i takes the parameters whose name starts with one of these prefixes
+# (checked in order; first match wins) — roughly the order the backward reaches them.  Anything unmatched joins the
+# first group.  Groups are cut into buckets of at most the cap; the observed order replaces this guess after one step.
 BUCKET_PREFIXES = (
     ("roi_heads.", "sem_seg_head.", "proposal_generator."),
     ("backbone.fpn_",),
@@ -34,6 +45,10 @@ BUCKET_PREFIXES = (
     ("backbone.bottom_up.res3", "backbone.res3", "backbone.bottom_up.res2", "backbone.res2", "backbone.bottom_up.stem",
      "backbone.stem"),
 )
+
+
+def bucket_cap_bytes():
+    return int(float(os.environ.get("JTSM_DP_BUCKET_MB", "64")) * (1 << 20))
 
 
 def env_ranks():
@@ -54,8 +69,48 @@ def _active():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _flat_view(t):
+    """The 1-D view over a dense tensor's memory (any permutation of a contiguous layout)."""
+    return t.as_strided((t.numel(),), (1,), t.storage_offset())
+
+
+def broadcast_state(model, src=0, group=None):
+    """Rank `src`'s parameters and buffers to every rank (DDP's constructor does the same,
+    detectron2/engine/defaults.py:288-291 -> torch DistributedDataParallel._sync_module_states): one flat buffer per
+    dtype, one broadcast each."""
+    if not _active():
+        return 0
+    by_dtype = {}
+    for t in list(model.parameters()) + list(model.buffers()):
+        if t.numel():
+            by_dtype.setdefault((t.dtype, t.device), []).append(t.data)
+    total = 0
+    for (dtype, device), tensors in by_dtype.items():
+        dense = [t if _dense(t) else None for t in tensors]
+        flat = torch.cat([(_flat_view(t) if d is not None else t.reshape(-1)) for t, d in zip(tensors, dense)])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t, d in zip(tensors, dense):
+            piece = flat[off:off + t.numel()]
+            if d is not None:
+                _flat_view(t).copy_(piece)
+            else:
+                t.copy_(piece.view(t.shape))
+            off += t.numel()
+        total += flat.numel() * flat.element_size()
+    return total
+
+
 class _Bucket(object):
     __slots__ = ("flat", "params", "pending", "event", "numel")
+
+
+class GradSlot(object):
+    """What layers/conv.py finds for a weight: the bucket view, and whether a launch of THIS backward already wrote it."""
+    __slots__ = ("view", "param", "owner", "written")
+
+    def __init__(self, view, param, owner):
+        self.view, self.param, self.owner, self.written = view, weakref.ref(param), weakref.ref(owner), False
 
 
 class GradientExchange(object):
@@ -63,9 +118,11 @@ class GradientExchange(object):
     (no collective; gradients still land in the flat buckets), which is how the single-process tests exercise the
     slot / hook machinery."""
 
-    def __init__(self, model, device=None, collective=None, group=None, force_collectives=False):
+    def __init__(self, model, device=None, collective=None, group=None, force_collectives=False, cap_bytes=None,
+                 rebucket=True):
         """force_collectives: issue the collectives even in a one-rank group (they are then copies) — how the GPU
-        suite drives the RCCL calls and the side-stream ordering on a single device."""
+        suite drives the RCCL calls and the side-stream ordering on a single device.  rebucket: after the first
+        backward lay the buckets out in the observed order of gradient completion."""
         self.model, self.group = model, group
         self.force = bool(force_collectives) and dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if (_active() or self.force) else 1
@@ -80,41 +137,113 @@ class GradientExchange(object):
         if collective not in ("rs_ag", "allreduce"):
             raise ValueError("collective must be 'rs_ag' or 'allreduce'")
         self.collective = collective
-        groups = [[] for _ in BUCKET_PREFIXES]
+        self.cap = bucket_cap_bytes() if cap_bytes is None else int(cap_bytes)
+        from ..layers import conv
         for n, p in named:
             if not _dense(p):
                 raise RuntimeError("GradientExchange: parameter %s is not dense in memory" % n)
+            e = conv.GRAD_SLOTS.get((p.data_ptr(), p.numel()))
+            if e is not None and e.param() is p and e.owner() is not None:
+                raise RuntimeError("GradientExchange: parameter %s already belongs to a live exchange (detach() it "
+                                   "first)" % n)
+        groups = [[] for _ in BUCKET_PREFIXES]
+        for n, p in named:
             idx = next((i for i, pre in enumerate(BUCKET_PREFIXES) if n.startswith(pre)), 0)
-            groups[idx].append((n, p))
-        self.buckets, self._slot = [], {}
+            groups[idx].append(p)
+        # within a group: roughly the order the backward finishes them
+        order = [p for members in groups for p in members[::-1]]
+        self._names = {p: n for n, p in named}
+        self._index = {p: i for i, (_, p) in enumerate(named)}
+        self._by_index = [p for _, p in named]
+        self.buckets, self._slot, self._handles = [], {}, []
+        self._layout(order, boundaries=[len(g) for g in groups if g])
+        ref = weakref.ref(self)   # the hooks must not keep the exchange (and through it the buckets) alive
+
+        def hook(p):
+            ex = ref()
+            if ex is not None:
+                ex._hook(p)
+        for p in self._by_index:
+            self._handles.append(p.register_post_accumulate_grad_hook(hook))
+        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.cuda and (self.world > 1 or self.force)) \
+            else None
+        self._in_backward = False
+        self._next = 0                     # the next bucket (index) whose collective may be issued
+        self._seen = []                    # parameters in the order their gradients became ready (first backward)
+        self._rebucket = bool(rebucket) and os.environ.get("JTSM_DP_REBUCKET", "1") != "0"
+        self.rebucketed = False
+        self.issue_log = None              # tests: set to [] to record the bucket index of every collective issued
+
+    # ---- bucket layout ------------------------------------------------------------------------------------------
+    def _layout(self, order, boundaries=None):
+        """Cut `order` into buckets of at most the cap (a parameter above the cap gets a bucket of its own; a
+        boundary of the name-based guess also closes a bucket) and point every parameter's slot into them.  Existing
+        gradients move along."""
         from ..layers import conv
-        for members in groups:
-            if not members:
-                continue
-            members = members[::-1]   # within a bucket: roughly the order the backward finishes them
+        cuts, run = set(), 0
+        for b in boundaries or []:
+            run += b
+            cuts.add(run)
+        chunks, cur, cur_bytes = [], [], 0
+        for i, p in enumerate(order):
+            nbytes = 4 * ((p.numel() + 63) // 64 * 64)
+            if cur and (cur_bytes + nbytes > self.cap or i in cuts):
+                chunks.append(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            chunks.append(cur)
+        old = self._slot
+        self.buckets, self._slot = [], {}
+        for members in chunks:
             b = _Bucket()
             # pad every slot to 64 floats (256 B) and the bucket to a multiple of 64 * world so that reduce-scatter
             # shards are equal and 256-byte aligned
             offs, total = [], 0
-            for _, p in members:
+            for p in members:
                 offs.append(total)
                 total += (p.numel() + 63) // 64 * 64
             total = (total + 64 * self.world - 1) // (64 * self.world) * (64 * self.world)
             b.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
             b.numel = total
-            b.params = [p for _, p in members]
+            b.params = list(members)
             b.pending = len(members)
             b.event = torch.cuda.Event() if self.cuda else None
-            for (n, p), off in zip(members, offs):
+            for p, off in zip(members, offs):
                 view = b.flat[off:off + p.numel()].as_strided(p.shape, p.stride())
+                if p in old:
+                    prev = old[p][1]
+                    if p.grad is not None and p.grad.data_ptr() == prev.data_ptr():
+                        view.copy_(prev)
+                        p.grad = view
                 self._slot[p] = (b, view)
-                conv.GRAD_SLOTS[(p.data_ptr(), p.numel())] = view
-                p.register_post_accumulate_grad_hook(self._hook)
+                conv.GRAD_SLOTS[(p.data_ptr(), p.numel())] = GradSlot(view, p, self)
             self.buckets.append(b)
-        self.comm_stream = torch.cuda.Stream(device=self.device) if (self.cuda and (self.world > 1 or self.force)) \
-            else None
-        self._in_backward = False
         self.bytes = 4 * sum(b.numel for b in self.buckets)
+
+    def _adopt_observed_order(self):
+        """After the first backward: rank 0's completion order becomes everyone's bucket order."""
+        seen, have = [], set()
+        for p in self._seen:
+            if p not in have:
+                have.add(p)
+                seen.append(p)
+        for b in self.buckets:            # parameters without a gradient in that step keep their old relative place
+            for p in b.params:
+                if p not in have:
+                    have.add(p)
+                    seen.append(p)
+        idx = torch.tensor([self._index[p] for p in seen], dtype=torch.int64,
+                           device=self.device if self.cuda and dist.is_initialized() and
+                           dist.get_backend(self.group) == "nccl" else "cpu")
+        if self.world > 1:
+            dist.broadcast(idx, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                           group=self.group)
+        order = [self._by_index[i] for i in idx.tolist()]
+        assert sorted(self._index[p] for p in order) == list(range(len(self._by_index)))
+        self._layout(order)
+        self.rebucketed = True
 
     # ---- per-parameter hook: runs right after autograd has stored p.grad
     def _hook(self, p):
@@ -126,11 +255,17 @@ class GradientExchange(object):
         if not self._in_backward:
             self._in_backward = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+        if not self.rebucketed:
+            self._seen.append(p)
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        while self._next < len(self.buckets) and self.buckets[self._next].pending == 0:
+            self._launch(self._next)
+            self._next += 1
 
-    def _launch(self, b):
+    def _launch(self, i):
+        b = self.buckets[i]
+        if self.issue_log is not None:
+            self.issue_log.append(i)
         if self.world == 1 and not self.force:
             return
         if self.comm_stream is None:     # CPU tensors (gloo)
@@ -141,8 +276,11 @@ class GradientExchange(object):
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(b.event)
             if self.collective == "rs_ag":
+                # the in-place forms RCCL documents: recv == send + rank * count (reduce-scatter), send == recv + rank *
+                # count (all-gather)
                 shard = b.numel // self.world
-                mine = b.flat[dist.get_rank(self.group) * shard:(dist.get_rank(self.group) + 1) * shard]
+                r = dist.get_rank(self.group)
+                mine = b.flat[r * shard:(r + 1) * shard]
                 dist.reduce_scatter_tensor(mine, b.flat, op=dist.ReduceOp.AVG, group=self.group)
                 dist.all_gather_into_tensor(b.flat, mine, group=self.group)
             else:
@@ -150,26 +288,44 @@ class GradientExchange(object):
                 b.flat.div_(self.world)
 
     def _finish(self):
-        """End of the backward pass: late buckets (a parameter without gradient this step) still go out, then the
-        compute stream waits for every collective."""
-        for b in self.buckets:
-            if 0 < b.pending < len(b.params):
+        """End of the backward pass: every bucket not yet issued goes out, IN INDEX ORDER — a bucket some of whose
+        parameters got no gradient this step, or none at all, is completed with zeros (another rank may hold real
+        gradients for it, and all ranks must issue the same collectives) — then the compute stream waits for the side
+        stream."""
+        from ..layers import conv
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b.pending:
                 for p in b.params:   # a parameter that received no gradient contributes zeros
-                    if p.grad is None or p.grad.data_ptr() != self._slot[p][1].data_ptr():
-                        if p.grad is None:
-                            self._slot[p][1].zero_()
-                            p.grad = self._slot[p][1]
-                self._launch(b)
+                    if p.grad is None:
+                        self._slot[p][1].zero_()
+                        p.grad = self._slot[p][1]
+            self._launch(self._next)
+            self._next += 1
+        for b in self.buckets:
             b.pending = len(b.params)
+        self._next = 0
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
+        for p in self._slot:
+            e = conv.GRAD_SLOTS.get((p.data_ptr(), p.numel()))
+            if e is not None:
+                e.written = False
         self._in_backward = False
+        if self._rebucket and not self.rebucketed:
+            self._adopt_observed_order()
+        self._seen = []
 
     def detach(self):
-        """Forget the kernel-side slots (tests that build several models in one process)."""
+        """Forget the kernel-side slots and the hooks (tests that build several exchanges in one process)."""
         from ..layers import conv
         for p in self._slot:
-            conv.GRAD_SLOTS.pop((p.data_ptr(), p.numel()), None)
+            e = conv.GRAD_SLOTS.get((p.data_ptr(), p.numel()))
+            if e is not None and e.owner() is self:
+                conv.GRAD_SLOTS.pop((p.data_ptr(), p.numel()), None)
+        for h in self._handles:
+            h.remove()
+        self._handles = []
 
 
 def _dense(p):
@@ -195,10 +351,13 @@ class DataParallel(torch.nn.Module):
         return self.module(*args, **kwargs)
 
 
-def wrap_data_parallel(model, device=None, collective=None):
-    """The model behind this repo's own gradient exchange (identity for a single process)."""
+def wrap_data_parallel(model, device=None, collective=None, broadcast=True):
+    """The model behind this repo's own gradient exchange (identity for a single process).  As DDP does in the
+    reference (detectron2/engine/defaults.py:288-291), rank 0's parameters and buffers replace every other rank's."""
     if not _active():
         return model
+    if broadcast:
+        broadcast_state(model)
     return DataParallel(model, GradientExchange(model, device, collective))
 
 

@@ -289,16 +289,25 @@ GRAD_SLOTS = {}
 
 
 def grad_slot(w, params=None):
-    """The bucket view for weight `w` (a parameter or a dense view of one), or None."""
+    """The bucket view for weight `w` (a parameter or a dense alias of one) if THIS launch may write it, else None:
+    only the first weight-gradient launch of a parameter in a backward gets the slot — a weight used several times in
+    one step (the RPN head over five pyramid levels) gets ordinary tensors for its later uses and autograd sums them
+    (engine/dp.py re-arms the flags at the end of the backward).  Entries whose parameter or exchange is gone are
+    dropped."""
     if not GRAD_SLOTS or w is None:
         return None
-    view = GRAD_SLOTS.get((w.data_ptr(), w.numel()))
-    if view is None:
+    key = (w.data_ptr(), w.numel())
+    e = GRAD_SLOTS.get(key)
+    if e is None:
         return None
-    base = w._base if w._base is not None else w
-    if base.grad is not None:       # a second backward into the same step: let autograd accumulate
+    p = e.param()
+    if p is None or e.owner() is None or p.data_ptr() != key[0]:
+        GRAD_SLOTS.pop(key, None)   # stale: the model or its exchange was dropped / the parameter re-allocated
         return None
-    return view
+    if p.grad is not None or e.written:   # a second use, or a second backward into the same step: autograd accumulates
+        return None
+    e.written = True
+    return e.view
 
 
 # Per-shape launch facts (the ctypes shape struct, output size, FLOPs, workspace sizes, bf16x3 eligibility)

@@ -82,6 +82,30 @@ def paint_sem_seg(boxes, classes, scores, counts, class_base, height, width, ero
 
 
 @torch.no_grad()
+def paint_sem_seg_evidence(target_idx, bag_offsets, oh_labels, superpixels, classes, scores, counts, class_base):
+    """Pseudo semantic target (B,H,W) int64 painted from the targets' superpixel-evidence masks, as the reference does
+    (roi_heads_jtsm.py:2038-2069): target j of image b is proposal row bag_offsets[b] + target_idx[b,j]; its mask is the
+    union of the superpixels that row of oh_labels (R,L) marks.  Ascending-score paint order, then classes left without
+    a pixel once more in list order (libjtsm_hip.so: jtsm_paint_sem_seg_evidence)."""
+    L.require_gpu(oh_labels, superpixels, scores)
+    B, G = classes.shape
+    _, h, w = superpixels.shape
+    assert superpixels.shape[0] == B and oh_labels.dim() == 2
+    oh_labels = oh_labels.to(torch.int32).contiguous()
+    superpixels = superpixels.to(torch.int32).contiguous()
+    classes, counts = classes.to(torch.int32).contiguous(), counts.to(torch.int32).contiguous()
+    lib = L.lib()
+    out = torch.empty((B, h, w), dtype=torch.int64, device=scores.device)
+    ws = torch.empty(lib.jtsm_paint_sem_seg_workspace_bytes(B), dtype=torch.uint8, device=scores.device)
+    L.note_bytes(12.0 * B * h * w)   # superpixel ids read, int64 target written
+    L.check(lib.jtsm_paint_sem_seg_evidence(
+        L.ptr(target_idx.to(torch.int32).contiguous()), L.ptr(bag_offsets), L.ptr(oh_labels), oh_labels.shape[1],
+        L.ptr(superpixels), L.ptr(classes), L.ptr(scores.contiguous()), L.ptr(counts), B, G, int(class_base), h, w,
+        L.ptr(out), L.ptr(ws), L.stream()), "paint_sem_seg_evidence")
+    return out
+
+
+@torch.no_grad()
 def rect_mask_targets(rois, rects, side, height, width, erode=2.0):
     """(N, side, side) bool mask targets: the H x W bitmask of rects[n] shrunk by `erode`, cropped and resized to
     rois[n] the way BitMasks.crop_and_resize does it (ROIAlign, aligned, adaptive sampling, >= 0.5) — evaluated

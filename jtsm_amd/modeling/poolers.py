@@ -153,6 +153,20 @@ class _MOILevels(Function):
         return (None, None, None, None, None, None, *grads)
 
 
+def moi_label_inputs(oh_labels_list, superpixels):
+    """The two label operands of MOIPool and of the superpixel-evidence targets in the form the kernels read:
+    oh_labels of all images concatenated (rows = the concatenated boxes), padded to a common width, int32; the
+    superpixel maps (B,Hs,Ws) int32.  Tensors already in that form pass through."""
+    sp = superpixels.tensor if hasattr(superpixels, "tensor") else superpixels
+    sp = sp.to(torch.int32).contiguous()
+    if isinstance(oh_labels_list, torch.Tensor):
+        return oh_labels_list.to(torch.int32).contiguous(), sp
+    max_len = max(l.size(1) for l in oh_labels_list)
+    labels = cat([l.to(torch.int32) if l.size(1) == max_len else
+                  torch.nn.functional.pad(l.to(torch.int32), (0, max_len - l.size(1))) for l in oh_labels_list])
+    return labels.contiguous(), sp
+
+
 class ROIPooler(nn.Module):
     def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224,
                  canonical_level=4):
@@ -205,14 +219,7 @@ class ROIPooler(nn.Module):
         pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
         moi = superpixels is not None
         if moi:
-            sp = superpixels.tensor if hasattr(superpixels, "tensor") else superpixels
-            sp = sp.to(torch.int32).contiguous()
-            max_len = max(l.size(1) for l in oh_labels_list)
-            labels = cat([l.to(torch.int32) if l.size(1) == max_len else
-                          torch.nn.functional.pad(l.to(torch.int32), (0, max_len - l.size(1))) for l in oh_labels_list])
-            labels = labels.contiguous()
-            # kept for the mask branch's superpixel-evidence targets (same rows as the concatenated boxes)
-            self.last_oh_labels, self.last_superpixels = labels, sp
+            labels, sp = moi_label_inputs(oh_labels_list, superpixels)
         if num_level_assignments == 1:
             if moi:
                 return self.level_poolers[0](x[0], pooler_fmt_boxes, labels, sp)

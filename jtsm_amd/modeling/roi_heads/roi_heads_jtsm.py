@@ -23,8 +23,9 @@ Mask pseudo labels, all on the device and without host round
     csrc/roi_align.hip: paste_crop_targets).
 Declared substitutions (identical in oracle/model.py): grabCut itself (the reference's live branch of
 object_evidence, an OpenCV CPU routine) is replaced by the superpixel evidence above; masks stay bitmasks where the
-reference encodes them as polygons and rasterises those again (cv2.findContours / pycocotools); the pseudo SEMANTIC
-target still paints pseudo-GT rectangles shrunk by 2 px.  MASK_TARGETS = "rect" restores round 1's rectangles.
+reference encodes them as polygons and rasterises those again (cv2.findContours / pycocotools).  The pseudo SEMANTIC
+target is painted from the same superpixel-evidence masks, as the reference paints it from its targets' pgt_masks
+(:2038-2069).  mask_targets / sem_targets = "rect" restore round 1's rectangles shrunk by 2 px.
 """
 from typing import Dict, List, Optional
 
@@ -33,11 +34,11 @@ import torch.nn.functional as F
 
 from ...layers.conv import linear_fused, linear_fused_split
 from ...layers.mining import (match_label, mine_top1, near_targets, pad_class_lists, paint_sem_seg,
-                              paste_crop_targets, rect_mask_targets, row_lse, sp_mask_targets)
+                              paint_sem_seg_evidence, paste_crop_targets, rect_mask_targets, row_lse, sp_mask_targets)
 from ...layers.roi_align import roi_align
 from ...layers.shape_spec import ShapeSpec
 from ...structures import Boxes, ImageList, Instances
-from ..poolers import ROIPooler
+from ..poolers import ROIPooler, moi_label_inputs
 from .box_head import build_box_head
 from .fast_rcnn_oicr import OICROutputLayers
 from .fast_rcnn_tsm import TSMOutputLayers
@@ -150,6 +151,8 @@ class JTSMROIHeads(ROIHeads):
         self.aux = {}
         self.mask_mined_top_k = 10            # roi_heads_jtsm.py:420 (self.mask_mined_top_k = 10)
         self.mask_targets = "evidence"        # "evidence" (reference semantics) or "rect" (round-1 rectangles)
+        self.sem_targets = "evidence"         # pseudo semantic target: from the evidence masks (:2038-2069) or "rect"
+        self._evidence = None                 # (oh_labels of all proposals (R,L) int32, superpixels (B,H,W) int32)
 
     # ------------------------------------------------------------------ label mining (no grad)
     @torch.no_grad()
@@ -175,35 +178,46 @@ class JTSMROIHeads(ROIHeads):
 
     @torch.no_grad()
     def get_pgt_sem_seg(self, prev_pred_boxes, prev_pred_scores, proposals, height, width):
-        """Reference-shaped entry (list-of-Instances mining, roi_heads_jtsm.py:2025-2070)."""
+        """Reference-shaped entry (list-of-Instances mining, roi_heads_jtsm.py:2025-2070): the targets' masks are
+        their superpixel evidence (object_evidence :1928-1994) — or, with sem_targets == "rect", their rectangles
+        shrunk by 2 px."""
         stuff_lists = [c[:int(n)].to(torch.int64) for c, n in zip(self.stuff_cls, self.stuff_cnt.tolist())]   # (syncs)
         targets = self.get_pgt_top_k(prev_pred_boxes, prev_pred_scores, proposals,
                                      self.num_classes + self.num_classes_stuff - 1, stuff_lists)
-        return self._paint_sem_seg([t.gt_boxes.tensor for t in targets], [t.gt_classes for t in targets],
-                                   [t.gt_scores for t in targets], height, width)
+        if self.sem_targets == "evidence":
+            sp = self.superpixels.tensor if hasattr(self.superpixels, "tensor") else self.superpixels
+            masks = []
+            for t, sp_i in zip(targets, sp):
+                ids = sp_i.reshape(1, -1).to(torch.int64)
+                width_l = t.oh_labels.shape[1]
+                inside = (ids >= 0) & (ids < width_l)
+                hit = torch.gather(t.oh_labels.to(torch.int64), 1, ids.clamp(0, width_l - 1).expand(len(t), -1)) != 0
+                masks.append((hit & inside).reshape(len(t), *sp_i.shape))
+        else:
+            masks = [eroded_rect_masks(t.gt_boxes.tensor, height, width) > 0.5 for t in targets]
+        return self._paint_sem_seg(masks, [t.gt_classes for t in targets], [t.gt_scores for t in targets], height, width)
 
     @torch.no_grad()
-    def _paint_sem_seg(self, boxes, classes, scores, height, width):
-        """Pseudo semantic target: every pseudo stuff box paints its (shrunk) rectangle with its class id,
-        in ascending score order so the best box ends on top; a class that got painted over completely is
-        painted once more (in class order).  Written without host synchronisation: "ascending order,
-        last write wins" is the per-pixel maximum of the boxes' score RANKS."""
-        out = torch.zeros(len(boxes), height, width, device=boxes[0].device, dtype=torch.int64)
-        for i, (bx, cl, sc) in enumerate(zip(boxes, classes, scores)):
-            n = bx.shape[0]
+    def _paint_sem_seg(self, masks, classes, scores, height, width):
+        """Pseudo semantic target: every pseudo stuff target paints its (n,H,W) bool mask with its class id, in
+        ascending score order so the best target ends on top; a class that got painted over completely is painted
+        once more (in class order).  Written without host synchronisation: "ascending order, last write wins" is the
+        per-pixel maximum of the targets' score RANKS."""
+        out = torch.zeros(len(masks), height, width, device=masks[0].device, dtype=torch.int64)
+        for i, (mk, cl, sc) in enumerate(zip(masks, classes, scores)):
+            n = mk.shape[0]
             if n == 0:
                 continue
-            masks = eroded_rect_masks(bx, height, width) > 0.5                  # (n,H,W)
             vals = cl.to(torch.int64) - self.num_classes + 1
             order = torch.argsort(sc, descending=False)
             rank = torch.empty_like(order)
             rank[order] = torch.arange(n, device=order.device)
-            top = torch.where(masks, rank.view(n, 1, 1), rank.new_full((), -1)).max(dim=0).values
+            top = torch.where(mk, rank.view(n, 1, 1), rank.new_full((), -1)).max(dim=0).values
             painted = vals[order[top.clamp(min=0)]]
             img = torch.where(top >= 0, painted, painted.new_zeros(()))
             for j in range(n):                                                  # sequential, but sync-free
                 missing = ~(img == vals[j]).any()
-                img = torch.where(missing & masks[j], vals[j], img)
+                img = torch.where(missing & mk[j], vals[j], img)
             out[i] = img
         return out
 
@@ -242,9 +256,11 @@ class JTSMROIHeads(ROIHeads):
     def _box_features(self, features, proposals):
         """MOIPool -> per-roi rescale -> DAN -> every predictor in one GEMM (roi_heads_jtsm.py:607-633)."""
         feats = [features[f] for f in self.box_in_features]
+        # the label operands in kernel form, once: MOIPool reads them here, the evidence masks of the semantic target
+        # and of the mask branch read the same tensors later (handed on explicitly, not through the pooler's state)
+        self._evidence = moi_label_inputs([x.oh_labels for x in proposals], self.superpixels)
         box_features, argmax = self.box_pooler(feats, [x.proposal_boxes for x in proposals],
-                                               oh_labels_list=[x.oh_labels for x in proposals],
-                                               superpixels=self.superpixels)
+                                               oh_labels_list=self._evidence[0], superpixels=self._evidence[1])
         with torch.no_grad():
             bins = argmax.size(2) * argmax.size(3)
             nvalid = (argmax[:, 0, :, :] != -1).reshape(argmax.size(0), -1).sum(dim=1).to(dtype=torch.float32)
@@ -306,8 +322,14 @@ class JTSMROIHeads(ROIHeads):
         if self.has_stuff:
             pg = mine_top1(scores, all_boxes, offsets, self.stuff_cls, self.stuff_cnt, img_probs)
             h, w = self.images.tensor.shape[-2:]
-            self.pgt_sem_seg = paint_sem_seg(pg["boxes"], self.stuff_cls, pg["scores"], self.stuff_cnt,
-                                             self.num_classes - 1, h, w)
+            if self.sem_targets == "evidence":
+                oh_all, sp = self._evidence
+                assert tuple(sp.shape[-2:]) == (h, w), "superpixel maps must be padded like the images"
+                self.pgt_sem_seg = paint_sem_seg_evidence(pg["idx"], offsets, oh_all, sp, self.stuff_cls, pg["scores"],
+                                                          self.stuff_cnt, self.num_classes - 1)
+            else:
+                self.pgt_sem_seg = paint_sem_seg(pg["boxes"], self.stuff_cls, pg["scores"], self.stuff_cnt,
+                                                 self.num_classes - 1, h, w)
         else:
             self.pgt_sem_seg = None
 
@@ -377,8 +399,7 @@ class JTSMROIHeads(ROIHeads):
             side = 2 * self.mask_pooler.output_size[0]
             if self.mask_targets == "evidence":
                 # the matched near target's superpixel-evidence mask, cropped to the proposal (never rasterised)
-                oh_all = self.box_pooler.last_oh_labels
-                sp = self.box_pooler.last_superpixels
+                oh_all, sp = self._evidence
                 gt_masks = sp_mask_targets(fg_boxes, lab["matched_near"][fg], img_of, oh_all, sp, side)
                 self.aux["near_rows"], self.aux["matched_near"] = lab["near_rows"], lab["matched_near"][fg]
             else:

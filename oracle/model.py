@@ -20,14 +20,15 @@ What each function follows (paths relative to the reference tree):
   box_deltas/apply      detectron2/modeling/box_regression.py:38-113
   mask_branch           .../roi_heads_jtsm.py:754-948; .../mask_head.py:23-103,266-343; structures/masks.py:169-200
   semseg_head           detectron2/modeling/meta_arch/semantic_seg.py:103-188
-  pgt_sem_seg           .../roi_heads_jtsm.py:2025-2070
+  pgt_sem_seg           .../roi_heads_jtsm.py:2025-2070 (masks: need_mask=True -> :1333-1334 -> :1928-1994)
   near targets          .../roi_heads_jtsm.py:840-905 (top-10 foreground proposals per pseudo box, second labelling)
   evidence masks        .../roi_heads_jtsm.py:1928-1994 (object_evidence, superpixel branch)
   refinery targets      .../roi_heads_jtsm.py:1997-2022 (get_pgt_mask: paste, then crop_and_resize)
 Declared substitutions (also made by the product path): grabCut (object_evidence's live branch, OpenCV) is
 replaced by the reference's own superpixel-evidence construction; masks stay bitmasks where the reference
-encodes them as polygons and rasterises those again; the pseudo SEMANTIC target paints pseudo-GT rectangles
-eroded by 2 px.  mask_targets="rect" selects round 1's rectangle masks + thresholded refinery targets.
+encodes them as polygons and rasterises those again.  The pseudo SEMANTIC target is painted from the targets'
+superpixel-evidence masks (:2038-2069).  mask_targets="rect" / sem_targets="rect" select round 1's rectangle masks
+(+ thresholded refinery targets / rectangles eroded by 2 px in the semantic target).
 Dropout is a caller-supplied mask (None = off).
 """
 import math
@@ -535,12 +536,32 @@ def eroded_rect_masks(boxes, H, W, erode=2):
             (ys <= b[:, 3] - erode)).to(torch.float32)
 
 
-def pgt_sem_seg(tgt_list, H, W, nt=NUM_THINGS):
+def evidence_masks(oh_rows, sp):
+    """(G,H,W) bool superpixel-evidence masks (object_evidence, roi_heads_jtsm.py:1928-1994, superpixel branch):
+    mask_g = union of the superpixels l < L with oh_rows[g, l] != 0 (the reference's `poses` loop runs over range(L),
+    so a superpixel id outside [0, L) belongs to no mask)."""
+    L = oh_rows.shape[1]
+    ids = sp.reshape(1, -1).to(torch.int64)
+    inside = (ids >= 0) & (ids < L)
+    hit = torch.gather(oh_rows.to(torch.int64), 1, ids.clamp(0, L - 1).expand(oh_rows.shape[0], -1)) != 0
+    return (hit & inside).reshape(oh_rows.shape[0], *sp.shape)
+
+
+def pgt_sem_seg(tgt_list, H, W, nt=NUM_THINGS, oh_list=None, sp=None):
+    """get_pgt_sem_seg (roi_heads_jtsm.py:2025-2070): the targets' masks painted with class - nt + 1 in ascending
+    score order (:2061-2062), then every class absent from the map painted once more in list order (:2064-2066).
+    Masks: the targets' pgt_masks = superpixel evidence of their oh_labels rows (oh_list / sp given; :2038-2047 with
+    need_mask=True -> :1333-1334 -> :1928-1994); without them round 1's rectangles shrunk by 2 px."""
     out = torch.zeros(len(tgt_list), H, W, dtype=torch.int64)
     for i, t in enumerate(tgt_list):
-        masks = eroded_rect_masks(t["boxes"], H, W) > 0.5
+        if oh_list is not None:
+            masks = evidence_masks(oh_list[i][t["idx"]], sp[i])
+        else:
+            masks = eroded_rect_masks(t["boxes"], H, W) > 0.5
         vals = t["classes"] - nt + 1
-        for j in torch.argsort(t["scores"], descending=False):
+        # (equal scores: the reference's argsort leaves their order open; fixed here and in the product as "lower
+        # index first")
+        for j in torch.argsort(t["scores"], descending=False, stable=True):
             out[i][masks[j]] = vals[j]
         for j in range(vals.numel()):
             if not (out[i] == vals[j]).any():
@@ -591,7 +612,7 @@ def near_targets_and_masks(boxes, sel, tgt, oh, sp, top_k=10):
 
 
 def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_aux=False, arch="fpn",
-                   nt=NUM_THINGS, ns=NUM_STUFF, mask_targets="evidence", forced=None):
+                   nt=NUM_THINGS, ns=NUM_STUFF, mask_targets="evidence", forced=None, sem_targets="evidence"):
     """batch: dict(images=[(3,H,W)], boxes=[(R_i,4)], objectness=[(R_i,)], oh_labels=[(R_i,L) int],
     superpixels=(B,H,W) int32, gt_classes=[(n_i,) int64], sem_seg=(B,H,W) int64).
     arch "fpn": the R50/R101-FPN composite with SemSegFPNHead; arch "dc5": the shipped single-level composite
@@ -600,12 +621,13 @@ def forward_losses(p, batch, depth=50, refine_k=4, dropout_masks=None, return_au
     global _FORCED
     _FORCED = forced
     try:
-        return _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, nt, ns, mask_targets)
+        return _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, nt, ns, mask_targets,
+                               sem_targets)
     finally:
         _FORCED = None
 
 
-def _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, nt, ns, mask_targets):
+def _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, nt, ns, mask_targets, sem_targets):
     single = arch == "dc5"
     NUM_THINGS, NUM_MIL = nt, nt + ns - 1   # (shadow the module constants: the body below is written with them)
     x = preprocess(p, batch["images"], 8 if single else 32)
@@ -643,7 +665,11 @@ def _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, 
     prev_scores = list(scores.detach().split(counts))
     prev_boxes = [b[:, None, :].expand(len(b), NUM_MIL, 4) for b in batch["boxes"]]
     sem_tgts = [mine_top1(pb, ps, st, ip) for pb, ps, st, ip in zip(prev_boxes, prev_scores, stuff, img_probs)]
-    sem_target = pgt_sem_seg(sem_tgts, Himg, Wimg, nt)
+    sp_pad = F.pad(batch["superpixels"], (0, Wimg - batch["superpixels"].shape[2], 0, Himg - batch["superpixels"].shape[1]))
+    if sem_targets == "evidence":
+        sem_target = pgt_sem_seg(sem_tgts, Himg, Wimg, nt, batch["oh_labels"], sp_pad)
+    else:
+        sem_target = pgt_sem_seg(sem_tgts, Himg, Wimg, nt)
     prev_boxes = [pb[:, :NUM_THINGS] for pb in prev_boxes]
     for k in range(refine_k):
         tg = [mine_top1(pb, ps, th, ip) for pb, ps, th, ip in zip(prev_boxes, prev_scores, things, img_probs)]
@@ -663,7 +689,6 @@ def _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, 
     lab = [match_and_label(b, t, nt) for b, t in zip(batch["boxes"], tg)]
     fg_rois, fg_cls, tgt_rois, gt_masks, near_rows = [], [], [], [], []
     base = row0 = 0
-    sp_pad = F.pad(batch["superpixels"], (0, Wimg - batch["superpixels"].shape[2], 0, Himg - batch["superpixels"].shape[1]))
     for i, (b, l, t) in enumerate(zip(batch["boxes"], lab, tg)):
         sel = torch.nonzero((l["classes"] >= 0) & (l["classes"] < NUM_THINGS))[:, 0]
         fg_rois.append(torch.cat([torch.full((len(sel), 1), float(i)), b[sel]], 1))
@@ -722,8 +747,14 @@ def _forward_losses(p, batch, depth, refine_k, dropout_masks, return_aux, arch, 
 
 
 # ----------------------------------------------------------------------------- synthetic batch
-def synthetic_batch(seed, B=2, size=1024, R=2000, sp_block=32, n_things=3, n_stuff=2, nt=NUM_THINGS, ns=NUM_STUFF):
+def synthetic_batch(seed, B=2, size=1024, R=2000, sp_block=32, n_things=3, n_stuff=2, nt=NUM_THINGS, ns=NUM_STUFF,
+                    cluster=0.0, objects=None):
+    """cluster > 0: that fraction of every image's proposals are jittered copies (each edge +-12 % of the side) of
+    `objects` rectangles per image — bench.py's headline recipe (jtsm_amd/utils/synthetic.py), where a mined pseudo box
+    has many proposals above IoU 0.5 and crowded, nearly equal IoUs (drawn from a second generator, so cluster = 0
+    reproduces the plain recipe bit for bit)."""
     g = torch.Generator().manual_seed(seed)
+    g2 = torch.Generator().manual_seed(seed * 7919 + 13)
     grid = size // sp_block
     ids = (torch.arange(size)[:, None] // sp_block) * grid + (torch.arange(size)[None, :] // sp_block)
     cy = (torch.arange(grid) * sp_block + sp_block / 2.0)
@@ -738,6 +769,15 @@ def synthetic_batch(seed, B=2, size=1024, R=2000, sp_block=32, n_things=3, n_stu
         w = torch.exp(torch.rand(R, generator=g) * (hi - lo) + lo)
         hh = torch.exp(torch.rand(R, generator=g) * (hi - lo) + lo)
         bx = torch.stack([x0, y0, (x0 + w).clamp(max=size), (y0 + hh).clamp(max=size)], 1)
+        if cluster > 0:
+            nc, no = int(round(cluster * R)), (n_things if objects is None else int(objects))
+            ox, oy = torch.rand(no, generator=g2) * size * 0.6, torch.rand(no, generator=g2) * size * 0.6
+            ow = torch.exp(torch.rand(no, generator=g2) * (hi - lo) + lo)
+            ohh = torch.exp(torch.rand(no, generator=g2) * (hi - lo) + lo)
+            which = torch.randint(0, no, (nc,), generator=g2)
+            jit = (torch.rand(nc, 4, generator=g2) - 0.5) * 0.24
+            cl = torch.stack([ox, oy, ox + ow, oy + ohh], 1)[which] + jit * torch.stack([ow, ohh, ow, ohh], 1)[which]
+            bx[:nc] = cl.clamp(0, size)
         out["boxes"].append(bx)
         out["objectness"].append(torch.rand(R, generator=g))
         iny = (cy[None, :] >= bx[:, 1:2]) & (cy[None, :] <= bx[:, 3:4])

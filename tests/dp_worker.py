@@ -83,7 +83,8 @@ def main():
         # every trainable parameter's gradient now lives in its flat bucket, with the parameter's own strides
         for p in ex._slot:
             assert p.grad is not None and p.grad.data_ptr() == ex._slot[p][1].data_ptr() and p.grad.stride() == p.stride()
-        info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes, "loss": float(sum(losses.values()).detach())}
+        info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes, "loss": float(sum(losses.values()).detach()),
+                "rebucketed": ex.rebucketed, "order": [ex._names[p] for b in ex.buckets for p in b.params]}
     else:
         grads = []
         for r in range(2):

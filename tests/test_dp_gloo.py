@@ -64,3 +64,143 @@ def test_world2_gloo_gradients_are_mean_of_rank_means():
     tot.backward()
     expect = torch.cat([p.grad.flatten() for p in ref.parameters()])
     assert torch.allclose(g0, expect, atol=1e-6)
+
+
+class _ThreeHeads(torch.nn.Module):
+    """A trunk with three heads; `skip` leaves one head out of the loss (its parameters get no gradient)."""
+
+    def __init__(self):
+        super().__init__()
+        self.trunk = torch.nn.Linear(8, 16)
+        self.heads = torch.nn.ModuleList([torch.nn.Linear(16, 3) for _ in range(3)])
+
+    def forward(self, x, skip=None):
+        h = torch.relu(self.trunk(x))
+        return sum((head(h) ** 2).mean() for i, head in enumerate(self.heads) if i != skip)
+
+
+def _worker_uneven(rank, world, port, out):
+    """Ranks start from DIFFERENT seeds (the wrap broadcasts rank 0's state); on the second step rank 1's loss omits a
+    head, on the third no rank touches it: collectives must still be issued in the same order on both ranks, the
+    missing gradients count as zeros, and the ranks end identical."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), JTSM_DP_BUCKET_MB="0.0001")     # ~100-byte cap: every tensor its own bucket
+    from jtsm_amd.engine import dp
+
+    dp.init_distributed("gloo")
+    torch.manual_seed(100 + rank)                            # different weights per rank before the wrap
+    model = _ThreeHeads()
+    before = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+    net = dp.wrap_data_parallel(model)
+    after = torch.cat([p.detach().flatten() for p in model.parameters()]).clone()
+    ex = net.exchange
+    assert len(ex.buckets) == 8 and not ex.rebucketed
+    g = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(4, 8, generator=g)
+    logs, grads = [], []
+    for step, skip in enumerate([None, (1 if rank == 1 else None), 1]):
+        model.zero_grad(set_to_none=True)
+        ex.issue_log = []
+        net(x, skip=skip).backward()
+        logs.append(list(ex.issue_log))
+        grads.append(torch.cat([p.grad.flatten() for p in model.parameters()]).clone())
+        assert ex.rebucketed                                 # the observed order replaced the name-based guess
+        for p in model.parameters():
+            assert p.grad.data_ptr() == ex._slot[p][1].data_ptr()
+    order = [ex._names[b.params[0]] for b in ex.buckets]
+    out[rank] = (before, after, x, logs, grads, order)
+    torch.distributed.destroy_process_group()
+
+
+def test_world2_broadcast_fixed_issue_order_and_missing_gradients():
+    world, port = 2, _free_port()
+    out = mp.Manager().dict()
+    mp.spawn(_worker_uneven, args=(world, port, out), nprocs=world, join=True)
+    (b0, a0, x0, logs0, g0, order0), (b1, a1, x1, logs1, g1, order1) = out[0], out[1]
+    assert not torch.equal(b0, b1)                           # different seeds ...
+    assert torch.equal(a0, a1) and torch.equal(a0, b0)       # ... rank 0's state everywhere after the wrap
+    assert order0 == order1                                  # same bucket layout (rank 0's observed order)
+    # the heads finish before the trunk in a backward: the rebuilt layout starts with head parameters
+    assert order0[0].startswith("heads.") and order0[-1].startswith("trunk.")
+    for l0, l1 in zip(logs0, logs1):
+        assert l0 == l1 == sorted(l0) and len(l0) == 8       # every bucket, in index order, on both ranks, every step
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    # step 2: rank 1 had no gradient for head 1 -> the mean is half of rank 0's; step 3: nobody had one -> zeros
+    torch.manual_seed(100)
+    ref = _ThreeHeads()
+    names = [n for n, _ in ref.named_parameters()]
+    sizes = [p.numel() for p in ref.parameters()]
+
+    def expect(skips):
+        tot = []
+        for x, skip in zip((x0, x1), skips):
+            ref.zero_grad(set_to_none=True)
+            ref(x, skip=skip).backward()
+            tot.append(torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten()
+                                  for p in ref.parameters()]))
+        return 0.5 * (tot[0] + tot[1])
+
+    for got, skips in zip(g0, [(None, None), (None, 1), (1, 1)]):
+        assert torch.allclose(got, expect(skips), atol=1e-6)
+    off = sum(sizes[:names.index("heads.1.weight")])
+    assert g0[2][off:off + sizes[names.index("heads.1.weight")]].abs().max() == 0
+
+
+class _SlotWgrad(torch.autograd.Function):
+    """The kernels' protocol on CPU: the weight gradient of y = x @ w.T is WRITTEN (not accumulated) into the slot
+    layers/conv.py hands out, exactly like a fresh weight-gradient launch."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from jtsm_amd.layers import conv
+        x, w = ctx.saved_tensors
+        dw = dy.t() @ x
+        slot = conv.grad_slot(w)
+        if slot is not None:
+            slot.copy_(dw)
+            dw = slot
+        return dy @ w, dw
+
+
+def test_weight_used_twice_in_one_backward_gets_the_sum():
+    """a weight applied several times in one step (the RPN head on five pyramid levels) must not
+    have its slot overwritten by each use; only the first launch gets the slot, autograd accumulates the rest."""
+    from jtsm_amd.engine import dp
+    from jtsm_amd.layers import conv
+
+    torch.manual_seed(0)
+    model = torch.nn.Linear(4, 3, bias=False)
+    ex = dp.GradientExchange(model, torch.device("cpu"))
+    try:
+        xs = [torch.randn(5, 4) for _ in range(3)]
+        for _ in range(2):                                   # the per-backward flags re-arm
+            model.zero_grad(set_to_none=True)
+            sum(_SlotWgrad.apply(x, model.weight).sum() for x in xs).backward()
+            want = sum(torch.ones(5, 3).t() @ x for x in xs)
+            assert torch.allclose(model.weight.grad, want, atol=1e-6)
+            assert model.weight.grad.data_ptr() == ex._slot[model.weight][1].data_ptr()
+        # a second exchange over the same parameters would fight for the slots: refused while the first is alive
+        try:
+            dp.GradientExchange(model, torch.device("cpu"))
+            raise AssertionError("a second live exchange was accepted")
+        except RuntimeError as e:
+            assert "already belongs" in str(e)
+    finally:
+        ex.detach()
+    assert not any(e.owner() is ex for e in conv.GRAD_SLOTS.values())
+    # stale entries (their parameter or exchange is gone) are ignored and dropped
+    model2 = torch.nn.Linear(4, 3, bias=False)
+    ex2 = dp.GradientExchange(model2, torch.device("cpu"))
+    key = (model2.weight.data_ptr(), model2.weight.numel())
+    assert key in conv.GRAD_SLOTS
+    w_alias = model2.weight.detach()
+    del ex2, model2
+    import gc
+    gc.collect()
+    assert conv.grad_slot(w_alias) is None and key not in conv.GRAD_SLOTS

@@ -209,6 +209,152 @@ def test_whole_step_gradients_at_1e4_with_frozen_discrete_choices(cuda, math):
         fused_blocks.ENABLED = old_fused
 
 
+def _check_against_oracle(model, losses, losses0, aux0):
+    assert set(losses) == set(losses0)
+    for k in sorted(losses0):
+        a, b = float(losses[k].detach()), float(losses0[k])
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
+    aux = model.roi_heads.aux
+    cnt = aux["things_cnt"].cpu().tolist()
+    for k in range(4):
+        pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
+        for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
+            assert cnt[i] == b.numel() and torch.equal(pad[i, :cnt[i]], b)
+        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+    assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
+    assert torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
+    assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
+    near = aux["near_rows"].cpu()
+    for i, want in enumerate(aux0["near_rows"]):
+        got = near[i, :cnt[i]].reshape(-1)
+        assert torch.equal(got[got >= 0].to(torch.int64), want), (i, got, want)
+    assert torch.equal(aux["mask_targets"].cpu(), aux0["mask_targets"])
+    assert (aux["mask_targets_r0"].cpu() != aux0["mask_targets_r0"]).float().mean().item() < 2e-3
+    return aux
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+@pytest.mark.parametrize("objects", [5, 8])
+def test_clustered_workload_matches_oracle(cuda, math, objects):
+    """parity on the workload that is benchmarked.  bench.py's proposals are jittered copies of a few
+    rectangles per image (cluster = 1): a mined pseudo box then has tens of foreground proposals with crowded, nearly
+    equal IoUs — where the tie-breaking of the "10 nearest" targets (roi_heads_jtsm.py:840-905) and of the matcher's
+    first maximum (matcher.py:61-103) decides integer artefacts.  Same recipe in oracle/model.py: every loss at 1e-4,
+    every integer artefact bit-exact, in both arithmetics."""
+    old = K.MATH
+    K.set_math(math)
+    try:
+        params = OM.init_params(seed=3, random_bn=True, input_gain=1.0 / 64)
+        batch = OM.synthetic_batch(1234, B=2, size=256, R=160, sp_block=8, cluster=1.0, objects=objects)
+        losses0, aux0 = OM.forward_losses(params, batch, return_aux=True)
+        assert aux0["fg_rois"].shape[0] >= 40              # the mask branch counts: dozens of rois per pseudo box
+        assert all(n.numel() == 30 for n in aux0["near_rows"])   # 3 classes x 10 nearest, every list full
+        model = build_model(jtsm_cfg("cuda"))
+        model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+        model.train()
+        model.roi_heads.box_head.dropout_p = 0.0
+        losses = model(to_batched_inputs(batch))
+        _check_against_oracle(model, losses, losses0, aux0)
+        sum(losses.values()).backward()
+        assert all(p.grad is None or bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+    finally:
+        K.set_math(old)
+
+
+def test_semantic_target_rect_mode_still_matches(cuda):
+    """sem_targets = "rect" (round 1's substitution: pseudo-GT rectangles shrunk by 2 px) stays in parity with the
+    oracle's same mode; the default paints the targets' superpixel-evidence masks as the reference does."""
+    params = OM.init_params(seed=3, random_bn=True, input_gain=1.0 / 64)
+    batch = OM.synthetic_batch(1234, B=2, size=256, R=160, sp_block=8)
+    losses0, aux0 = OM.forward_losses(params, batch, sem_targets="rect", return_aux=True)
+    _, aux1 = OM.forward_losses(params, batch, return_aux=True)
+    assert not torch.equal(aux0["sem_target"], aux1["sem_target"])       # the two constructions differ
+    model = build_model(jtsm_cfg("cuda"))
+    model.load_state_dict({k: v.detach() for k, v in params.items()}, strict=True)
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    model.roi_heads.sem_targets = "rect"
+    losses = model(to_batched_inputs(batch))
+    assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
+    a, b = float(losses["loss_sem_seg"].detach()), float(losses0["loss_sem_seg"])
+    assert abs(a - b) <= 1e-4 * abs(b)
+
+
+def test_semantic_target_from_evidence_masks_bit_exact(cuda):
+    """jtsm_paint_sem_seg_evidence against the oracle's literal reading of get_pgt_sem_seg (roi_heads_jtsm.py:2038-2069
+    with the masks of :1928-1994) on crafted targets: overlapping evidence painted in ascending-score order, a class
+    painted over COMPLETELY (repainted by the second pass, in list order), equal scores (lower index first — argsort is
+    stable in the oracle's torch build for this size), superpixel ids outside [0, L), a ragged target count, and the
+    reference-shaped list-of-Instances entry."""
+    from jtsm_amd.layers.mining import paint_sem_seg_evidence
+
+    g = torch.Generator().manual_seed(11)
+    B, H, W, L, R, G = 2, 48, 64, 24, 12, 5
+    sp = torch.randint(-1, L + 2, (B, H, W), generator=g, dtype=torch.int32)      # ids -1, L, L+1: no mask owns them
+    oh = [(torch.rand(R, L, generator=g) < 0.3).to(torch.int32) for _ in range(B)]
+    idx = torch.tensor([[3, 5, 7, 1, 0], [2, 9, 4, 0, 0]])
+    counts = [5, 3]
+    scores = torch.tensor([[0.2, 0.9, 0.2, 0.5, 0.7], [0.6, 0.1, 0.6, 0.0, 0.0]])
+    classes = torch.tensor([[81, 84, 90, 95, 100], [82, 83, 99, 0, 0]])
+    # image 0: target 1 has the top score and its evidence covers target 0's -> class 81 is painted over and comes
+    # back in the second pass; target 3 marks nothing at all (stays absent)
+    oh[0][5] = torch.maximum(oh[0][5], oh[0][3])
+    oh[0][1] = 0
+    tg = [dict(idx=idx[i, :counts[i]], classes=classes[i, :counts[i]].to(torch.int64), scores=scores[i, :counts[i]])
+          for i in range(B)]
+    want = OM.pgt_sem_seg(tg, H, W, 80, oh, sp)
+    assert (want[0] == 2).any() and not (want[0] == 16).any()
+    offsets = torch.tensor([0, R, 2 * R], dtype=torch.int32, device=cuda)
+    got = paint_sem_seg_evidence(idx.to(cuda), offsets, torch.cat(oh).to(cuda), sp.to(cuda), classes.to(cuda),
+                                 scores.to(cuda), torch.tensor(counts, device=cuda), 79)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+
+
+def test_full_size_clustered_step_is_reproducible_and_finite(cuda):
+    """The benchmarked step itself (bench.py defaults: cluster = 1, 40 rectangles per image, ~300 foreground rois):
+    finite losses and gradients, reproducible losses, and the label path's invariants at full size — every foreground
+    row carries a thing label, the near targets are foreground rows of the right image, every mask target row exists."""
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+
+    torch.manual_seed(0)
+    model = build_model(jtsm_cfg("cuda"))
+    model.train()
+    model.roi_heads.box_head.dropout_p = 0.0
+    with torch.no_grad():
+        model.backbone.bottom_up.stem.conv1.weight.mul_(1.0 / 64)
+    inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=cuda, cluster=1.0, objects=40)
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        losses = model(inputs)
+        sum(losses.values()).backward()
+        runs.append(({k: float(v) for k, v in losses.items()},
+                     {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.requires_grad}))
+    (l0, g0), (l1, g1) = runs
+    assert all(np.isfinite(v) for v in l0.values()), l0
+    for k in l0:
+        assert abs(l0[k] - l1[k]) <= 1e-6 * max(abs(l0[k]), 1e-6), (k, l0[k], l1[k])
+    for n in g0:
+        assert bool(torch.isfinite(g0[n]).all()), n
+        if n.endswith("box_predictor.det.bias"):
+            continue
+        assert float((g0[n] - g1[n]).abs().max()) <= 1e-4 * (float(g0[n].abs().max()) + 1e-12), n
+    aux = model.roi_heads.aux
+    fg = aux["fg_rois"]
+    assert fg.shape[0] >= 100 and aux["mask_targets"].shape[0] == fg.shape[0]
+    assert bool(((aux["fg_classes"] >= 0) & (aux["fg_classes"] < 80)).all())
+    labels = aux["labels_r3"]
+    near = aux["near_rows"]                               # (B, G, 10) global rows, -1 = empty slot
+    cnt = aux["things_cnt"].cpu().tolist()
+    for b in range(2):
+        rows = near[b, :cnt[b]].reshape(-1)
+        rows = rows[rows >= 0].to(torch.int64)
+        assert rows.numel() > 0 and bool(((rows >= 2000 * b) & (rows < 2000 * (b + 1))).all())
+    sem = model.roi_heads.pgt_sem_seg
+    assert sem.shape == (2, 1024, 1024) and int(sem.max()) <= 53 and int(sem.min()) >= 0
+    assert labels.shape[0] == 4000
+
+
 def test_full_size_step_is_reproducible_and_finite(cuda):
     """BASELINE configs[2] at full size (2 x 1024^2, 2000 proposals per image): too big for the CPU oracle, so check
     what needs none — every loss finite, every trainable parameter gets a finite gradient, and a second run of the
