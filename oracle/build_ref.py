@@ -1,9 +1,12 @@
 """ORACLE — TEST INFRASTRUCTURE ONLY.
 
 Builds oracle/_ref/jtsm_ref_cpu.so from the reference's own CPU sources, compiled where
-they lie under /root/reference (never copied), plus oracle/ref_shim.cpp (ours).  Runs only
-in the build container: /root/reference does not exist on the GPU box, where the prebuilt
-.so (git-ignored, but shipped by gpurun) is used if present.
+they lie under /root/reference (never copied), plus oracle/ref_shim.cpp (ours).  Build-container
+only: the module pins the C restatement (tests/test_oracle_pooling.py) and generates the committed
+vectors (tests/golden/make_golden.py); those .npz files are the pin on the GPU box.  The built
+files are TRANSIENT — __graft_entry__.build() and the test session remove them again (clean()),
+so no compiled reference code travels to the GPU box, and load_prebuilt() refuses to load one
+where /root/reference is absent.
 
     python oracle/build_ref.py        # or: make -C oracle ref
 """
@@ -39,10 +42,20 @@ def build(verbose=False):
     )
 
 
+def clean():
+    """Remove every built file under oracle/_ref (the .so, its objects, the ninja files)."""
+    import shutil
+
+    shutil.rmtree(OUT, ignore_errors=True)
+
+
 def load_prebuilt():
-    """Import the already-built module from oracle/_ref (GPU box or later sessions)."""
+    """Import the already-built module from oracle/_ref — in the build container only."""
     import glob
     import importlib.util
+
+    if not os.path.isdir(REF):
+        return None
 
     import torch  # noqa: F401  (libtorch symbols must be loaded first)
 

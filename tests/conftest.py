@@ -26,13 +26,17 @@ def load_cases(fname):
 
 @pytest.fixture(scope="session")
 def reference_module():
-    """The reference's own CPU ROIAlign build (oracle/_ref), or None when not present."""
-    from oracle.build_ref import build, load_prebuilt
+    """The reference's own CPU ROIAlign / NMS sources compiled where they lie (oracle/build_ref.py) — in the build
+    container only; None on the GPU box, where the committed vectors under tests/golden/ are the pin.  The built
+    files are removed when the session ends: no compiled reference code stays in the tree (or travels with it)."""
+    from oracle.build_ref import build, clean, load_prebuilt
 
-    m = load_prebuilt()
-    if m is None and os.path.isdir("/root/reference"):
-        m = build()
-    return m
+    if not os.path.isdir("/root/reference"):
+        yield None
+        return
+    m = load_prebuilt() or build()
+    yield m
+    clean()
 
 
 @pytest.fixture(scope="session")
