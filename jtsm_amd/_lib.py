@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libjtsm_hip.so")
+LIB_PATH = os.environ.get("JTSM_HIP_LIB") or os.path.join(_HERE, "lib", "libjtsm_hip.so")   # (override: A/B sweeps)
 _lib = None
 
 NCHW, NHWC = 0, 1

@@ -19,7 +19,7 @@ OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libjtsm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc"]
+         "-fno-gpu-rdc"] + os.environ.get("JTSM_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale(target, deps):

@@ -52,4 +52,58 @@ __device__ __forceinline__ int compact256(bool flag, int* __restrict__ wave_coun
 }
 
 
+// Ordered compaction of a per-thread flag over the NW wavefronts of the workgroup: this thread's slot (if flagged) and
+// the total; two barriers.
+template <int NW>
+__device__ __forceinline__ int compact_wg(bool flag, int* __restrict__ wave_count, int& total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  __syncthreads();                       // previous readers of wave_count are done
+  if (lane == 0) wave_count[wv] = __popcll(bal);
+  __syncthreads();
+  int off = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) { const int n = wave_count[w]; if (w < wv) off += n; total += n; }
+  return off + __popcll(bal & ((1ull << lane) - 1ull));
+}
+
+// The launch plan, from the census (one workgroup of 1024): plan[0] = the census maximum (fallback test), plan[1] = the
+// number of work entries, plan[2 ...] = `fan` entries (tile * fan + k) for every tile whose census is at least
+// `heavy_min`, heaviest first (four load classes relative to the maximum, index order inside a class — the busy workgroups stride this list, so
+// the few tiles under a pile of proposals start first instead of ending the launch).
+static __global__ __launch_bounds__(1024) void tile_plan_kernel(const int* __restrict__ census, int total,
+                                                                int* __restrict__ plan, int heavy_min, int fan) {
+  __shared__ int wave_count[16];
+  __shared__ int part[16];
+  const int t = threadIdx.x;
+  int m = 0;
+  for (int i = t; i < total; i += 1024) m = max(m, census[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+  if ((t & 63) == 0) part[t >> 6] = m;
+  __syncthreads();
+  int mm = 0;
+  for (int w = 0; w < 16; ++w) mm = max(mm, part[w]);
+  if (t == 0) plan[0] = mm;
+  int filled = 0;
+  if (mm >= heavy_min) {   // (uniform)
+    // load classes relative to the heaviest tile: [max / 2, ..), [max / 8, max / 2), [max / 32, max / 8), [heavy_min, max / 32)
+    const long h = heavy_min, t0 = max(h, (long)mm / 2), t1 = max(h, (long)mm / 8), t2 = max(h, (long)mm / 32);
+    const long lo[4] = {t0, t1, t2, h}, hi[4] = {1L << 40, t0, t1, t2};
+    for (int cls = 0; cls < 4; ++cls)
+      for (int base = 0; base < total; base += 1024) {
+        const int i = base + t;
+        const long v = i < total ? census[i] : 0;
+        const bool take = v >= lo[cls] && v < hi[cls];
+        int cnt;
+        const int slot = compact_wg<16>(take, wave_count, cnt);
+        if (take)
+          for (int k = 0; k < fan; ++k) plan[2 + (filled + slot) * fan + k] = i * fan + k;
+        filled += cnt;
+      }
+  }
+  if (t == 0) plan[1] = filled * fan;
+}
+
+
 }  // namespace jtsm

@@ -147,7 +147,10 @@ __device__ __forceinline__ void moi_pool_wave(
     // The bin's cells in (h, w) order, FOUR at a time: their mask words are requested together, then the features
     // of those that hit, so a round trip to memory serves four cells instead of one (the walk is latency-bound:
     // mask word -> ballot -> feature row -> compare).  Comparison order = cell order (first maximum wins).
-    constexpr int kAhead = 4;
+#ifndef JTSM_MOI_AHEAD
+#define JTSM_MOI_AHEAD 4
+#endif
+    constexpr int kAhead = JTSM_MOI_AHEAD;
     const int bwid = q.we - q.ws, ncell = (q.he - q.hs) * bwid;
     // (the walk keeps its own (h, w) counters: the kernel is bound by instruction issue — rocprofv3 counted 850 vector
     // and 370 scalar instructions per wavefront for ~6 cells — and two integer divisions per cell were a large part)
@@ -236,9 +239,17 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_levels(
     float* __restrict__ out, int* __restrict__ argmax, int C, int M, int words, int PH, int PW,
     const int* __restrict__ roi_level, int nlevels) {
   const int nbins = PH * PW;
+  // Workgroups are dealt round-robin over the 8 XCDs (private L2s): give each XCD a CONTIGUOUS run of (roi, bin)
+  // pairs, so that the bins of a roi — which share a third of their cells — and neighbouring rois meet in one L2
+  // (dealt out pair by pair every XCD fetched every roi's cells: 1.86 GB of fabric traffic per launch for 0.6 GB of
+  // distinct bytes).  Speed only: any placement computes the same result.
+  const unsigned nblk = gridDim.x, per = (nblk + 7) / 8, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const unsigned q = nblk >> 3, r8 = nblk & 7;   // XCDs 0 .. r8-1 hold q + 1 workgroups, the rest q
+  const unsigned blk = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + idx;
+  (void)per;
   // (readfirstlane: the wavefront index is uniform, but the compiler cannot see that through threadIdx — with it
   // the roi / bin / address arithmetic below runs on the scalar unit instead of once per lane)
-  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const long wave = (long)blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (wave >= (long)M * nbins) return;
   const int n = (int)(wave / nbins), bin = (int)(wave - (long)n * nbins);
   const int l = roi_level[n];
@@ -277,13 +288,14 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_levels(
 // gradients into LDS — thread c owns channel c, so there are no atomics, the order is the roi / bin order (bitwise
 // reproducible), and every cell of the map is written exactly once (no zero fill, no read-modify-write in L2; the
 // scatter form above spends its time in L2 atomic line operations).
-constexpr int kTile = 8;
+constexpr int kTile = 8;      // tile of the census and of the per-tile gather (cells, both axes)
+constexpr int kTileY = 8;
+constexpr int kQuad = 4;      // the busy-tile gather splits a tile into 2 x 2 quadrants of 4 x 4 cells
 struct MoiTiles {
   int first[kMaxLevels + 1];   // first workgroup of each level
   int tiles_x[kMaxLevels], tiles_y[kMaxLevels];
 };
 
-constexpr int kPairCap = 1024;
 
 // rois of one (level, image), in index order: lists[(l * B + b) * M ...], counts[l * B + b].  One workgroup each.
 __global__ __launch_bounds__(256) void moi_roi_lists_kernel(const float* __restrict__ rois,
@@ -308,7 +320,12 @@ __global__ __launch_bounds__(256) void moi_roi_lists_kernel(const float* __restr
 // in ONE workgroup, so a tile under very many overlapping rois (proposals piled on one object) would take longer than
 // the whole scatter form.  The census lets the call fall back: above kCensusLimit pairs on one tile the gather only
 // clears the maps and the float-atomic scatter (whose cost does not depend on where the rois are) does the work.
-constexpr int kCensusLimit = 4000;   // ~0.1-0.15 us per pair for the gather; the scatter form takes ~1 ms in all
+constexpr int kCensusLimit = 64000;   // (estimated) rows on one tile above which the scatter form (~1 ms whatever the rois) takes the call
+// rows on one tile from which its four quadrants go to moi_pool_bwd_busy (overridable for sweeps)
+static int moi_heavy_min() {
+  static const int v = [] { const char* e = getenv("JTSM_MOI_HEAVY_MIN"); return e ? atoi(e) : 1024; }();
+  return v;
+}
 
 __global__ __launch_bounds__(256) void moi_tile_census_kernel(const MoiLevels lv, const MoiTiles tl,
                                                               const float* __restrict__ rois,
@@ -323,8 +340,8 @@ __global__ __launch_bounds__(256) void moi_tile_census_kernel(const MoiLevels lv
   const int xa = max(r.x0, 0), xz = min(r.x1, W - 1), ya = max(r.y0, 0), yz = min(r.y1, H - 1);
   if (xa > xz || ya > yz) return;
   const float bw = (float)max(r.x1 - r.x0 + 1, 1) / (float)PW, bh = (float)max(r.y1 - r.y0 + 1, 1) / (float)PH;
-  for (int ty = ya / kTile; ty <= yz / kTile; ++ty) {
-    const int oy = min(yz, ty * kTile + kTile - 1) - max(ya, ty * kTile) + 1;      // overlapped rows
+  for (int ty = ya / kTileY; ty <= yz / kTileY; ++ty) {
+    const int oy = min(yz, ty * kTileY + kTileY - 1) - max(ya, ty * kTileY) + 1;   // overlapped rows
     const int by = min(PH, (int)((float)oy / bh) + 2);                            // bins touching them (upper bound)
     for (int tx = xa / kTile; tx <= xz / kTile; ++tx) {
       const int ox = min(xz, tx * kTile + kTile - 1) - max(xa, tx * kTile) + 1;
@@ -334,21 +351,30 @@ __global__ __launch_bounds__(256) void moi_tile_census_kernel(const MoiLevels lv
   }
 }
 
-__global__ __launch_bounds__(256) void moi_census_max_kernel(const int* __restrict__ census, int total,
-                                                             int* __restrict__ out) {
-  __shared__ int part[4];
-  int m = 0;
-  for (int i = threadIdx.x; i < total; i += 256) m = max(m, census[i]);
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) *out = max(max(part[0], part[1]), max(part[2], part[3]));
-}
+// Gather form, round 3.  What round 2's profile showed (rocprofv3 counters on the bench's proposals): the launch
+// averaged 2 resident wavefronts per CU — it was one long tail.  Proposals pile up on objects, small rois put all 49
+// bins of every piled roi on the same few cells, and a tile was ONE workgroup whose 256 threads (thread = channel)
+// added its ~2500 rows one dependent LDS read-modify-write after the other.  Now: (1) the maps are cleared by a memset
+// and only the tiles some box overlaps get a workgroup (the plan above), heaviest first, through a fixed grid that
+// strides the list; (2) a tile is 4 x 4 cells and its workgroup has 16 wavefronts: thread = (channel, copy), FOUR
+// copies of the tile in LDS, the row list dealt to the copies in batches of 16 rows, each copy's additions in list
+// order, the copies added in a fixed order at the end — still no atomics, still reproducible bit for bit; (3) a
+// batch's loads are in flight while the previous batch is applied.  (LDS float atomics — ds_add_f32, fire and forget —
+// were measured for the additions: 2-3x SLOWER than the plain read-modify-write.)
+constexpr int kPairCap = 1024;
 
+// Gather form of the backward: a workgroup owns an 8 x 8-cell tile of one level's gradient map (x 256 channels, 64 KB
+// of LDS), finds the (roi, bin) pairs whose bin range touches the tile from the roi geometry alone, and adds their
+// gradients into LDS — thread c owns channel c, so there are no atomics, the order is the roi / bin order (bitwise
+// reproducible), and every cell of the map is written exactly once (no zero fill, no read-modify-write in L2; the
+// scatter form above spends its time in L2 atomic line operations).  Tiles no box overlaps (census 0: most of a call)
+// write their zeros at once, 16 bytes per lane; tiles at or above `heavy_min` (estimated) rows are left to
+// moi_pool_bwd_busy below.
 __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
     const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
-    const int* __restrict__ counts, int nlevels, const int* __restrict__ census_max) {
+    const int* __restrict__ counts, int nlevels, const int* __restrict__ plan, const int* __restrict__ census,
+    int heavy_min) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 cells][256 channels]
   __shared__ int roi_list[256];
@@ -367,39 +393,59 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   const int c = blockIdx.y * 256 + t;
   const float scale = lv.scale[l];
   const int nbins = PH * PW;
-  if (*census_max > kCensusLimit) {   // too many rois on one tile somewhere: clear the map for the scatter form
-    float* __restrict__ z = lv.gin[l] + (size_t)b * H * W * C;
-    for (int y = y0; y <= y1; ++y)
-      for (int x = x0; x <= x1; ++x) z[((size_t)y * W + x) * C + c] = 0.f;
+  float* __restrict__ out = lv.gin[l] + (size_t)b * H * W * C;
+  const int load = census[blockIdx.x];
+  const bool fallback = plan[0] > kCensusLimit;   // too many rois on one tile somewhere: the scatter form adds into zeros
+  if (load == 0 || fallback) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = t; i < kTile * kTile * 64; i += 256) {
+      const int cell = i >> 6, y = y0 + cell / kTile, x = x0 + cell % kTile;
+      if (y <= y1 && x <= x1)
+        *reinterpret_cast<float4*>(out + ((size_t)y * W + x) * C + blockIdx.y * 256 + (i & 63) * 4) = z;
+    }
     return;
   }
+  if (load >= heavy_min) return;   // moi_pool_bwd_busy writes this tile
   for (int i = t; i < kTile * kTile * 64; i += 256) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   int np = 0;   // uniform
 
-  // a / W by multiply-high (exact for a * W < 2^32: a is a cell index of one map): the drain runs it once per
-  // (pair, channel) and is bound by instruction issue, not by its loads (rocprofv3: 60 M vector instructions per launch
-  // against 3 M loads; an integer division is ~25 of them)
+  // a / W by multiply-high (exact for a * W < 2^32: a is a cell index of one map; the host sends larger maps to the
+  // scatter form): the drain runs it once per (row, channel)
   const unsigned magicW = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);
-  const bool magic_ok = (unsigned long long)H * W * W < 0xFFFFFFFFull;   // (maps beyond ~1600 x 1600 cells divide plainly)
   const unsigned magic_bins = (unsigned)((0x100000000ull + (unsigned)nbins - 1) / (unsigned)nbins);   // k < 256 * nbins
   const unsigned magic_pw = (unsigned)((0x100000000ull + (unsigned)PW - 1) / (unsigned)PW);
   constexpr int kDepth = 16;
-  auto drain = [&]() {   // add the listed rows' gradients into the tile: kDepth rows' loads in flight per thread
+  float* __restrict__ mine_acc = acc + t;
+  const unsigned rows_in = (unsigned)(y1 - y0 + 1), cols_in = (unsigned)(x1 - x0 + 1);
+  auto fetch = [&](int j, int (&a)[kDepth], float (&g)[kDepth]) {   // rows j .. j + kDepth - 1 of the list
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) {
+      const size_t row = (size_t)pair_list[min(j + u, np - 1)];
+      a[u] = j + u < np ? argmax[row * C + c] : -1;
+      g[u] = j + u < np ? grad[row * C + c] : 0.f;
+    }
+  };
+  auto apply = [&](const int (&a)[kDepth], const float (&g)[kDepth]) {
+#pragma unroll
+    for (int u = 0; u < kDepth; ++u) {
+      const unsigned ay = __umulhi((unsigned)a[u], magicW), ax = (unsigned)a[u] - ay * (unsigned)W;
+      const unsigned ry = ay - (unsigned)y0, rx = ax - (unsigned)x0;
+      if ((a[u] >= 0) & (ry < rows_in) & (rx < cols_in)) mine_acc[(int)(ry * kTile + rx) * 256] += g[u];
+    }
+  };
+  // add the listed rows' gradients into the tile, in list order; two batches of kDepth rows alternate, the loads of one
+  // in flight while the other is applied
+  auto drain = [&]() {
     __syncthreads();
-    for (int j = 0; j < np; j += kDepth) {
-      int a[kDepth];
-      float g[kDepth];
-#pragma unroll
-      for (int u = 0; u < kDepth; ++u) {
-        const size_t row = (size_t)pair_list[min(j + u, np - 1)];
-        a[u] = j + u < np ? argmax[row * C + c] : -1;
-        g[u] = j + u < np ? grad[row * C + c] : 0.f;
-      }
-#pragma unroll
-      for (int u = 0; u < kDepth; ++u) {
-        if (a[u] < 0) continue;
-        const int ay = magic_ok ? (int)__umulhi((unsigned)a[u], magicW) : a[u] / W, ax = a[u] - ay * W;
-        if (ay >= y0 && ay <= y1 && ax >= x0 && ax <= x1) acc[((ay - y0) * kTile + (ax - x0)) * 256 + t] += g[u];
+    int a0[kDepth], a1[kDepth];
+    float g0[kDepth], g1[kDepth];
+    if (np > 0) fetch(0, a0, g0);
+    for (int j = 0; j < np; j += 2 * kDepth) {
+      if (j + kDepth < np) fetch(j + kDepth, a1, g1);
+      apply(a0, g0);
+      if (j + kDepth < np) {
+        if (j + 2 * kDepth < np) fetch(j + 2 * kDepth, a0, g0);
+        apply(a1, g1);
       }
     }
     np = 0;
@@ -411,15 +457,16 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     // ---- rois of this level / image whose box touches the tile, in index order
     const int n = base + t < nmine ? mine[base + t] : -1;
     bool hit = false;
+    IBox r = {};
     if (n >= 0) {
-      const IBox r = round_box(rois + (size_t)n * 5, scale);
+      r = round_box(rois + (size_t)n * 5, scale);
       hit = r.x0 <= x1 && r.x1 >= x0 && r.y0 <= y1 && r.y1 >= y0;
     }
     int nroi;
     const int slot = compact256(hit, wave_count, nroi);
     if (hit) {
       roi_list[slot] = n;
-      roi_box[slot] = round_box(rois + (size_t)n * 5, scale);
+      roi_box[slot] = r;
     }
     __syncthreads();
     // ---- their bins whose cell range touches the tile, in (roi, bin) order
@@ -431,9 +478,9 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
       int row = 0;
       if (k < ncombo) {
         const int i = (int)__umulhi((unsigned)k, magic_bins), bin = k - i * nbins, m = roi_list[i];
-        const IBox r = roi_box[i];
+        const IBox rb = roi_box[i];
         const int ph = (int)__umulhi((unsigned)bin, magic_pw);
-        const BinRange q = bin_range(r, ph, bin - ph * PW, PH, PW, H, W);
+        const BinRange q = bin_range(rb, ph, bin - ph * PW, PH, PW, H, W);
         bh = q.he > q.hs && q.we > q.ws && q.hs <= y1 && q.he > y0 && q.ws <= x1 && q.we > x0;
         row = m * nbins + bin;
       }
@@ -445,10 +492,148 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     __syncthreads();   // roi_list is rewritten by the next chunk
   }
   drain();
-  float* __restrict__ out = lv.gin[l] + (size_t)b * H * W * C;
+  __syncthreads();
   for (int y = y0; y <= y1; ++y)
     for (int x = x0; x <= x1; ++x)
       out[((size_t)y * W + x) * C + c] = acc[((y - y0) * kTile + (x - x0)) * 256 + t];
+}
+
+constexpr int kCopies = 4;
+constexpr int kPairCapBusy = 2048;
+
+__global__ __launch_bounds__(1024) void moi_pool_bwd_busy(
+    const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
+    const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
+    const int* __restrict__ counts, int nlevels, const int* __restrict__ plan) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float acc[];   // [kCopies][kQuad * kQuad cells][256 channels]
+  __shared__ int roi_list[256];
+  __shared__ IBox roi_box[256];            // their rounded boxes (rounded once per roi, not once per (roi, bin))
+  __shared__ int pair_list[kPairCapBusy];  // (roi * nbins + bin) rows whose bin range touches the tile, in order
+  __shared__ int wave_count[16];
+  if (plan[0] > kCensusLimit) return;      // piled-up rois beyond what one workgroup should walk: the scatter form
+  const int nbusy = plan[1];
+  const int t = threadIdx.x, ch = t & 255, copy = t >> 8;
+  constexpr int kCells = kQuad * kQuad;
+  const int nbins = PH * PW;
+  const unsigned magic_bins = (unsigned)((0x100000000ull + (unsigned)nbins - 1) / (unsigned)nbins);   // k < 256 * nbins
+  const unsigned magic_pw = (unsigned)((0x100000000ull + (unsigned)PW - 1) / (unsigned)PW);
+  float* __restrict__ mine_acc = acc + copy * kCells * 256 + ch;
+  constexpr int kDepth = 16;
+
+  for (int job = blockIdx.x; job < nbusy; job += gridDim.x) {
+    const int entry = plan[2 + job], tile = entry >> 2, quad = entry & 3;   // (tile of the census grid, its quadrant)
+    int l = 0;
+    while (l + 1 < nlevels && tile >= tl.first[l + 1]) ++l;
+    const int H = lv.H[l], W = lv.W[l];
+    int rel = tile - tl.first[l];
+    const int tx = rel % tl.tiles_x[l]; rel /= tl.tiles_x[l];
+    const int ty = rel % tl.tiles_y[l];
+    const int b = rel / tl.tiles_y[l];
+    const int x0 = tx * kTile + (quad & 1) * kQuad, y0 = ty * kTileY + (quad >> 1) * kQuad;
+    if (x0 >= W || y0 >= H) continue;        // (a quadrant beyond the map's edge; uniform)
+    const int x1 = min(x0 + kQuad, W) - 1, y1 = min(y0 + kQuad, H) - 1;
+    const float scale = lv.scale[l];
+    float* __restrict__ out = lv.gin[l] + (size_t)b * H * W * C;
+    // a / W by multiply-high (exact for a * W < 2^32: a is a cell index of one map; the host sends larger maps to the
+    // scatter form): the drain runs it once per (row, channel)
+    const unsigned magicW = (unsigned)((0x100000000ull + (unsigned)W - 1) / (unsigned)W);
+    const unsigned rows_in = (unsigned)(y1 - y0 + 1), cols_in = (unsigned)(x1 - x0 + 1);
+
+    for (int cb = 0; cb < C; cb += 256) {   // (256-channel blocks: one on the JTSM path)
+      const int c = cb + ch;
+      __syncthreads();                       // the previous job's / block's readers of acc and the lists are done
+      for (int i = t; i < kCopies * kCells * 64; i += 1024) reinterpret_cast<float4*>(acc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      int np = 0;   // uniform
+
+      auto fetch = [&](int j, int (&a)[kDepth], float (&g)[kDepth]) {   // rows j .. j + kDepth - 1 of the list
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+          const size_t row = (size_t)pair_list[min(j + u, np - 1)];
+          a[u] = j + u < np ? argmax[row * C + c] : -1;
+          g[u] = j + u < np ? grad[row * C + c] : 0.f;
+        }
+      };
+      auto apply = [&](const int (&a)[kDepth], const float (&g)[kDepth]) {
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+          const unsigned ay = __umulhi((unsigned)a[u], magicW), ax = (unsigned)a[u] - ay * (unsigned)W;
+          const unsigned ry = ay - (unsigned)y0, rx = ax - (unsigned)x0;
+          if ((a[u] >= 0) & (ry < rows_in) & (rx < cols_in)) mine_acc[(int)(ry * kQuad + rx) * 256] += g[u];
+        }
+      };
+      // copy k takes the batches k, k + 4, ... of kDepth rows; two batches alternate, one's loads in flight while the
+      // other is applied
+      auto drain = [&]() {
+        __syncthreads();
+        int a0[kDepth], a1[kDepth];
+        float g0[kDepth], g1[kDepth];
+        constexpr int kStep = kCopies * kDepth;
+        const int j0 = copy * kDepth;
+        if (j0 < np) fetch(j0, a0, g0);
+        for (int j = j0; j < np; j += 2 * kStep) {
+          if (j + kStep < np) fetch(j + kStep, a1, g1);
+          apply(a0, g0);
+          if (j + kStep < np) {
+            if (j + 2 * kStep < np) fetch(j + 2 * kStep, a0, g0);
+            apply(a1, g1);
+          }
+        }
+        np = 0;
+        __syncthreads();                     // pair_list is rewritten next
+      };
+
+      const int* __restrict__ mine = lists + (size_t)(l * B + b) * M;
+      const int nmine = counts[l * B + b];
+      for (int base = 0; base < nmine; base += 256) {
+        // ---- rois of this level / image whose box touches the tile, in index order
+        const int n = (t < 256 && base + t < nmine) ? mine[base + t] : -1;
+        bool hit = false;
+        IBox r = {};
+        if (n >= 0) {
+          r = round_box(rois + (size_t)n * 5, scale);
+          hit = r.x0 <= x1 && r.x1 >= x0 && r.y0 <= y1 && r.y1 >= y0;
+        }
+        int nroi;
+        const int slot = compact_wg<16>(hit, wave_count, nroi);
+        if (hit) {
+          roi_list[slot] = n;
+          roi_box[slot] = r;
+        }
+        __syncthreads();
+        // ---- their bins whose cell range touches the tile, in (roi, bin) order
+        const int ncombo = nroi * nbins;
+        for (int k0 = 0; k0 < ncombo; k0 += 1024) {
+          if (np > kPairCapBusy - 1024) drain();
+          const int k = k0 + t;
+          bool bh = false;
+          int row = 0;
+          if (k < ncombo) {
+            const int i = (int)__umulhi((unsigned)k, magic_bins), bin = k - i * nbins, m = roi_list[i];
+            const IBox rb = roi_box[i];
+            const int ph = (int)__umulhi((unsigned)bin, magic_pw);
+            const BinRange q = bin_range(rb, ph, bin - ph * PW, PH, PW, H, W);
+            bh = q.he > q.hs && q.we > q.ws && q.hs <= y1 && q.he > y0 && q.ws <= x1 && q.we > x0;
+            row = m * nbins + bin;
+          }
+          int cnt;
+          const int ps = compact_wg<16>(bh, wave_count, cnt);
+          if (bh) pair_list[np + ps] = row;
+          np += cnt;
+        }
+        __syncthreads();   // roi_list is rewritten by the next chunk
+      }
+      drain();
+      // the four copies, added in a fixed order; whole 1 KiB rows
+      for (int i = t; i < kCells * 256; i += 1024) {
+        const int cell = i >> 8, cc = i & 255;
+        const int y = y0 + cell / kQuad, x = x0 + cell % kQuad;
+        if (y > y1 || x > x1) continue;
+        const float* a = acc + cell * 256 + cc;
+        out[((size_t)y * W + x) * C + cb + cc] = (a[0] + a[kCells * 256]) + (a[2 * kCells * 256] + a[3 * kCells * 256]);
+      }
+    }
+  }
 }
 
 // NCHW (reference layout): one thread per output element; cell test done per thread.
@@ -736,14 +921,14 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
 
 static long census_tiles(const int* H, const int* W, int nlevels, int B) {
   long n = 0;
-  for (int l = 0; l < nlevels; ++l) n += (long)B * ceil_div(W[l], kTile) * ceil_div(H[l], kTile);
+  for (int l = 0; l < nlevels; ++l) n += (long)B * ceil_div(W[l], kTile) * ceil_div(H[l], kTileY);
   return n;
 }
 
 size_t jtsm_moi_pool_backward_levels_workspace_bytes(const int* H, const int* W, int nlevels, int B, int M) {
   if (nlevels <= 0 || nlevels > kMaxLevels || B <= 0 || M <= 0 || !H || !W) return 0;
-  // per-(level, image) roi lists + counts, then the tile census + its maximum
-  return (((size_t)nlevels * B * ((size_t)M + 1) + (size_t)census_tiles(H, W, nlevels, B) + 4) * sizeof(int) + 15) &
+  // per-(level, image) roi lists + counts, then the tile census and the launch plan (maximum, count, busy tiles)
+  return (((size_t)nlevels * B * ((size_t)M + 1) + 5 * (size_t)census_tiles(H, W, nlevels, B) + 8) * sizeof(int) + 15) &
          ~(size_t)15;
 }
 
@@ -763,7 +948,9 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
     all = all && grad_inputs[l] != nullptr;
   }
   // gather form: needs the level scales (bin geometry), 256-channel blocks, bins that fit one wavefront
-  const bool tiled = scales && workspace && all && C % 256 == 0 && M > 0 && B > 0;
+  bool small_maps = true;   // argmax -> (y, x) by multiply-high needs cell * W < 2^32
+  for (int l = 0; l < nlevels; ++l) small_maps = small_maps && (unsigned long long)H[l] * W[l] * W[l] < 0xFFFFFFFFull;
+  const bool tiled = scales && workspace && all && small_maps && C % 256 == 0 && M > 0 && B > 0;
   if (tiled) {
     JTSM_REQUIRE(grad && rois && roi_level && argmax, "moi_pool levels backward: null pointer");
     const size_t need = jtsm_moi_pool_backward_levels_workspace_bytes(H, W, nlevels, B, M);
@@ -773,27 +960,29 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
     int* counts = lists + (size_t)nlevels * B * M;
     int* census = counts + (size_t)nlevels * B;
     const int ntile = (int)census_tiles(H, W, nlevels, B);
-    int* census_max = census + ntile;
+    int* plan = census + ntile;            // [0] census maximum, [1] number of busy tiles, [2 ...] their indices
     hipLaunchKernelGGL(moi_roi_lists_kernel, dim3(nlevels * B), dim3(256), 0, st, rois, roi_level, M, B, lists, counts);
     MoiTiles tl = {};
     int blocks = 0;
     for (int l = 0; l < nlevels; ++l) {
       tl.first[l] = blocks;
       tl.tiles_x[l] = ceil_div(W[l], kTile);
-      tl.tiles_y[l] = ceil_div(H[l], kTile);
+      tl.tiles_y[l] = ceil_div(H[l], kTileY);
       blocks += B * tl.tiles_x[l] * tl.tiles_y[l];
     }
     tl.first[nlevels] = blocks;
-    JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
+    JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)ntile * sizeof(int), st));
     hipLaunchKernelGGL(moi_tile_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, lv, tl, rois, roi_level, M, nlevels,
                        pooled_h, pooled_w, census);
-    hipLaunchKernelGGL(moi_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census_max);
+    // the plan: the census maximum and the heavy tiles (4 quadrant entries each), heaviest first
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, st, census, ntile, plan, moi_heavy_min(), 4);
     hipLaunchKernelGGL(moi_pool_bwd_tiled, dim3(blocks, C / 256), dim3(256), kTile * kTile * 256 * sizeof(float), st, lv, tl,
-                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, census_max);
+                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, census, moi_heavy_min());
+    hipLaunchKernelGGL(moi_pool_bwd_busy, dim3(256), dim3(1024), (size_t)kCopies * kQuad * kQuad * 256 * sizeof(float), st,
+                       lv, tl, grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan);
     // (returns at once unless the census sent the gather home)
     hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(std::min(ceil_div((long)M * pooled_h * pooled_w, 4), 8192)), dim3(256), 0,
-                       st, lv, grad, rois, argmax, C, M, pooled_h * pooled_w, roi_level, nlevels, census_max,
-                       kCensusLimit);
+                       st, lv, grad, rois, argmax, C, M, pooled_h * pooled_w, roi_level, nlevels, plan, kCensusLimit);
     JTSM_CHECK_LAUNCH("moi_pool backward levels (tiled)");
     return JTSM_OK;
   }

@@ -199,12 +199,13 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
 // atomics, reproducible bit for bit, every map cell written exactly once (no zero fill).  2-5x faster than the scatter
 // form above on spread-out rois; a tile under a pile of rois is walked by one workgroup, so a census of the boxes
 // (estimated bins per tile) sends such calls to the scatter form instead (as csrc/moi_pool.hip does).
-constexpr int kTile = 8, kPairCap = 1024;
+constexpr int kTile = 8;
 // (estimated) bins on one tile above which the scatter form takes the call; overridable for sweeps
 static int census_limit() {
-  static const int v = [] { const char* e = getenv("JTSM_ALIGN_CENSUS_LIMIT"); return e ? atoi(e) : 20000; }();
+  static const int v = [] { const char* e = getenv("JTSM_ALIGN_CENSUS_LIMIT"); return e ? atoi(e) : 200000; }();
   return v;
 }
+
 
 // The maps of the call: one level (jtsm_roi_align_backward_level_f32 / the plain entry) or all FPN levels at once
 // (jtsm_roi_align_backward_levels_f32) — tiles of every level are workgroups of ONE launch, so the levels' critical
@@ -257,69 +258,50 @@ __global__ __launch_bounds__(256) void align_census_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void align_census_max_kernel(const int* __restrict__ census, int total,
-                                                               int* __restrict__ out) {
-  __shared__ int part[4];
-  int m = 0;
-  for (int i = threadIdx.x; i < total; i += 256) m = max(m, census[i]);
-  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) *out = max(max(part[0], part[1]), max(part[2], part[3]));
-}
-
-constexpr int kSub = 64;        // listed rois whose tile weights are staged in LDS at a time
+constexpr int kSub = 32;        // listed rois whose tile weights are staged in LDS at a time
 constexpr int kMaxBins = 16;    // PH, PW <= 16 (7 and 14 on the JTSM path); wider poolers use the scatter form
+constexpr int kSubsets = 4;     // wavefronts that share a channel block's work items (register copies, added at the end)
 
-__global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__ grad, const float* __restrict__ rois,
-                                                       const AlignLevels lv, int C, int M, int PH, int PW, int sr,
-                                                       int aligned, const int* __restrict__ roi_level,
-                                                       const int* __restrict__ census_max, int census_lim,
-                                                       const int4* __restrict__ reach_in, const int* __restrict__ meta_in) {
+// Gather form of the backward, round 3.  A fixed grid of workgroups (4 wavefronts each) strides the plan's list of
+// (tile, 64-channel block) jobs — every 8 x 8-cell tile some roi can reach, heaviest first (tile_plan_kernel); the maps
+// are cleared by a memset beforehand, so tiles no roi reaches (most of a call) cost nothing but that.
+// Wavefront w of a job takes the work items w, w + 4, ... (lane = channel): the rois that can reach the tile are listed
+// (256 at a time); for 32 of them at a time the threads compute, one (roi, axis, bin) each, the bilinear weights of
+// every bin that reaches the tile on the tile's lines into LDS (the sample loops run once per workgroup), and the
+// staged rois' reaching bin ROWS become one flat list of work items.  An item's contribution g * wy[r] * wx[q] is
+// applied as v[q] = sum_pw g wx_pw[q], acc[r][q] += wy_ph[r] v[q] — weights from LDS as broadcast reads, the NEXT
+// item's gradients (whichever roi it belongs to) already in flight.  The four register copies are added in a fixed order
+// through LDS at the end, (a0 + a1) + (a2 + a3): no atomics, reproducible bit for bit, every cell of a listed tile
+// written exactly once.
+//
+// What round 2's profile showed (rocprofv3 counters on the bench's ~300 foreground rois, 6 piles of ~50): the launch
+// averaged 3.6 resident wavefronts per CU.  It was (a) ~100 us of floor — 10 880 workgroups of 215 registers and 64 KiB
+// of LDS, almost all of them there to find no roi and write zeros — and (b) a tail: a tile under a pile was ONE
+// workgroup walking roi after roi, 2-3 dependent load round trips each.  Measured and NOT kept: a 16-wavefront form for
+// the tiles under piles (4 x 4-cell quadrants x 256 channels, items over four wavefronts per channel block): the same
+// time as this form on the piled workload — its per-job listing and staging cost what the wider walk saved.
+template <int TILE, int NBLK>
+__global__ __launch_bounds__(256 * NBLK) void align_bwd_gather(
+    const float* __restrict__ grad, const float* __restrict__ rois, const AlignLevels lv, int C, int M, int PH, int PW,
+    int sr, int aligned, const int* __restrict__ plan, int census_lim, int fan, const int4* __restrict__ reach_in,
+    const int* __restrict__ meta_in) {
 #pragma clang fp contract(off)
-  int lvl = 0;
-  while (lvl + 1 < lv.n && (int)blockIdx.x >= lv.first_tile[lvl + 1]) ++lvl;
-  float* __restrict__ gin = lv.gin[lvl];
-  const int H = lv.H[lvl], W = lv.W[lvl], tiles_x = lv.tiles_x[lvl], tiles_y = lv.tiles_y[lvl];
-  const int level = lv.level_id[lvl];
-  const float scale = lv.scale[lvl];
-  // One workgroup per (8 x 8-cell tile, 64 channels): lane = channel, and each of the four wavefronts keeps its own
-  // copy of the tile's 64 cells in REGISTERS.  The rois that can reach the tile are listed (256 at a time); for 64 of
-  // them at a time the 256 threads compute, one (roi, axis, bin) each, the bilinear weights of every bin that reaches
-  // the tile on the tile's eight lines (the sample loops run once per workgroup, spread over the lanes) into LDS.  The
-  // wavefronts then share the staged rois round-robin: a bin's contribution g * wy[r] * wx[q] is applied as
-  // v[q] = sum_pw g wx_pw[q], acc[r][q] += wy_ph[r] v[q], weights coming from LDS as broadcast reads, the gradients
-  // of the next bin row already in flight.  The four copies are added in a fixed order at the end: no atomics,
-  // reproducible bit for bit, every map cell written exactly once (no zero fill).
   __shared__ int roi_list[256];
   __shared__ float roi_row[256][5];
-  __shared__ int wave_count[4];
-  __shared__ __attribute__((aligned(16))) float pool[kSub * 2 * kMaxBins * kTile];   // 64 KiB: weights, then the 4 copies
-  float (*wts)[2][kMaxBins][kTile] = reinterpret_cast<float (*)[2][kMaxBins][kTile]>(pool);   // [roi][axis y|x][slot][line]
+  constexpr int NW = 4 * NBLK, NT = 256 * NBLK, NCH = 64 * NBLK;
+  __shared__ int wave_count[NW];
+  __shared__ __attribute__((aligned(16))) float wts[kSub][2][kMaxBins][TILE];     // [roi][axis y|x][slot][line]
+  __shared__ __attribute__((aligned(16))) float copies[2][TILE * TILE][NCH];       // 32 KiB: two slots of the final sums
   __shared__ int first_bin[kSub][2], nbin[kSub][2];
   __shared__ float inv_cnt[kSub];
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  int rel = blockIdx.x - lv.first_tile[lvl];
-  const int tx = rel % tiles_x; rel /= tiles_x;
-  const int ty = rel % tiles_y;
-  const int b = rel / tiles_y;
-  const int x0 = tx * kTile, y0 = ty * kTile, x1 = min(x0 + kTile, W) - 1, y1 = min(y0 + kTile, H) - 1;
-  const int c = blockIdx.y * 64 + lane;
+  __shared__ unsigned char row_lo[kSub][kMaxBins], row_hi[kSub][kMaxBins];   // tile lines with a non-zero y weight
+  __shared__ int item_base[kSub + 1];
+  __shared__ unsigned short items[kSub * kMaxBins];                         // roi slot << 8 | bin-row slot
+  if (plan[0] > census_lim) return;   // piled-up rois beyond what one workgroup should walk: the scatter form
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cblk = wv % NBLK, subset = wv / NBLK;
   const int nbins = PH * PW;
-  float* __restrict__ out = gin + (size_t)b * H * W * C;
-  if (*census_max > census_lim) {   // piled-up rois somewhere: clear the map, the scatter form does the work
-    for (int cell = wv; cell < kTile * kTile; cell += 4) {
-      const int y = y0 + cell / kTile, x = x0 + cell % kTile;
-      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
-    }
-    return;
-  }
-  float acc[kTile][kTile];
-#pragma unroll
-  for (int r = 0; r < kTile; ++r)
-#pragma unroll
-    for (int q = 0; q < kTile; ++q) acc[r][q] = 0.f;
-  bool touched = false;   // block-uniform: did any roi reach this tile?
+  const int njobs = plan[1];
 
   // cells a sample coordinate range [lo, hi] can touch: floor(lo) .. floor(hi) + 1, after the clamp to the map
   auto reach = [](float lo, float hi, int n, int& a, int& z) {
@@ -327,136 +309,192 @@ __global__ __launch_bounds__(256) void align_bwd_tiled(const float* __restrict__
     z = min((int)floorf(hi) + 1, n - 1);
   };
 
-  for (int base = 0; base < M; base += 256) {
-    const int n = base + t;
-    bool hit = false;
-    if (n < M && meta_in[n] == (b | (lvl << 16))) {   // this level, this image, a box with samples (census kernel)
-      const int4 rc = reach_in[n];                     // (ya, yz, xa, xz)
-      hit = rc.x <= y1 && rc.y >= y0 && rc.z <= x1 && rc.w >= x0;
-    }
-    int nroi;
-    const int slot = compact256(hit, wave_count, nroi);
-    if (hit) {
-      roi_list[slot] = n;
+  for (int job = blockIdx.x; job < njobs; job += gridDim.x) {
+    const int entry = plan[2 + job], tile = entry / fan, group = entry - tile * fan;   // (tile, channel group)
+    int lvl = 0;
+    while (lvl + 1 < lv.n && tile >= lv.first_tile[lvl + 1]) ++lvl;
+    const int H = lv.H[lvl], W = lv.W[lvl], tiles_x = lv.tiles_x[lvl], tiles_y = lv.tiles_y[lvl];
+    const float scale = lv.scale[lvl];
+    int rel = tile - lv.first_tile[lvl];
+    const int tx = rel % tiles_x; rel /= tiles_x;
+    const int ty = rel % tiles_y;
+    const int b = rel / tiles_y;
+    const int x0 = tx * TILE, y0 = ty * TILE, x1 = min(x0 + TILE, W) - 1, y1 = min(y0 + TILE, H) - 1;
+    float* __restrict__ out = lv.gin[lvl] + (size_t)b * H * W * C;
+    {
+      const int cb0 = group * NCH;
+      const int nblk = min(NBLK, (C - cb0) >> 6);   // channel blocks present: wavefronts beyond them only keep step
+      const bool serving = cblk < nblk;
+      const int c = cb0 + cblk * 64 + lane;
+      float acc[TILE][TILE];
 #pragma unroll
-      for (int q = 0; q < 5; ++q) roi_row[slot][q] = rois[(size_t)n * 5 + q];
-    }
-    __syncthreads();
-    touched = touched || nroi > 0;
-    for (int sub = 0; sub < nroi; sub += kSub) {
-      const int ns = min(kSub, nroi - sub);
-      // ---- stage: bins of each axis that reach the tile, and their weights on the tile's eight lines
-      if (t < ns * 2) {   // one thread per (roi, axis): the contiguous range of reaching bins
-        const int i = t >> 1, axis = t & 1;
-        const RoiGeom<float> g = geom_box<float>(roi_row[sub + i], scale, PH, PW, sr, aligned != 0);
-        const float origin = axis ? g.x0 : g.y0, bin = axis ? g.bw : g.bh;
-        const int P = axis ? PW : PH, n_lines = axis ? W : H, t0 = axis ? x0 : y0, t1 = axis ? x1 : y1;
-        int lo = max(0, (int)floorf(((float)t0 - 1.f - origin) / fmaxf(bin, 1e-6f)) - 1);
-        int hi = min(P - 1, (int)floorf(((float)t1 + 1.f - origin) / fmaxf(bin, 1e-6f)) + 1);
-        auto reaches = [&](int p) {
-          int a, z;
-          reach(origin + (float)p * bin, origin + (float)(p + 1) * bin, n_lines, a, z);
-          return a <= t1 && z >= t0;
-        };
-        while (lo <= hi && !reaches(lo)) ++lo;
-        while (hi >= lo && !reaches(hi)) --hi;
-        first_bin[i][axis] = lo;
-        nbin[i][axis] = max(hi - lo + 1, 0);
-        if (axis == 0) inv_cnt[i] = 1.f / (float)(g.gh * g.gw);
-      }
-      __syncthreads();
-      for (int task = t; task < ns * 2 * kMaxBins; task += 256) {   // one (roi, axis, bin slot) per thread
-        const int i = task / (2 * kMaxBins), axis = (task / kMaxBins) & 1, sl = task % kMaxBins;
-        if (sl >= nbin[i][axis]) continue;
-        const RoiGeom<float> g = geom_box<float>(roi_row[sub + i], scale, PH, PW, sr, aligned != 0);
-        const float origin = axis ? g.x0 : g.y0, bin = axis ? g.bw : g.bh;
-        const int grid = axis ? g.gw : g.gh, n_lines = axis ? W : H, t0 = axis ? x0 : y0;
-        const int p = first_bin[i][axis] + sl;
-        float w[kTile];
+      for (int r = 0; r < TILE; ++r)
 #pragma unroll
-        for (int r = 0; r < kTile; ++r) w[r] = 0.f;
-        for (int k = 0; k < grid; ++k) {
-          float y = origin + (float)p * bin + (float)((float)k + .5f) * bin / (float)grid;
-          if (y < -1.0f || y > (float)n_lines) continue;
-          if (y <= 0.f) y = 0.f;
-          int yl = (int)y, yh;
-          if (yl >= n_lines - 1) { yh = yl = n_lines - 1; y = (float)yl; } else { yh = yl + 1; }
-          const float ly = y - (float)yl, hy = 1.f - ly;
-#pragma unroll
-          for (int r = 0; r < kTile; ++r) w[r] += (yl == t0 + r ? hy : 0.f) + (yh == t0 + r ? ly : 0.f);
+        for (int q = 0; q < TILE; ++q) acc[r][q] = 0.f;
+
+      for (int base = 0; base < M; base += 256) {
+        const int n = base + t;
+        bool hit = false;
+        if (t < 256 && n < M && meta_in[n] == (b | (lvl << 16))) {   // this level, this image, a box with samples
+          const int4 rc = reach_in[n];                               // (ya, yz, xa, xz)
+          hit = rc.x <= y1 && rc.y >= y0 && rc.z <= x1 && rc.w >= x0;
         }
+        int nroi;
+        const int slot = compact_wg<NW>(hit, wave_count, nroi);
+        if (hit) {
+          roi_list[slot] = n;
 #pragma unroll
-        for (int r = 0; r < kTile; ++r) wts[i][axis][sl][r] = w[r];
-      }
-      __syncthreads();
-      // ---- walk: EVERY wavefront visits every staged roi and takes its bin rows wv, wv + 4, ... (the four register
-      // copies are added at the end, so any split of the work is exact).  Splitting the rows rather than the rois
-      // keeps all four wavefronts busy on a tile that one or two rois reach — the common case away from piles, where
-      // one wavefront used to walk a roi's ~12 rows (a dependent load each) while three idled.
-      {
-        for (int i = 0; i < ns; ++i) {
-          const int npw = nbin[i][1], nph = nbin[i][0];
-          if (npw == 0 || nph <= wv) continue;
-          const int pw0 = first_bin[i][1], ph0 = first_bin[i][0];
-          const float inv = inv_cnt[i];
-          const float* __restrict__ gro = grad + ((size_t)roi_list[sub + i] * nbins + (size_t)ph0 * PW + pw0) * C + c;
-          float gk[kMaxBins], gnext[kMaxBins];
+          for (int q = 0; q < 5; ++q) roi_row[slot][q] = rois[(size_t)n * 5 + q];
+        }
+        __syncthreads();
+        for (int sub = 0; sub < nroi; sub += kSub) {
+          const int ns = min(kSub, nroi - sub);
+          // ---- stage: bins of each axis that reach the tile, and their weights on the tile's lines
+          if (t < ns * 2) {   // one thread per (roi, axis): the contiguous range of reaching bins
+            const int i = t >> 1, axis = t & 1;
+            const RoiGeom<float> g = geom_box<float>(roi_row[sub + i], scale, PH, PW, sr, aligned != 0);
+            const float origin = axis ? g.x0 : g.y0, bin = axis ? g.bw : g.bh;
+            const int P = axis ? PW : PH, n_lines = axis ? W : H, t0 = axis ? x0 : y0, t1 = axis ? x1 : y1;
+            int lo = max(0, (int)floorf(((float)t0 - 1.f - origin) / fmaxf(bin, 1e-6f)) - 1);
+            int hi = min(P - 1, (int)floorf(((float)t1 + 1.f - origin) / fmaxf(bin, 1e-6f)) + 1);
+            auto reaches = [&](int p) {
+              int a, z;
+              reach(origin + (float)p * bin, origin + (float)(p + 1) * bin, n_lines, a, z);
+              return a <= t1 && z >= t0;
+            };
+            while (lo <= hi && !reaches(lo)) ++lo;
+            while (hi >= lo && !reaches(hi)) --hi;
+            first_bin[i][axis] = lo;
+            nbin[i][axis] = max(hi - lo + 1, 0);
+            if (axis == 0) inv_cnt[i] = 1.f / (float)(g.gh * g.gw);
+          }
+          __syncthreads();
+          for (int task = t; task < ns * 2 * kMaxBins; task += NT) {   // one (roi, axis, bin slot) per thread
+            const int i = task / (2 * kMaxBins), axis = (task / kMaxBins) & 1, sl = task % kMaxBins;
+            if (sl >= nbin[i][axis]) continue;
+            const RoiGeom<float> g = geom_box<float>(roi_row[sub + i], scale, PH, PW, sr, aligned != 0);
+            const float origin = axis ? g.x0 : g.y0, bin = axis ? g.bw : g.bh;
+            const int grid = axis ? g.gw : g.gh, n_lines = axis ? W : H, t0 = axis ? x0 : y0;
+            const int p = first_bin[i][axis] + sl;
+            float w[TILE];
+#pragma unroll
+            for (int r = 0; r < TILE; ++r) w[r] = 0.f;
+            for (int k = 0; k < grid; ++k) {
+              float y = origin + (float)p * bin + (float)((float)k + .5f) * bin / (float)grid;
+              if (y < -1.0f || y > (float)n_lines) continue;
+              if (y <= 0.f) y = 0.f;
+              int yl = (int)y, yh;
+              if (yl >= n_lines - 1) { yh = yl = n_lines - 1; y = (float)yl; } else { yh = yl + 1; }
+              const float ly = y - (float)yl, hy = 1.f - ly;
+#pragma unroll
+              for (int r = 0; r < TILE; ++r) w[r] += (yl == t0 + r ? hy : 0.f) + (yh == t0 + r ? ly : 0.f);
+            }
+            int lo = TILE, hi = -1;
+#pragma unroll
+            for (int r = 0; r < TILE; ++r) {
+              wts[i][axis][sl][r] = w[r];
+              if (w[r] != 0.f) { lo = min(lo, r); hi = r; }
+            }
+            if (axis == 0) { row_lo[i][sl] = (unsigned char)lo; row_hi[i][sl] = (unsigned char)(hi + 1); }   // [lo, hi)
+          }
+          // ---- the staged rois' reaching bin rows as one item list, in (roi, row) order
+          if (t < 64) {   // (first wavefront: an exclusive scan of the rois' row counts)
+            const int cnt = (t < ns && nbin[t][1] > 0) ? nbin[t][0] : 0;
+            int inc = cnt;
+#pragma unroll
+            for (int o = 1; o < kSub; o <<= 1) {
+              const int up = __shfl_up(inc, o);
+              if (t >= o) inc += up;
+            }
+            if (t < ns) item_base[t] = inc - cnt;
+            if (t == ns - 1) item_base[ns] = inc;
+          }
+          __syncthreads();
+          for (int task = t; task < ns * kMaxBins; task += NT) {
+            const int i = task / kMaxBins, a = task % kMaxBins;
+            if (nbin[i][1] > 0 && a < nbin[i][0]) items[item_base[i] + a] = (unsigned short)(i << 8 | a);
+          }
+          __syncthreads();
+          // ---- walk: this wavefront takes items subset, subset + 4, ... for its channel block; the next item's
+          // gradient row is requested before this one is applied
           {
-            const float* __restrict__ grow = gro + (size_t)wv * PW * C;
+            const int nitems = serving ? item_base[ns] : 0;
+            float gk[kMaxBins], gnext[kMaxBins];
+            auto request = [&](int j, float (&g)[kMaxBins]) {
+              const int it = __builtin_amdgcn_readfirstlane((int)items[j]);
+              const int i = it >> 8, a = it & 255;
+              const int npw = __builtin_amdgcn_readfirstlane(nbin[i][1]);
+              const int ph0 = __builtin_amdgcn_readfirstlane(first_bin[i][0]), pw0 = __builtin_amdgcn_readfirstlane(first_bin[i][1]);
+              const int m = __builtin_amdgcn_readfirstlane(roi_list[sub + i]);
+              const float* __restrict__ grow = grad + ((size_t)m * nbins + (size_t)(ph0 + a) * PW + pw0) * C + c;
 #pragma unroll
-            for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? grow[(size_t)k * C] : 0.f;
+              for (int k = 0; k < kMaxBins; ++k) g[k] = k < npw ? grow[(size_t)k * C] : 0.f;
+            };
+            if (subset < nitems) request(subset, gnext);
+            for (int j = subset; j < nitems; j += kSubsets) {
+#pragma unroll
+              for (int k = 0; k < kMaxBins; ++k) gk[k] = gnext[k];
+              if (j + kSubsets < nitems) request(j + kSubsets, gnext);
+              const int it = __builtin_amdgcn_readfirstlane((int)items[j]);
+              const int i = it >> 8, a = it & 255;
+              const int npw = __builtin_amdgcn_readfirstlane(nbin[i][1]);
+              const float inv = inv_cnt[i];
+              float v[TILE];
+#pragma unroll
+              for (int q = 0; q < TILE; ++q) v[q] = 0.f;
+#pragma unroll
+              for (int k = 0; k < kMaxBins; ++k) {
+                if (k >= npw) break;
+                const float gs = gk[k] * inv;
+#pragma unroll
+                for (int q = 0; q < TILE; ++q) v[q] += gs * wts[i][1][k][q];
+              }
+              const int rlo = __builtin_amdgcn_readfirstlane((int)row_lo[i][a]), rhi = __builtin_amdgcn_readfirstlane((int)row_hi[i][a]);
+#pragma unroll
+              for (int r = 0; r < TILE; ++r) {
+                if (r < rlo || r >= rhi) continue;      // (scalar test: lines this bin row has no weight on)
+                const float wy = wts[i][0][a][r];
+#pragma unroll
+                for (int q = 0; q < TILE; ++q) acc[r][q] += wy * v[q];
+              }
+            }
           }
-          for (int a = wv; a < nph; a += 4) {
-#pragma unroll
-            for (int k = 0; k < kMaxBins; ++k) gk[k] = gnext[k];
-            if (a + 4 < nph) {   // this wavefront's next bin row is on its way while this one is applied
-              const float* __restrict__ grow = gro + (size_t)(a + 4) * PW * C;
-#pragma unroll
-              for (int k = 0; k < kMaxBins; ++k) gnext[k] = k < npw ? grow[(size_t)k * C] : 0.f;
-            }
-            float v[kTile];
-#pragma unroll
-            for (int q = 0; q < kTile; ++q) v[q] = 0.f;
-#pragma unroll
-            for (int k = 0; k < kMaxBins; ++k) {
-              if (k >= npw) break;
-              const float gs = gk[k] * inv;
-#pragma unroll
-              for (int q = 0; q < kTile; ++q) v[q] += gs * wts[i][1][k][q];
-            }
-#pragma unroll
-            for (int r = 0; r < kTile; ++r) {
-              const float wy = wts[i][0][a][r];
-              if (wy == 0.f) continue;
-#pragma unroll
-              for (int q = 0; q < kTile; ++q) acc[r][q] += wy * v[q];
-            }
-          }
+          __syncthreads();                  // before the next batch overwrites the staged weights
         }
+        __syncthreads();                    // before the next chunk overwrites roi_list / roi_row
       }
-      __syncthreads();                  // before the next batch overwrites the staged weights
-    }
-    __syncthreads();                    // before the next chunk overwrites roi_list / roi_row
-  }
-  if (!touched) {   // most tiles of a call: no roi reaches them — zeros straight from registers, no LDS round trip
-    for (int cell = wv; cell < kTile * kTile; cell += 4) {
-      const int y = y0 + cell / kTile, x = x0 + cell % kTile;
-      if (y <= y1 && x <= x1) out[((size_t)y * W + x) * C + c] = 0.f;
-    }
-    return;
-  }
-  // the four wavefronts' copies -> LDS (the weight pool is free now), added in a fixed order
-  constexpr int SLAB = kTile * kTile * 64;
+      // the four register copies of every channel block, added in a fixed order through LDS: (a0 + a1) + (a2 + a3)
+      auto put = [&](int slot) {
 #pragma unroll
-  for (int r = 0; r < kTile; ++r)
+        for (int r = 0; r < TILE; ++r)
 #pragma unroll
-    for (int q = 0; q < kTile; ++q) pool[wv * SLAB + (r * kTile + q) * 64 + lane] = acc[r][q];
-  __syncthreads();
-  for (int cell = wv; cell < kTile * kTile; cell += 4) {
-    const int y = y0 + cell / kTile, x = x0 + cell % kTile;
-    if (y > y1 || x > x1) continue;
-    const int o = cell * 64 + lane;
-    out[((size_t)y * W + x) * C + c] = ((pool[o] + pool[SLAB + o]) + pool[2 * SLAB + o]) + pool[3 * SLAB + o];
+          for (int q = 0; q < TILE; ++q) copies[slot][r * TILE + q][cblk * 64 + lane] = acc[r][q];
+      };
+      auto take = [&](int slot) {
+#pragma unroll
+        for (int r = 0; r < TILE; ++r)
+#pragma unroll
+          for (int q = 0; q < TILE; ++q) acc[r][q] += copies[slot][r * TILE + q][cblk * 64 + lane];
+      };
+      if (subset == 1) put(0);
+      if (subset == 3) put(1);
+      __syncthreads();
+      if (subset == 0) take(0);
+      if (subset == 2) take(1);
+      __syncthreads();
+      if (subset == 2) put(0);
+      __syncthreads();
+      if (subset == 0) { take(0); put(1); }
+      __syncthreads();
+      for (int i = t; i < TILE * TILE * (NCH / 4); i += NT) {   // whole rows, 16 bytes per lane
+        const int cell = i / (NCH / 4), cc = (i % (NCH / 4)) * 4;
+        const int y = y0 + cell / TILE, x = x0 + cell % TILE;
+        if (y > y1 || x > x1 || cc >= nblk * 64) continue;
+        const float* src = &copies[1][cell][cc];
+        *reinterpret_cast<float4*>(out + ((size_t)y * W + x) * C + cb0 + cc) = make_float4(src[0], src[1], src[2], src[3]);
+      }
+      __syncthreads();                      // the copies are rewritten by the next job
+    }
   }
 }
 
@@ -592,28 +630,35 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
     ntile += B * lv.tiles_x[l] * lv.tiles_y[l];
   }
   lv.first_tile[lv.n] = ntile;
+  // every map cleared first: the gather writes only the tiles some roi can reach, the scatter form adds into zeros
+  for (int l = 0; l < lv.n; ++l)
+    JTSM_CHECK_HIP(hipMemsetAsync(lv.gin[l], 0, (size_t)B * lv.H[l] * lv.W[l] * C * sizeof(float), st));
   int* census = nullptr;
-  const size_t head = ((size_t)(ntile + 1) * sizeof(int) + 15) & ~(size_t)15;      // census + its maximum, then per roi:
+  // census, then the launch plan (maximum, number of jobs, C / 64 (tile, channel block) jobs per reachable tile), then
+  // per roi: reach + meta
+  const int fan = C / 64;
+  const size_t head = ((size_t)ntile * (1 + fan) * sizeof(int) + 4 * sizeof(int) + 15) & ~(size_t)15;
   JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), head + (size_t)M * (sizeof(int4) + sizeof(int)), st));
-  JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)(ntile + 1) * sizeof(int), st));
+  JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)ntile * sizeof(int), st));
+  int* plan = census + ntile;
   int4* reach = reinterpret_cast<int4*>(reinterpret_cast<char*>(census) + head);   // cell reach (16-byte aligned)
   int* meta = reinterpret_cast<int*>(reach + M);                                    // image | level entry << 16
   hipLaunchKernelGGL(align_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, rois, M, PH, PW, sr, aligned,
                      roi_level, lv, census, reach, meta);
-  hipLaunchKernelGGL(align_census_max_kernel, dim3(1), dim3(256), 0, st, census, ntile, census + ntile);
-  hipLaunchKernelGGL(align_bwd_tiled, dim3(ntile, C / 64), dim3(256), 0, st, grad, rois, lv, C, M, PH, PW, sr, aligned,
-                     roi_level, census + ntile, census_limit(), reach, meta);
+  hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, st, census, ntile, plan, 1, fan);
+  hipLaunchKernelGGL((align_bwd_gather<8, 1>), dim3(std::min(ntile * fan, 512)), dim3(256), 0, st, grad, rois, lv, C, M, PH,
+                     PW, sr, aligned, plan, census_limit(), fan, reach, meta);
   constexpr int V = WideVec<float>::value;
   const int blocks = ceil_div((long)M * PH * PW, 4);
   for (int l = 0; l < lv.n; ++l) {   // the scatter form, level by level (each returns at once unless the census says so)
     if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
       hipLaunchKernelGGL((align_bwd_nhwc<float, V, false>), dim3(blocks), dim3(256), 0, st, grad, rois, lv.gin[l], C,
                          lv.H[l], lv.W[l], M, lv.scale[l], PH, PW, sr, aligned, roi_level, lv.level_id[l],
-                         census + ntile, census_limit());
+                         plan, census_limit());
     else
       hipLaunchKernelGGL((align_bwd_nhwc<float, 1, false>), dim3(blocks), dim3(256), 0, st, grad, rois, lv.gin[l], C,
                          lv.H[l], lv.W[l], M, lv.scale[l], PH, PW, sr, aligned, roi_level, lv.level_id[l],
-                         census + ntile, census_limit());
+                         plan, census_limit());
   }
   JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
   JTSM_CHECK_HIP(hipFreeAsync(census, st));
