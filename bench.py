@@ -127,6 +127,10 @@ def config4_leg(device, args):
             last = step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        roof = roof_detail = None
+        if not args.no_roofline:   # dominant kernel of THIS leg against the fp16 MFMA roof (2.5 PFLOP/s dense)
+            roof, roof_detail = roofline_leg(step)
+            roof.pop("contractions", None)
         out = {"value": round(args.batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
                "dtype": "f16", "steps": steps, "final_loss": round(float(last.detach()), 5),
                "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
@@ -134,6 +138,9 @@ def config4_leg(device, args):
                            "superpixels per image, fp16 MFMA path (fp16 operand planes, fp32 accumulate / losses / "
                            "master weights, gradient planes x 2^%d)" % (args.batch, args.proposals, 32 * 64,
                                                                        conv_layers.GRAD_SHIFT)}
+        if roof is not None:
+            out["roofline"] = roof
+            out["roofline_detail"] = roof_detail
         del model, opt, inputs
         torch.cuda.empty_cache()
         return out
@@ -454,7 +461,7 @@ def main():
         del net, opt, model, inputs
         torch.cuda.empty_cache()
         c4 = config4_leg(device, args)
-        detail["config4_fp16"] = c4
+        detail["config4_fp16"] = dict(c4)
         out["config4_fp16"] = {k: c4[k] for k in ("value", "unit", "ms_per_step", "dtype", "steps",
                                                   "foreground_rois_last_step") if k in c4}
         if "roofline" in c4:

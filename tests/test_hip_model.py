@@ -138,7 +138,17 @@ def test_gradients_match(step):
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
 
 
-@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+# The fp16 leg (BASELINE configs[4]): operands round at 2^-11 = 4.9e-4 where split-bf16 rounds at ~4e-6, and the MIL
+# gradient amplifies relative errors by ~1e2 (the bf16x3 step's 5.6e-4 ... 7.5e-4 is that amplification of ~6e-6 per layer).
+# Stated end-to-end gradient tolerance of the fp16 arithmetic with the discrete choices frozen (max-norm relative to
+# each tensor's largest entry); measured: 3.2e-2 (det.weight), 1.5e-2 (fc2); the test prints the worst three.
+FP16_GRAD_TOL = 5e-2
+# fp16 operands round at 2^-11 (4.9e-4) relative; through ~105 convolutions and the heads the losses come out within a
+# few 1e-3 of the fp32 oracle's.  Stated tolerance of the fp16 leg: 2e-2 relative per loss.
+FP16_LOSS_TOL = 2e-2
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3", "f16"])
 def test_whole_step_gradients_at_1e4_with_frozen_discrete_choices(cuda, math):
     """End-to-end gradients at the 1e-4 bar, in both arithmetics.  test_gradients_match has to accept ~1e-2 because a
     ReLU gate or a max-pool winner that sits within rounding of a tie falls on different sides in two correct
@@ -183,9 +193,10 @@ def test_whole_step_gradients_at_1e4_with_frozen_discrete_choices(cuda, math):
             params[n].requires_grad_(True)
         losses0 = OM.forward_losses(params, batch, forced=forced)
         sum(losses0.values()).backward()
+        loss_tol = FP16_LOSS_TOL if math == "f16" else 1e-4
         for k in sorted(losses0):
             a, b = float(losses[k].detach()), float(losses0[k])
-            assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
+            assert abs(a - b) <= loss_tol * max(abs(b), 1e-6) + 1e-7, (k, a, b)
         got = dict(model.named_parameters())
         worst = {}
         for n in names:
@@ -195,13 +206,16 @@ def test_whole_step_gradients_at_1e4_with_frozen_discrete_choices(cuda, math):
             if n.endswith("box_head.fc1.weight"):
                 g = model.roi_heads.box_head._hwc_cols(g, False)
             worst[n] = _rel(g, g0)
+        top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+        print("frozen-choices gradient errors (%s), worst three:" % math, [(k, "%.2e" % v) for k, v in top])
         # det.weight: the detection-stream gradient of every class column sums to zero over the bag (softmax over
         # proposals), so its entries are differences of nearly equal terms — measured 1.3e-4, bar 5e-4 for it alone
         # The split-bf16 contractions are ~20x less exact per layer than fp32 MFMA (6e-6 against 3e-7, both far inside the
         # 1e-4 bar per LAYER, tests/test_hip_conv.py); the MIL gradient is ill-conditioned (amplification ~1e2: the same
-        # effect puts fp32's det.weight at 1.3e-4), so the END-TO-END gradients of the bf16x3 step agree to 5.6e-4
-        # (measured; the DAN and predictor layers, which sit right behind the MIL loss) — bar 1e-3 for that arithmetic.
-        lim = 1e-4 if math == "f32" else 1e-3
+        # effect puts fp32's det.weight at 1.3e-4), so the END-TO-END gradients of the bf16x3 step agree to 5.6e-4 ... 7.5e-4
+        # (measured in rounds 2 / 3; the DAN and predictor layers, which sit right behind the MIL loss) — bar 1e-3 for that
+        # arithmetic; fp16: 3.2e-2 on det.weight, 1.5e-2 on the DAN (measured) — bar FP16_GRAD_TOL.
+        lim = {"f32": 1e-4, "bf16x3": 1e-3, "f16": FP16_GRAD_TOL}[math]
         bad = {k: v for k, v in worst.items() if v > (max(lim, 5e-4) if k.endswith("box_predictor.det.weight") else lim)}
         assert not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:8]
     finally:
@@ -470,10 +484,6 @@ def test_r101_rectangular_losses_match(cuda):
         assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6) + 1e-7, (k, a, b)
     assert float(losses0["loss_mask"]) > 0                # the case has foreground rois
 
-
-# fp16 operands round at 2^-11 (4.9e-4) relative; through ~105 convolutions and the heads the losses of this case
-# come out within a few 1e-3 of the fp32 oracle's.  Stated tolerance of the fp16 leg: 2e-2 relative per loss.
-FP16_LOSS_TOL = 2e-2
 
 
 def test_r101_rectangular_fp16_losses_within_stated_tolerance(cuda):

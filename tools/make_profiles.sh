@@ -10,8 +10,9 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 A=gpurun_out/art
 mkdir -p $A
 FAST="--no-cpu-baseline --no-roofline --no-exact --no-config4"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_fetch.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_write.log 2>&1 &&
+PMCF="--no-cpu-baseline --no-roofline --no-exact"   # (with the configs[4] fp16 leg: its kernels' traffic rows)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $PMCF > $A/pmc_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $PMCF > $A/pmc_write.log 2>&1 &&
 python tools/pmc_traffic.py $A/pmc profiles/pmc_traffic.json && cp profiles/pmc_traffic.json $A/pmc_traffic.json &&
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $A/pmc/mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_mfma.log 2>&1 &&
 (cd tools && python pmc_mfma.py ../$A/pmc/mfma ../profiles/pmc_mfma.json) && cp profiles/pmc_mfma.json $A/pmc_mfma.json &&

@@ -22,7 +22,7 @@ ROLE = {"0": "FWD", "1": "DGRAD", "2": "WGRAD"}
 # non-contraction kernels that bench.py reports under their C-ABI entry point (the entry's dominant kernel)
 ENTRY = (("splitk_finish<4", "splitk_finish<4>"),   # <4, 1> and <4, 16> (threads per piece) book as one
          ("moi_pool_fwd_levels", "jtsm_moi_pool_forward_levels_f32"),
-         ("moi_pool_bwd_tiled", "jtsm_moi_pool_backward_levels_f32"), ("align_bwd_tiled", "jtsm_roi_align_backward_levels_f32"),
+         ("moi_pool_bwd_tiled", "jtsm_moi_pool_backward_levels_f32"), ("align_bwd_gather", "jtsm_roi_align_backward_levels_f32"),
          ("relu_bwd_split_kernel", "jtsm_relu_backward_split_f32"), ("channel_sum4_kernel", "jtsm_channel_sum_ws_f32"),
          ("split_bf16_kernel", "jtsm_split_bf16_f32"), ("sgd_multi_kernel", "jtsm_sgd_momentum_multi_f32"),
          ("ce_up_bwd_kernel", "jtsm_semseg_ce_backward_f32"),
@@ -99,7 +99,7 @@ def main():
                     "is fabric-side traffic, an upper bound on HBM bytes",
         }
     json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --steps 2 --warmup 1 "
-                          "--no-cpu-baseline --no-roofline --no-exact --no-config4", "kernels": kernels}, open(out, "w"), indent=1)
+                          "--no-cpu-baseline --no-roofline --no-exact (the configs[4] fp16 leg included: its kernels carry the \",1\" labels)", "kernels": kernels}, open(out, "w"), indent=1)
     print("wrote", out, len(kernels), "kernels")
 
 
