@@ -440,6 +440,24 @@ int jtsm_conv2d_backward_weight_bias_bf16x3(const uint16_t* dy_hi, const uint16_
 int jtsm_conv2d_backward_weight_bias_f16(const uint16_t* dy_h, const uint16_t* x_h, float* dw, float* db,
                                          const jtsm_conv_shape* s, const float* row_scale, int zero_dw, int grad_shift,
                                          void* workspace, size_t workspace_bytes, void* stream);
+/* Up to 8 weight gradients of ONE shape in a single launch (+ one finishing launch): member i is
+ * dw[i] = row_scale[i][out] * sum_pixels dy_i (x) x_i (fresh results; row_scale may be NULL, or hold NULL members).
+ * For the layers a network repeats (the bottleneck blocks of a ResNet stage: same ATen convolution_backward, weight
+ * output only, as jtsm_conv2d_backward_weight_bf16x3): the K (pixel) axis of the whole group is cut into as many slices
+ * as ONE launch needs to fill the chip — a sixth of the slabs six separate launches write and fold.  Deterministic (slabs
+ * folded in slice order); results are bit-identical for a given (shape, n), not to the single-layer entry (different
+ * slicing).  Workspace: jtsm_conv_bf16x3_wgrad_group_workspace_bytes(s, n); jtsm_conv_bf16x3_wgrad_group_splits reports
+ * the slice count (0: bad arguments). */
+size_t jtsm_conv_bf16x3_wgrad_group_workspace_bytes(const jtsm_conv_shape* s, int n);
+int jtsm_conv_bf16x3_wgrad_group_splits(const jtsm_conv_shape* s, int n);
+int jtsm_conv2d_backward_weight_group_bf16x3(int n, const uint16_t* const* dy_hi, const uint16_t* const* dy_lo,
+                                             const uint16_t* const* x_hi, const uint16_t* const* x_lo,
+                                             float* const* dw, const float* const* row_scale,
+                                             const jtsm_conv_shape* s, void* workspace, size_t workspace_bytes,
+                                             void* stream);
+int jtsm_conv2d_backward_weight_group_f16(int n, const uint16_t* const* dy_h, const uint16_t* const* x_h,
+                                          float* const* dw, const float* const* row_scale, const jtsm_conv_shape* s,
+                                          int grad_shift, void* workspace, size_t workspace_bytes, void* stream);
 /* g = dy where y > 0 else 0 (fp32), and g's fp16 plane times 2^shift (n % 8 == 0) in the same pass. */
 int jtsm_relu_backward_split_f16(const float* dy, const float* y, float* g, uint16_t* g_h, long n, int shift,
                                  void* stream);

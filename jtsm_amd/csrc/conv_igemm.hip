@@ -1199,7 +1199,7 @@ __global__ __launch_bounds__(256) void splitk_finish_shared(const Params p, int 
 
 // G == 1: one thread per output piece; the epilogue's operands and up to four slices' loads travel together.
 template <int VEC, int G = 1>
-__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
+__device__ __forceinline__ void splitk_finish_body(const Params& p, int splits, int scale_by_row) {
   if (p.bias_out) {   // the weight gradient's bias partials: 32 lanes per output channel, a fixed reduction tree
     const int r = threadIdx.x >> 5, l = threadIdx.x & 31;
     for (int mb = blockIdx.x; mb * 8 < p.M; mb += gridDim.x) {
@@ -1342,6 +1342,11 @@ __global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits,
   }
 }
 
+template <int VEC, int G = 1>
+__global__ __launch_bounds__(256) void splitk_finish(const Params p, int splits, int scale_by_row) {
+  splitk_finish_body<VEC, G>(p, splits, scale_by_row);
+}
+
 // How many K slices for an (ntiles, ktiles) problem: aim at >= 3 workgroups per CU, keep >= 4 K tiles
 // (128 k) per slice, at most 16 slices.
 inline int plan_splits(int ntiles, int ktiles, int target = 768) {
@@ -1455,6 +1460,18 @@ int launch_split(Params& p, void* workspace, size_t workspace_bytes, hipStream_t
 }
 
 #include "conv_x3.h"
+
+// The finishing pass of a GROUP of same-shape weight gradients (conv_x3.h: X3Group): blockIdx.y = member.
+template <int VEC>
+__global__ __launch_bounds__(256) void splitk_finish_group(const Params p_in, int splits, const X3Group G) {
+  Params p = p_in;
+  const int z = blockIdx.y;
+  p.C = G.C[z];
+  p.e.scale = G.scale[z];
+  p.slab += (size_t)z * G.slab_stride;
+  splitk_finish_body<VEC, 1>(p, splits, 1);
+}
+
 
 template <int ROLE, int BM, int BN>
 int launch(const Params& p, int splits, hipStream_t st) {
@@ -1956,7 +1973,133 @@ static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, cons
   return JTSM_OK;
 }
 
+// K slices of a GROUP of n same-shape weight gradients: the single launch's rule with n times the tiles — one resident
+// round of workgroups over the whole group.
+static int x3_wgrad_group_splits(const Params& p, int n) {
+  if (x3_wgrad_halo(p)) {
+    const int ntiles = ceil_div(p.M, 128) * (p.s.Cin / 32) * n, segs = p.K / 32;
+    int splits = ntiles >= 512 ? 1 : 512 / ntiles;
+    if (splits > segs / 8) splits = segs / 8;   // at least 8 segments per workgroup
+    if (splits > 64) splits = 64;
+    if (splits < 1) splits = 1;
+    return ceil_div(segs, ceil_div(segs, splits));
+  }
+  const bool big = x3_wgrad_big(p);
+  const int t = big ? 256 : 128;
+  const int ntiles = ceil_div(p.N, t) * ceil_div(p.M, t) * n;
+  const int ktiles = ceil_div(p.K, XBK);
+  int splits = max(1, (big ? 256 : 512) / ntiles);
+  const int min_stages = big ? 16 : 8;
+  if (splits > ceil_div(ktiles, min_stages)) splits = ceil_div(ktiles, min_stages);
+  if (splits > 64) splits = 64;
+  if (splits < 1) splits = 1;
+  const int kps = ceil_div(ktiles, splits);
+  return kps > 0 ? ceil_div(ktiles, kps) : 1;
+}
+
+static int group_shape(const jtsm_conv_shape* s, Params& p) {
+  int rc = check_shape(s);
+  if (rc) return rc;
+  p.s = to_shape(s);
+  JTSM_REQUIRE(p.s.Ho > 0 && p.s.Wo > 0, "conv: kernel larger than padded input");
+  JTSM_REQUIRE(x3_eligible(WGRAD, p.s), "conv backward-weight group: in_c=%d and out_c=%d must be multiples of 8",
+               p.s.Cin, p.s.Cout);
+  p.M = p.s.Cout;
+  p.N = p.s.KH * p.s.KW * p.s.Cin;
+  p.K = p.s.Bn * p.s.Ho * p.s.Wo;
+  return JTSM_OK;
+}
+
+template <int NP>
+static int x3_backward_weight_group(int n, const uint16_t* const* dy_hi, const uint16_t* const* dy_lo,
+                                    const uint16_t* const* x_hi, const uint16_t* const* x_lo, float* const* dw,
+                                    const float* const* row_scale, const jtsm_conv_shape* s, int grad_shift,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(n >= 1 && n <= kMaxGroup && dy_hi && x_hi && dw && (NP == 1 || (dy_lo && x_lo)),
+               "conv backward-weight group: 1..%d members and non-null tables", kMaxGroup);
+  Params p = {};
+  int rc = group_shape(s, p);
+  if (rc) return rc;
+  JTSM_REQUIRE(p.K > 0, "conv backward-weight group: empty batch (use the single-layer entry)");
+  JTSM_REQUIRE(grad_shift >= 0 && grad_shift <= 24, "conv backward-weight group: grad_shift must be in 0..24");
+  hipStream_t st = as_stream(stream);
+  p.in_shift = grad_shift;
+  p.ldc = p.N;
+  p.wide = 1;
+  X3Group G = {};
+  G.n = n;
+  for (int i = 0; i < n; ++i) {
+    JTSM_REQUIRE(dy_hi[i] && x_hi[i] && dw[i] && (NP == 1 || (dy_lo[i] && x_lo[i])), "conv backward-weight group: null member %d", i);
+    JTSM_REQUIRE(aligned16(dy_hi[i]) && aligned16(x_hi[i]) && aligned16(dw[i]) && (NP == 1 || (aligned16(dy_lo[i]) && aligned16(x_lo[i]))),
+                 "conv backward-weight group: member %d is not 16-byte aligned", i);
+    G.A_hi[i] = reinterpret_cast<const __bf16*>(dy_hi[i]);
+    G.A_lo[i] = NP == 1 ? nullptr : reinterpret_cast<const __bf16*>(dy_lo[i]);
+    G.B_hi[i] = reinterpret_cast<const __bf16*>(x_hi[i]);
+    G.B_lo[i] = NP == 1 ? nullptr : reinterpret_cast<const __bf16*>(x_lo[i]);
+    G.C[i] = dw[i];
+    G.scale[i] = row_scale ? row_scale[i] : nullptr;
+  }
+  const int splits = x3_wgrad_group_splits(p, n);
+  G.slab_stride = (size_t)splits * p.M * p.N;
+  const size_t need = splits > 1 ? (size_t)n * G.slab_stride * sizeof(float) : 0;
+  JTSM_REQUIRE(splits <= 1 || (workspace && workspace_bytes >= need && aligned16(workspace)),
+               "conv backward-weight group: workspace of %zu bytes needed (jtsm_conv_bf16x3_wgrad_group_workspace_bytes)", need);
+  p.ktiles_per_split = ceil_div(ceil_div(p.K, XBK), splits);
+  p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
+  p.tickets = nullptr;
+  const bool big = x3_wgrad_big(p);
+  const int tl = big ? 256 : 128;
+  const int ntiles = ceil_div(p.N, tl) * ceil_div(p.M, tl);
+  if (x3_wgrad_halo(p)) {
+    const int halo_tiles = ceil_div(p.M, 128) * (p.s.Cin / 32);
+    hipLaunchKernelGGL((igemm_x3_wgrad_halo_group_kernel<NP>), dim3(halo_tiles, splits, n), dim3(256), 0, st, p, G);
+  } else if (big) {
+    hipLaunchKernelGGL((igemm_x3_wgrad_group_kernel<4, 2, 2, 4, 2, NP>), dim3(ntiles, splits, n), dim3(512), 0, st, p, G);
+  } else {
+    hipLaunchKernelGGL((igemm_x3_wgrad_group_kernel<2, 2, 2, 2, 2, NP>), dim3(ntiles, splits, n), dim3(256), 0, st, p, G);
+  }
+  JTSM_CHECK_LAUNCH("igemm bf16x3 wgrad group");
+  record_mid(st);
+  if (splits > 1) {
+    const long total = (long)p.M * (p.N / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_finish_group<4>, dim3(blocks, n), dim3(256), 0, st, p, splits, G);
+    JTSM_CHECK_LAUNCH("splitk_finish group");
+  }
+  return JTSM_OK;
+}
+
 extern "C" {
+
+size_t jtsm_conv_bf16x3_wgrad_group_workspace_bytes(const jtsm_conv_shape* s, int n) {
+  if (!s || n < 1 || n > kMaxGroup) return 0;
+  Params p = {};
+  if (group_shape(s, p) || p.K == 0) return 0;
+  const int splits = x3_wgrad_group_splits(p, n);
+  return splits > 1 ? (size_t)n * splits * p.M * p.N * sizeof(float) : 0;
+}
+
+int jtsm_conv_bf16x3_wgrad_group_splits(const jtsm_conv_shape* s, int n) {
+  if (!s || n < 1 || n > kMaxGroup) return 0;
+  Params p = {};
+  if (group_shape(s, p) || p.K == 0) return 0;
+  return x3_wgrad_group_splits(p, n);
+}
+
+int jtsm_conv2d_backward_weight_group_bf16x3(int n, const uint16_t* const* dy_hi, const uint16_t* const* dy_lo,
+                                             const uint16_t* const* x_hi, const uint16_t* const* x_lo,
+                                             float* const* dw, const float* const* row_scale,
+                                             const jtsm_conv_shape* s, void* workspace, size_t workspace_bytes,
+                                             void* stream) {
+  return x3_backward_weight_group<2>(n, dy_hi, dy_lo, x_hi, x_lo, dw, row_scale, s, 0, workspace, workspace_bytes, stream);
+}
+
+int jtsm_conv2d_backward_weight_group_f16(int n, const uint16_t* const* dy_h, const uint16_t* const* x_h,
+                                          float* const* dw, const float* const* row_scale, const jtsm_conv_shape* s,
+                                          int grad_shift, void* workspace, size_t workspace_bytes, void* stream) {
+  return x3_backward_weight_group<1>(n, dy_h, nullptr, x_h, nullptr, dw, row_scale, s, grad_shift, workspace,
+                                     workspace_bytes, stream);
+}
 
 int jtsm_conv2d_forward_bf16x3(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t* w_hi,
                                const uint16_t* w_lo, float* y, uint16_t* y_hi, uint16_t* y_lo,

@@ -87,6 +87,20 @@ struct X3Planes {
   const __bf16* B_hi; const __bf16* B_lo;
 };
 
+// Same-shape weight gradients in ONE launch (blockIdx.z = member): a weight gradient is not on the backward's critical
+// path, and res3 / res4 / res5 repeat three layer shapes 3-6 times — launched one by one each of those small GEMMs
+// (res4 1x1: M = 256, N = 1024, K = 8192 pixels) is cut into 32 pixel slices to fill the chip, and its slabs (32 x the
+// result) are written and folded again; a group of six needs 5-6 slices for the same number of workgroups.
+constexpr int kMaxGroup = 8;
+struct X3Group {
+  int n;
+  const __bf16* A_hi[kMaxGroup]; const __bf16* A_lo[kMaxGroup];   // dY planes
+  const __bf16* B_hi[kMaxGroup]; const __bf16* B_lo[kMaxGroup];   // X planes
+  float* C[kMaxGroup];                                            // dW
+  const float* scale[kMaxGroup];                                  // per-row factor (the FrozenBN scale), or null
+  size_t slab_stride;                                             // floats between two members' slab sets
+};
+
 // PAIRED planes (weights).  A K stage takes 32 k = 64 bytes per row and plane.  With the planes in two arrays that is
 // HALF a 128-byte line from each: the line's other half belongs to the next stage, by which time the 64 KiB that passed
 // through the CU's 32 KiB L1 have evicted it — every line crosses L2 -> L1 twice, and that fill path (64 B/clk per CU),
@@ -607,7 +621,7 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* lo_rows, const char* hi_ro
 // WM x WN wavefronts of TM x TN MFMA tiles, as in igemm_x3_kernel; operands wider than 128 channels are kept
 // as several 128-channel images (each with the swizzle above).
 template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2, bool BIAS = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const Params p, const X3Planes q) {
+__device__ __forceinline__ void x3_wgrad_body(const Params& p, const X3Planes& q) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(BM % 128 == 0 && BN % 128 == 0 && 8 % NW == 0, "128-channel images; 8 row groups shared by the wavefronts");
@@ -801,6 +815,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
     store_tile<WGRAD, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
+template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2, bool BIAS = false>
+__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const Params p, const X3Planes q) {
+  x3_wgrad_body<WM, WN, TM, TN, NBUF, NP, BIAS>(p, q);
+}
+
+// The member's operands, result, row factors and slab set in place of the launch's (everything else — the shape, the
+// K slicing — is shared by the group).
+__device__ __forceinline__ void x3_group_member(const Params& p_in, const X3Group& G, Params& p, X3Planes& q) {
+  const int z = blockIdx.z;
+  p = p_in;
+  q.A_hi = G.A_hi[z]; q.A_lo = G.A_lo[z]; q.B_hi = G.B_hi[z]; q.B_lo = G.B_lo[z];
+  p.C = G.C[z];
+  p.e.scale = G.scale[z];
+  if (p.slab) p.slab += (size_t)z * G.slab_stride;
+}
+
+template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2>
+__global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_group_kernel(const Params p_in, const X3Group G) {
+  Params p;
+  X3Planes q;
+  x3_group_member(p_in, G, p, q);
+  x3_wgrad_body<WM, WN, TM, TN, NBUF, NP, false>(p, q);
+}
+
 // ---- 3x3 weight gradient with an LDS-resident input halo --------------------------------------------------
 // dW[co][kh][kw][ci] = sum_p dY[p][co] * X[pix(p)+(kh,kw)][ci].  The generic kernel gives every (tap, ci) column
 // group its own workgroup, so X is fetched nine times.  Here a workgroup owns 128 output channels x ONE block of 32
@@ -812,7 +850,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
 // Halo image: [102 pixel rows][64 B] per plane, UNswizzled — a transposed read of 4 consecutive pixel rows x 32
 // channels is one contiguous 256-byte run (all 64 banks) wherever it starts.
 template <int NP = 2, bool BIAS = false>
-__global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Params p, const X3Planes q) {
+__device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Planes& q) {
   constexpr int SEG = 32, HPW = SEG + 2, HP = 3 * HPW;          // 102 halo pixels
   constexpr int A_PL = SEG * 256;                                 // dY stage plane: 32 px x 128 co
   constexpr int B_G = (HP + 15) / 16, B_PL = B_G * 1024;          // halo plane: 7 groups of 16 pixel rows
@@ -981,6 +1019,19 @@ __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Param
     }
     *reinterpret_cast<float4*>(p.C + o) = v;
   });
+}
+
+template <int NP = 2, bool BIAS = false>
+__global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_kernel(const Params p, const X3Planes q) {
+  x3_wgrad_halo_body<NP, BIAS>(p, q);
+}
+
+template <int NP = 2>
+__global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_group_kernel(const Params p_in, const X3Group G) {
+  Params p;
+  X3Planes q;
+  x3_group_member(p_in, G, p, q);
+  x3_wgrad_halo_body<NP, false>(p, q);
 }
 
 // ---- the splitting pre-passes ---------------------------------------------------------------------

@@ -247,6 +247,8 @@ class GradientExchange(object):
 
     # ---- per-parameter hook: runs right after autograd has stored p.grad
     def _hook(self, p):
+        if p.grad is None:           # (autograd runs the hook also when a node handed it no gradient — a weight whose
+            return                   # gradient is queued for the grouped launch, layers/conv.py: it comes again)
         b, view = self._slot[p]
         g = p.grad
         if g.data_ptr() != view.data_ptr():
@@ -293,6 +295,7 @@ class GradientExchange(object):
         gradients for it, and all ranks must issue the same collectives) — then the compute stream waits for the side
         stream."""
         from ..layers import conv
+        conv.flush_deferred_weight_gradients()   # queued weight gradients reach their slots (and hooks) before the close
         while self._next < len(self.buckets):
             b = self.buckets[self._next]
             if b.pending:

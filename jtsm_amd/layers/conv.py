@@ -855,6 +855,115 @@ def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_sc
     return out
 
 
+# ---- deferred, grouped weight gradients --------------------------------------------------------------------------
+# A weight gradient is not on the backward's critical path (only the optimizer and the gradient exchange read it), and
+# res3 / res4 / res5 repeat three layer shapes 3-6 times.  Launched where autograd reaches them, each of those small
+# contractions is cut into ~32 pixel slices to fill the chip and its slabs are written and folded again.  With
+# DEFER_WGRAD the fused bottleneck node only QUEUES its weight gradients (operand planes kept alive) and hands autograd
+# nothing; flush_deferred_weight_gradients() — called by the first block of every stage (the last of the stage to run
+# in a backward), by the gradient exchange before it closes its buckets, and at the end of the backward — launches the
+# queued layers of one shape as ONE group (jtsm_conv2d_backward_weight_group_*: a sixth of the slices, one finishing
+# launch), stores the results as the parameters' .grad (accumulating into an existing one) and runs their
+# post-accumulate hooks, which is all AccumulateGrad would have done.
+# Only for leaf parameters reached through `.backward()`: `torch.autograd.grad(..., inputs=[weight])` must switch it off
+# (defer_weight_gradients(False)), since the node returns None for a queued weight.
+DEFER_WGRAD = os.environ.get("JTSM_DEFER_WGRAD", "1") != "0"
+GROUP_MAX = 8
+_DEFERRED = []
+_DEFER_ARMED = [False]
+
+
+def defer_weight_gradients(on):
+    global DEFER_WGRAD
+    flush_deferred_weight_gradients()
+    DEFER_WGRAD = bool(on)
+
+
+def planes_backward_weight_deferred(g, x, w, stride=1, pad=0, dil=1, row_scale=None):
+    """Queue dW of a leaf parameter for the grouped launch and return None — or, when deferral does not apply (switched
+    off, not a leaf parameter, no backward in progress), compute it now and return it."""
+    if not (DEFER_WGRAD and MATH != "f32" and w.is_leaf and w.requires_grad and w._base is None):
+        return planes_backward_weight(g, x, w, stride, pad, dil, row_scale=row_scale)
+    if not _DEFER_ARMED[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_weight_gradients)
+        except RuntimeError:     # not inside a backward pass: nothing would flush the queue
+            return planes_backward_weight(g, x, w, stride, pad, dil, row_scale=row_scale)
+        _DEFER_ARMED[0] = True
+    _DEFERRED.append((g, x, w, stride, pad, dil, row_scale))
+    return None
+
+
+def _deliver_grad(w, dw):
+    """What AccumulateGrad does for a leaf: store (or add) the gradient, then the post-accumulate hooks."""
+    if dw.stride() != w.stride() and dw.shape[2] == 1 and dw.shape[3] == 1:
+        dw = dw.as_strided(w.shape, w.stride())      # (a 1x1 weight: both orders are the same bytes)
+    if w.grad is None:
+        w.grad = dw
+    else:
+        w.grad.add_(dw)
+    hooks = getattr(w, "_post_accumulate_grad_hooks", None)
+    if hooks:
+        for hook in list(hooks.values()):
+            hook(w)
+
+
+@torch.no_grad()
+def flush_deferred_weight_gradients():
+    global _DEFERRED
+    _DEFER_ARMED[0] = False
+    if not _DEFERRED:
+        return
+    items, _DEFERRED = _DEFERRED, []
+    groups = {}
+    for it in items:
+        g, x, w, stride, pad, dil, _ = it
+        groups.setdefault((tuple(x.shape), tuple(w.shape), stride, pad, dil), []).append(it)
+    lib = L.lib()
+    for (x_shape, w_shape, stride, pad, dil), members in groups.items():
+        pl = _plan(x_shape, w_shape, stride, pad, dil)
+        for i0 in range(0, len(members), GROUP_MAX):
+            part = members[i0:i0 + GROUP_MAX]
+            if len(part) == 1 or not pl.x3[2]:
+                for g, x, w, _, _, _, rs in part:
+                    _deliver_grad(w, planes_backward_weight(g, x, w, stride, pad, dil, row_scale=rs))
+                continue
+            n = len(part)
+            outs = []
+            for g, x, w, _, _, _, rs in part:
+                slot = grad_slot(w)
+                taps = w_shape[2] * w_shape[3]
+                if slot is not None:
+                    slot = slot.as_strided(w_shape, (taps * w_shape[1], 1, w_shape[3] * w_shape[1], w_shape[1]))
+                outs.append(slot if slot is not None else
+                            torch.empty(w_shape, dtype=torch.float32, device=x.device, memory_format=CL))
+            ptr_t = C.c_void_p * n
+            gh, gl = zip(*[_hl(g.buf) for g, *_ in part])
+            xh, xl = zip(*[_hl(x.buf) for _, x, *_ in part])
+            val = lambda v: v.value if isinstance(v, C.c_void_p) else v   # noqa: E731
+            dws = ptr_t(*[o.data_ptr() for o in outs])
+            scales = ptr_t(*[(it[6].data_ptr() if it[6] is not None else None) for it in part])
+            nbytes = lib.jtsm_conv_bf16x3_wgrad_group_workspace_bytes(pl.ref, n)
+            ws = _scratch(nbytes, outs[0].device)
+            variant = None
+            if LAUNCH_LOG is not None:
+                base = str(_x3_variant(pl.s, 2)).replace("wgrad_kernel", "wgrad_group_kernel").replace(
+                    "wgrad_halo_kernel", "wgrad_halo_group_kernel")
+                variant = _Variant(base, lib.jtsm_conv_bf16x3_wgrad_group_splits(pl.ref, n))
+            desc = pl.desc[:-1] + (pl.desc[-1] * n,) if pl.desc is not None else None
+            if MATH == "f16":
+                call = lambda: lib.jtsm_conv2d_backward_weight_group_f16(      # noqa: E731
+                    n, ptr_t(*[val(v) for v in gh]), ptr_t(*[val(v) for v in xh]), dws, scales, pl.ref, GRAD_SHIFT,
+                    L.ptr(ws), C.c_size_t(nbytes), L.stream())
+            else:
+                call = lambda: lib.jtsm_conv2d_backward_weight_group_bf16x3(   # noqa: E731
+                    n, ptr_t(*[val(v) for v in gh]), ptr_t(*[val(v) for v in gl]), ptr_t(*[val(v) for v in xh]),
+                    ptr_t(*[val(v) for v in xl]), dws, scales, pl.ref, L.ptr(ws), C.c_size_t(nbytes), L.stream())
+            L.check(_timed(variant, pl.flops * n, call, desc, 0, outs[0].numel() * n), "conv2d_backward_weight_group")
+            for (g, x, w, *_), o in zip(part, outs):
+                _deliver_grad(w, o)
+
+
 def planes_channel_sum(g, grad=True):
     """Bias gradient of a gradient held as planes: sum over every axis but channels."""
     ch = g.shape[1]

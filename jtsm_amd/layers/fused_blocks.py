@@ -146,16 +146,18 @@ class _BottleneckFn(Function):
         # the block's own output gate (fp32 + planes) — inside a stage the next block's conv1 data gradient applied it
         g3 = dy if _take_pregated(dy) else relu_backward(dy, y3, emit_planes=True)
         g3p = K.PlaneTensor.of(g3, grad=True)
+        # (weight gradients: queued for the grouped launch of the stage's same-shape layers, layers/conv.py — a queued
+        # gradient reaches the parameter without passing through autograd, so the node returns None for it)
         if need[7]:
-            dw3 = K.planes_backward_weight(g3p, y2, w3, 1, 0, 1, row_scale=s3)
+            dw3 = K.planes_backward_weight_deferred(g3p, y2, w3, 1, 0, 1, row_scale=s3)
         d2 = K.planes_backward_data(g3p, w3, y2.shape, 1, 0, 1, gate=y2, kscale=s3)      # gated by conv2's ReLU
         if need[4]:
-            dw2 = K.planes_backward_weight(d2, y1, w2, stride2, pad2, dil2, row_scale=s2)
+            dw2 = K.planes_backward_weight_deferred(d2, y1, w2, stride2, pad2, dil2, row_scale=s2)
         d1 = K.planes_backward_data(d2, w2, y1.shape, stride2, pad2, dil2, gate=y1, kscale=s2)
         if need[1]:
-            dw1 = K.planes_backward_weight(d1, xp, w1, stride1, 0, 1, row_scale=s1)
+            dw1 = K.planes_backward_weight_deferred(d1, xp, w1, stride1, 0, 1, row_scale=s1)
         if ws is not None and need[10]:
-            dws = K.planes_backward_weight(g3p, xp, ws, stride_s, 0, 1, row_scale=ss)
+            dws = K.planes_backward_weight_deferred(g3p, xp, ws, stride_s, 0, 1, row_scale=ss)
         if need[0]:
             xs = tuple(x.shape)
             if ws is None:
@@ -172,6 +174,8 @@ class _BottleneckFn(Function):
             else:
                 dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, kscale=s1)
                 dx = dx.add_(K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss))
+        if ws is not None:   # the first block of a stage is the last of it to run backward: launch the stage's groups
+            K.flush_deferred_weight_gradients()
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
                 None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None,
                 None)

@@ -702,3 +702,64 @@ def test_block_output_gate_rides_in_the_next_blocks_epilogue(cuda, monkeypatch, 
             assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
         else:
             assert torch.equal(a, b), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f16"])
+def test_deferred_weight_gradients_are_grouped_and_match_the_single_launches(cuda, math):
+    """layers/conv.py: with DEFER_WGRAD the fused bottleneck node queues its weight gradients and the same-shape layers
+    of a stage go out as ONE grouped launch (jtsm_conv2d_backward_weight_group_*).  A stage of one projection block +
+    four identity blocks: the data gradient is the same bits either way; every weight gradient agrees with the
+    single-launch result to summation order (different K slicing: 1e-5 of the tensor's magnitude; fp16 planes round the
+    same operands the same way, so the bar is the same), twice in a row gives the same bits, and the launch log shows
+    the groups (conv1 x4, conv2 x4, conv3 x5 -> 3 grouped launches + 3 single ones instead of 16)."""
+    from jtsm_amd.modeling.backbone.resnet import BottleneckBlock
+    old = K.MATH
+    K.set_math(math)
+    try:
+        torch.manual_seed(11)
+        blocks = [BottleneckBlock(64, 128, bottleneck_channels=32, stride=2, norm="FrozenBN").to(cuda)] + \
+                 [BottleneckBlock(128, 128, bottleneck_channels=32, norm="FrozenBN").to(cuda) for _ in range(4)]
+        for b in blocks:
+            for c in [b.conv1, b.conv2, b.conv3] + ([b.shortcut] if b.shortcut is not None else []):
+                c.norm.bias.copy_(torch.randn_like(c.norm.bias) * 0.3)
+                c.norm.weight.copy_(torch.rand_like(c.norm.weight) + 0.5)
+        x0 = torch.randn(2, 64, 64, 96, device=cuda).contiguous(memory_format=CL)
+        # (small output gradients: the fp16 planes carry them times 2^12, and |g| 2^12 must stay below fp16's 65504)
+        wgt = (torch.randn(2, 128, 32, 48, device=cuda) * 1e-2).contiguous(memory_format=CL)
+
+        def run(defer, log=False):
+            K.defer_weight_gradients(defer)
+            K.planes_clear()
+            for b in blocks:
+                b.zero_grad(set_to_none=True)
+            x = x0.clone().requires_grad_()
+            y = x
+            for b in blocks:
+                y = b(y)
+            K.LAUNCH_LOG = [] if log else None
+            (y * wgt).sum().backward()
+            names, K.LAUNCH_LOG = [str(e[0]) for e in (K.LAUNCH_LOG or [])], None
+            params = [p for b in blocks for p in b.parameters()]
+            assert all(p.grad is not None for p in params)
+            return x.grad.clone(), [p.grad.clone() for p in params], names
+
+        dx0, g0, _ = run(False)
+        dx1, g1, names = run(True, log=True)
+        dx2, g2, _ = run(True)
+        assert torch.equal(dx0, dx1) and torch.equal(dx1, dx2)
+        assert sum("group" in n for n in names) == 3, names
+        for a, b, c in zip(g0, g1, g2):
+            assert torch.equal(b, c)                                            # reproducible
+            assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), float((a - b).abs().max())
+        # accumulation into an existing .grad (no zero_grad between two backward passes): the sum of both
+        K.defer_weight_gradients(True)
+        x = x0.clone().requires_grad_()
+        y = x
+        for b in blocks:
+            y = b(y)
+        (y * wgt).sum().backward()
+        for p, b in zip([p for blk in blocks for p in blk.parameters()], g1):
+            assert float((p.grad - 2 * b).abs().max()) <= 1e-5 * float(b.abs().max())
+    finally:
+        K.defer_weight_gradients(True)
+        K.set_math(old)
