@@ -446,10 +446,10 @@ int jtsm_conv2d_backward_weight_bias_f16(const uint16_t* dy_h, const uint16_t* x
  * output only, as jtsm_conv2d_backward_weight_bf16x3): the K (pixel) axis of the whole group is cut into as many slices
  * as ONE launch needs to fill the chip — a sixth of the slabs six separate launches write and fold.  Deterministic (slabs
  * folded in slice order); results are bit-identical for a given (shape, n), not to the single-layer entry (different
- * slicing).  Workspace: jtsm_conv_bf16x3_wgrad_group_workspace_bytes(s, n); jtsm_conv_bf16x3_wgrad_group_splits reports
- * the slice count (0: bad arguments). */
+ * slicing).  Workspace: jtsm_conv_bf16x3_wgrad_group_workspace_bytes(s, n); jtsm_conv_bf16x3_wgrad_group_plan reports
+ * the kernel (tile: 0 = the 3x3 LDS-halo kernel, 128, 256) and the slice count. */
 size_t jtsm_conv_bf16x3_wgrad_group_workspace_bytes(const jtsm_conv_shape* s, int n);
-int jtsm_conv_bf16x3_wgrad_group_splits(const jtsm_conv_shape* s, int n);
+int jtsm_conv_bf16x3_wgrad_group_plan(const jtsm_conv_shape* s, int n, int* tile, int* splits);
 int jtsm_conv2d_backward_weight_group_bf16x3(int n, const uint16_t* const* dy_hi, const uint16_t* const* dy_lo,
                                              const uint16_t* const* x_hi, const uint16_t* const* x_lo,
                                              float* const* dw, const float* const* row_scale,

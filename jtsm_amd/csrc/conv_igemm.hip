@@ -1975,6 +1975,20 @@ static int x3_backward_weight(const uint16_t* dy_hi, const uint16_t* dy_lo, cons
 
 // K slices of a GROUP of n same-shape weight gradients: the single launch's rule with n times the tiles — one resident
 // round of workgroups over the whole group.
+// 256 x 256 tiles for a GROUP: the single launch's rule with the group's tile count (a res4 1x1 layer alone has 4 such
+// tiles — too few to fill the chip at any slice count; six of them have 24).
+static bool x3_wgrad_group_big(const Params& p, int n) {
+  static const int mode = [] { const char* e = getenv("JTSM_WGRAD_GROUP_BIG"); return e ? atoi(e) : 1; }();   // sweeps
+  if (mode == 0) return x3_wgrad_big(p);
+  if (p.M < 256 || p.N < 256) return false;
+  const long t256 = (long)ceil_div(p.N, 256) * ceil_div(p.M, 256) * n;
+  if (t256 < 8 || t256 * ceil_div(p.K, XBK) < 2000) return false;
+  // ... and only where slices of >= 16 stages still give most CUs a workgroup (res5's 2048 pixels do not: measured
+  // 53 us on 128 such workgroups against 44 us on 512 of the 128 x 128 tiles)
+  const long slices = std::min<long>(std::max<long>(1, 256 / t256), std::max<long>(1, ceil_div(p.K, XBK) / 16));
+  return t256 * slices >= 192;
+}
+
 static int x3_wgrad_group_splits(const Params& p, int n) {
   if (x3_wgrad_halo(p)) {
     const int ntiles = ceil_div(p.M, 128) * (p.s.Cin / 32) * n, segs = p.K / 32;
@@ -1984,7 +1998,7 @@ static int x3_wgrad_group_splits(const Params& p, int n) {
     if (splits < 1) splits = 1;
     return ceil_div(segs, ceil_div(segs, splits));
   }
-  const bool big = x3_wgrad_big(p);
+  const bool big = x3_wgrad_group_big(p, n);
   const int t = big ? 256 : 128;
   const int ntiles = ceil_div(p.N, t) * ceil_div(p.M, t) * n;
   const int ktiles = ceil_div(p.K, XBK);
@@ -2047,7 +2061,7 @@ static int x3_backward_weight_group(int n, const uint16_t* const* dy_hi, const u
   p.ktiles_per_split = ceil_div(ceil_div(p.K, XBK), splits);
   p.slab = splits > 1 ? reinterpret_cast<float*>(workspace) : nullptr;
   p.tickets = nullptr;
-  const bool big = x3_wgrad_big(p);
+  const bool big = x3_wgrad_group_big(p, n);
   const int tl = big ? 256 : 128;
   const int ntiles = ceil_div(p.N, tl) * ceil_div(p.M, tl);
   if (x3_wgrad_halo(p)) {
@@ -2079,11 +2093,14 @@ size_t jtsm_conv_bf16x3_wgrad_group_workspace_bytes(const jtsm_conv_shape* s, in
   return splits > 1 ? (size_t)n * splits * p.M * p.N * sizeof(float) : 0;
 }
 
-int jtsm_conv_bf16x3_wgrad_group_splits(const jtsm_conv_shape* s, int n) {
-  if (!s || n < 1 || n > kMaxGroup) return 0;
+int jtsm_conv_bf16x3_wgrad_group_plan(const jtsm_conv_shape* s, int n, int* tile, int* splits) {
+  JTSM_REQUIRE(s && tile && splits && n >= 1 && n <= kMaxGroup, "wgrad group plan: bad arguments");
   Params p = {};
-  if (group_shape(s, p) || p.K == 0) return 0;
-  return x3_wgrad_group_splits(p, n);
+  int rc = group_shape(s, p);
+  if (rc) return rc;
+  *tile = x3_wgrad_halo(p) ? 0 : (x3_wgrad_group_big(p, n) ? 256 : 128);
+  *splits = p.K > 0 ? x3_wgrad_group_splits(p, n) : 1;
+  return JTSM_OK;
 }
 
 int jtsm_conv2d_backward_weight_group_bf16x3(int n, const uint16_t* const* dy_hi, const uint16_t* const* dy_lo,

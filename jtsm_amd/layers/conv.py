@@ -947,9 +947,14 @@ def flush_deferred_weight_gradients():
             ws = _scratch(nbytes, outs[0].device)
             variant = None
             if LAUNCH_LOG is not None:
-                base = str(_x3_variant(pl.s, 2)).replace("wgrad_kernel", "wgrad_group_kernel").replace(
-                    "wgrad_halo_kernel", "wgrad_halo_group_kernel")
-                variant = _Variant(base, lib.jtsm_conv_bf16x3_wgrad_group_splits(pl.ref, n))
+                tile, sp = C.c_int(), C.c_int()
+                L.check(lib.jtsm_conv_bf16x3_wgrad_group_plan(pl.ref, n, C.byref(tile), C.byref(sp)), "wgrad_group_plan")
+                np_ = ",1" if MATH == "f16" else ""
+                if tile.value == 0:
+                    base = "igemm_x3_wgrad_halo_group_kernel" + ("<1>" if MATH == "f16" else "")
+                else:
+                    base = "igemm_x3_wgrad_group_kernel<%s,2%s>" % ("4,2,2,4" if tile.value == 256 else "2,2,2,2", np_)
+                variant = _Variant(base, sp.value)
             desc = pl.desc[:-1] + (pl.desc[-1] * n,) if pl.desc is not None else None
             if MATH == "f16":
                 call = lambda: lib.jtsm_conv2d_backward_weight_group_f16(      # noqa: E731

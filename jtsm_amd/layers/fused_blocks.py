@@ -273,7 +273,10 @@ class _MaskTowerFn(Function):
             inside = need[2 * j] and need[2 * j + 1] and K.wgrad_bias_fits(hs[j].shape, w.shape, 1, 1, 1)
             if need[2 * j]:
                 db = torch.empty(w.shape[0], dtype=torch.float32, device=x_device) if inside else None
-                grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1, bias_out=db)
+                if db is None:   # queued: the tower's same-shape layers (both heads) go out as one grouped launch
+                    grads[2 * j] = K.planes_backward_weight_deferred(g, hs[j], w, 1, 1, 1)
+                else:
+                    grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1, bias_out=db)
                 grads[2 * j + 1] = db
             if need[2 * j + 1] and not inside:      # (256x256-tile layers: one batched sum over the planes at the end)
                 bias_of.append((2 * j + 1, g))

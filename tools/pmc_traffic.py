@@ -36,6 +36,13 @@ def label(name):
     def np_suffix(v):
         return "" if v in (None, "2") else "," + v
 
+    m = re.search(r"igemm_x3_wgrad_halo_group_kernel(?:<(\d+)>)?", name)   # grouped launches (conv_x3.h: X3Group)
+    if m:
+        return "igemm_x3_wgrad_halo_group_kernel" + ("<1>" if m.group(1) == "1" else "")
+    m = re.search(r"igemm_x3_wgrad_group_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
+    if m:
+        g = m.groups()
+        return "igemm_x3_wgrad_group_kernel<%s,%s,%s,%s,%s%s>" % (g[:5] + (np_suffix(g[5]),))
     m = re.search(r"igemm_x3_wgrad_halo_kernel(?:<(\d+)(?:, (?:true|false))?>)?", name)   # <NP, BIAS>
     if m:
         return "igemm_x3_wgrad_halo_kernel" + ("<1>" if m.group(1) == "1" else "")
