@@ -862,12 +862,16 @@ __device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Plan
   const void* const zero_page = zero_page_address();
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ncb = s.Cin / 32;
-  const int tile = blockIdx.x;
+  // all tiles of a pixel slice on one XCD (as the generic weight gradient): they read the same dY / X rows.  Dealt out
+  // in dispatch order, the 16 tiles of a slice sat on all eight XCDs and every L2 fetched every slice — rocprofv3
+  // counted 464 MB of fabric traffic per launch for 65 MB of operands (7.1x) on these kernels.
+  int tile, split;
+  xcd_slice_major((int)gridDim.x, tile, split);
   const int m0 = (tile / ncb) * 128, ci0 = (tile % ncb) * 32;
 
   int kbeg = 0, kend = p.K;   // K = output pixels, in stages of one 32-pixel segment
   if (gridDim.y > 1) {
-    kbeg = blockIdx.y * p.ktiles_per_split * SEG;
+    kbeg = split * p.ktiles_per_split * SEG;
     kend = min(p.K, kbeg + p.ktiles_per_split * SEG);
   }
   const int nstage = kbeg < kend ? (kend - kbeg) / SEG : 0;
@@ -970,7 +974,7 @@ __device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Plan
     }
   }
 
-  if (BIAS && do_bias) x3_bias_store(p, bacc, m0 + wave * 32, gridDim.y > 1 ? blockIdx.y : 0, lane);
+  if (BIAS && do_bias) x3_bias_store(p, bacc, m0 + wave * 32, gridDim.y > 1 ? split : 0, lane);
   // epilogue: tile t of this wavefront is dW[m0 + 32*wave + row][tap t][ci0 + col]
   const Epilogue& e = p.e;
   const int col = ci0 + (lane & 31);
@@ -983,7 +987,7 @@ __device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Plan
       if (m >= p.M) continue;
       float v = acc[t][r];
       if (gridDim.y > 1) {
-        float* dst = p.slab + ((size_t)blockIdx.y * p.M + m) * p.ldc + n;
+        float* dst = p.slab + ((size_t)split * p.M + m) * p.ldc + n;
         if (p.tickets) st_sc1(dst, v); else *dst = v;
         continue;
       }
@@ -997,7 +1001,7 @@ __device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Plan
   if (!(gridDim.y > 1 && p.tickets)) return;
   // split-K finishing by the tile's last-arriving slice (conv_igemm.hip: splitk_fold): 128 rows x nine 32-column runs
   __syncthreads();
-  if (!splitk_last_arrival(p, reinterpret_cast<int*>(lds), blockIdx.x)) return;
+  if (!splitk_last_arrival(p, reinterpret_cast<int*>(lds), tile)) return;
   constexpr int NPIECE = 128 * TAPS * 8 / 256;          // float4 pieces per thread
   splitk_fold(p, NPIECE, [&](int k, int& m, int& n) {
     const int c = tid + 256 * k;                        // (row, tap, 4-column group): the group is fastest

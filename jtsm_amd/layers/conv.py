@@ -153,10 +153,17 @@ _PLANES_MAX_BYTES = 16 << 30   # entries pin their tensors: a caller that never 
 _planes_bytes = 0
 
 
+# callables run by planes_clear(): per-step state other modules key on this cache's lifetime (layers/fused_blocks.py
+# drops its held block-output gradient)
+CLEAR_HOOKS = []
+
+
 def planes_clear():
     global _planes_bytes
     _PLANES.clear()
     _planes_bytes = 0
+    for hook in CLEAR_HOOKS:
+        hook()
     refresh_weight_planes()
 
 

@@ -45,6 +45,15 @@ def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=No
 _PREGATED = [None]
 
 
+def _drop_pregated():
+    """A gradient handed over but never taken (the previous block frozen or detached) must not stay pinned — a whole
+    res-stage activation gradient — beyond the step: cleared with the plane cache, at the start of every forward."""
+    _PREGATED[0] = None
+
+
+K.CLEAR_HOOKS.append(_drop_pregated)
+
+
 def _hand_pregated(dx):
     _PREGATED[0] = (dx, dx._version)
 

@@ -206,6 +206,11 @@ class StandardROIHeads(torch.nn.Module):
         for p, t in zip(fg, targets):
             if len(p) == 0:
                 continue
+            if not isinstance(t.gt_masks, torch.Tensor) or t.gt_masks.dim() != 3:
+                # (the reference's default INPUT.MASK_FORMAT is "polygon": PolygonMasks rasterised per roi by
+                # pycocotools — outside the HIP scope; BitMasks users pass `.tensor`)
+                raise TypeError("StandardROIHeads mask branch: gt_masks must be a (G, H, W) bitmask tensor "
+                                "(INPUT.MASK_FORMAT = 'bitmask'), got %r" % type(t.gt_masks).__name__)
             masks = t.gt_masks.to(torch.float32)[:, None]                         # (G, 1, H, W) bitmasks
             rois = torch.cat([p.matched_gt_idx.to(torch.float32)[:, None], p.proposal_boxes.tensor], dim=1)
             tgt.append(roi_align(masks, rois, (side, side), 1.0, 0, True)[:, 0] >= 0.5)
