@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict_
   }
 }
 
+// l0 * a + l1 * b with the contraction spelled out: the two backward forms below must round alike
+__device__ __forceinline__ float mix2(float l0, float a, float l1, float b) { return __fmaf_rn(l0, a, l1 * b); }
+
 // dz[n,h,w,c] = up/count * sum over output pixels o touching (h,w) of weight(o -> (h,w)) * (softmax_o[c] - [c == t_o])
 // A gather (no atomics, deterministic): 16 lanes per source pixel, one float4 of channels per lane.  For one
 // output column the three source rows h-1, h, h+1 are interpolated along x once and reused by all of that
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(256) void ce_up_bwd_kernel(const float* __restrict_
       for (int i = 0; i < 3; ++i) {
         const float4 u0 = *reinterpret_cast<const float4*>(zn + ((size_t)rows[i] * Ws + b.i0) * ldc);
         const float4 u1 = *reinterpret_cast<const float4*>(zn + ((size_t)rows[i] * Ws + b.i1) * ldc);
-        r[i][0] = b.l0 * u0.x + b.l1 * u1.x; r[i][1] = b.l0 * u0.y + b.l1 * u1.y;
-        r[i][2] = b.l0 * u0.z + b.l1 * u1.z; r[i][3] = b.l0 * u0.w + b.l1 * u1.w;
+        r[i][0] = mix2(b.l0, u0.x, b.l1, u1.x); r[i][1] = mix2(b.l0, u0.y, b.l1, u1.y);
+        r[i][2] = mix2(b.l0, u0.z, b.l1, u1.z); r[i][3] = mix2(b.l0, u0.w, b.l1, u1.w);
       }
       for (int oh = oh0; oh < oh1; ++oh) {
         const LerpS a = lerp_scale(oh, Hs, inv);
@@ -470,9 +473,9 @@ __global__ __launch_bounds__(256) void ce_up_bwd_kernel(const float* __restrict_
         for (int e = 0; e < 4; ++e) {
           const float t0 = lo0 ? r[0][e] : (hi0 ? r[2][e] : r[1][e]);
           const float t1 = lo1 ? r[0][e] : (hi1 ? r[2][e] : r[1][e]);
-          const float v = a.l0 * t0 + a.l1 * t1;
+          const float v = mix2(a.l0, t0, a.l1, t1);
           const float pr = c0 + e < C ? __expf(v - l) : 0.f;
-          acc[e] += wgt * (pr - ((long)(c0 + e) == t ? 1.f : 0.f));
+          acc[e] = __fmaf_rn(wgt, pr - ((long)(c0 + e) == t ? 1.f : 0.f), acc[e]);
         }
       }
     }
@@ -483,6 +486,171 @@ __global__ __launch_bounds__(256) void ce_up_bwd_kernel(const float* __restrict_
 }
 
 inline int grid_for(long total) { return (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192); }
+
+// The same gather through LDS, for S = 4 (the JTSM path: logits at stride 4).  In the form above every output pixel's
+// soft-max is evaluated by each of the (up to) four source pixels it feeds — 4 x the exponentials, and the kernel is
+// bound by exactly those (0.29 ms per step at 3 % of the HBM roof).  Here a workgroup owns a 4 x 4 tile of source
+// pixels: the 6 x 6 source logits it interpolates from are staged once, each of the <= 20 x 20 output pixels that
+// touch the tile gets its (soft-max - one-hot) row computed ONCE into LDS (1.56 x instead of 4 x), and 16 x ldc / 4
+// threads gather their source pixel's sum from there — in the order of the form above (output column outer, row
+// inner, the same products), so the result is the same bits.
+constexpr int CE_TS = 4, CE_S = 4, CE_OT = CE_TS * CE_S + 4, CE_ZT = CE_TS + 2;
+struct CeTile { int n, h0, w0, oh_lo, ow_lo, nrow, ncol, zr0, zc0, zr1, zc1; };
+
+// A fixed grid (one workgroup per CU: 111 KB of LDS) strides the tile list, and the next tile's logits, labels and
+// log-sum-exps are in flight (one float4 or two, one label per thread) while the current tile is worked on — with one
+// workgroup per CU nothing else would hide those loads.
+__global__ __launch_bounds__(512) void ce_up_bwd_tiled_kernel(const float* __restrict__ z, int ldc, int C,
+                                                              const long* __restrict__ target,
+                                                              const float* __restrict__ lse, const float* __restrict__ fin,
+                                                              const float* __restrict__ upstream, float* __restrict__ dz,
+                                                              int N, int Hs, int Ws, long ignore, int tiles) {
+  __shared__ __attribute__((aligned(16))) float zs[CE_ZT * CE_ZT * 64];     // source logits of the tile + 1 ring
+  __shared__ __attribute__((aligned(16))) float gs[CE_OT * CE_OT * 64];     // (soft-max - one-hot) of the outputs
+  __shared__ int tgs[CE_OT * CE_OT];                                        // their labels (-1: ignored) ...
+  __shared__ float ls[CE_OT * CE_OT];                                       // ... and log-sum-exp
+  constexpr int S = CE_S;
+  const int t = threadIdx.x, nq = ldc >> 2;
+  const int tiles_x = (Ws + CE_TS - 1) / CE_TS, tiles_y = (Hs + CE_TS - 1) / CE_TS;
+  const int H = Hs * S, W = Ws * S;
+  const float inv = 1.f / (float)S;
+  const float k = (upstream ? *upstream : 1.f) / fin[1];
+  // a / d by multiply-high, exact for a * d < 2^32 (a < 2^15 here)
+  const unsigned magic_nq = (unsigned)((0x100000000ull + (unsigned)nq - 1) / (unsigned)nq);
+  const int nz = CE_ZT * CE_ZT * nq;   // float4s of the staged logits: <= 576, two per thread at most
+
+  auto geom = [&](int tile) {
+    CeTile g;
+    const int tx = tile % tiles_x;
+    tile /= tiles_x;
+    g.n = tile / tiles_y;
+    g.h0 = (tile - g.n * tiles_y) * CE_TS;
+    g.w0 = tx * CE_TS;
+    // outputs that can put weight on the tile (the form above: S*h - (S+1)/2 .. S*h + S + (S+1)/2)
+    g.oh_lo = max(S * g.h0 - S / 2, 0);
+    g.ow_lo = max(S * g.w0 - S / 2, 0);
+    g.nrow = min(S * (g.h0 + CE_TS) + S / 2, H) - g.oh_lo;
+    g.ncol = min(S * (g.w0 + CE_TS) + S / 2, W) - g.ow_lo;
+    g.zr0 = max(g.h0 - 1, 0);
+    g.zc0 = max(g.w0 - 1, 0);
+    g.zr1 = min(g.h0 + CE_TS, Hs - 1);
+    g.zc1 = min(g.w0 + CE_TS, Ws - 1);
+    return g;
+  };
+  auto fetch = [&](const CeTile& g, float4 (&pz)[2], long& ptg, float& pl) {
+    const float* zn = z + (size_t)g.n * Hs * Ws * ldc;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + 512 * u;
+      const int pix = (int)__umulhi((unsigned)i, magic_nq), q = i - pix * nq;
+      const int sy = g.zr0 + pix / CE_ZT, sx = g.zc0 + pix % CE_ZT;
+      if (i < nz && sy <= g.zr1 && sx <= g.zc1)
+        pz[u] = *reinterpret_cast<const float4*>(zn + ((size_t)sy * Ws + sx) * ldc + 4 * q);
+    }
+    if (t < g.nrow * g.ncol) {   // (<= 400 of the 512)
+      const int oy = t / g.ncol, ox = t - oy * g.ncol;
+      const long og = ((long)g.n * H + g.oh_lo + oy) * W + g.ow_lo + ox;
+      ptg = target[og];
+      pl = lse[og];
+    }
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= tiles) return;
+  CeTile cur = geom(tile);
+  float4 pz[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  long ptg = ignore;
+  float pl = 0.f;
+  fetch(cur, pz, ptg, pl);
+  for (; tile < tiles; tile += gridDim.x) {
+    // (zs / tgs / ls were last read before the previous tile's middle barrier)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i = t + 512 * u;
+      if (i < nz) *reinterpret_cast<float4*>(zs + 4 * i) = pz[u];    // (pix * ldc + 4 q = 4 i; rows outside the map: stale, never read)
+    }
+    if (t < cur.nrow * cur.ncol) {
+      tgs[t] = ptg == ignore ? -1 : (int)ptg;
+      ls[t] = pl;
+    }
+    __syncthreads();
+    const CeTile g = cur;
+    if (tile + (int)gridDim.x < tiles) {
+      cur = geom(tile + gridDim.x);
+      fetch(cur, pz, ptg, pl);
+    }
+    const unsigned magic_ncol = (unsigned)((0x100000000ull + (unsigned)g.ncol - 1) / (unsigned)g.ncol);
+    const int nitem = g.nrow * g.ncol * nq;
+#pragma unroll 2
+    for (int it = t; it < nitem; it += 512) {
+      const int o = (int)__umulhi((unsigned)it, magic_nq), q = it - o * nq;
+      const int oy = (int)__umulhi((unsigned)o, magic_ncol), ox = o - oy * g.ncol;
+      const int oh = g.oh_lo + oy, ow = g.ow_lo + ox;
+      const int tg = tgs[o];
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tg >= 0) {
+        const float l = ls[o];
+        const LerpS a = lerp_scale(oh, Hs, inv), b = lerp_scale(ow, Ws, inv);
+        const float4 u00 = *reinterpret_cast<const float4*>(zs + ((a.i0 - g.zr0) * CE_ZT + (b.i0 - g.zc0)) * ldc + 4 * q);
+        const float4 u01 = *reinterpret_cast<const float4*>(zs + ((a.i0 - g.zr0) * CE_ZT + (b.i1 - g.zc0)) * ldc + 4 * q);
+        const float4 u10 = *reinterpret_cast<const float4*>(zs + ((a.i1 - g.zr0) * CE_ZT + (b.i0 - g.zc0)) * ldc + 4 * q);
+        const float4 u11 = *reinterpret_cast<const float4*>(zs + ((a.i1 - g.zr0) * CE_ZT + (b.i1 - g.zc0)) * ldc + 4 * q);
+        const float r0[4] = {mix2(b.l0, u00.x, b.l1, u01.x), mix2(b.l0, u00.y, b.l1, u01.y),
+                             mix2(b.l0, u00.z, b.l1, u01.z), mix2(b.l0, u00.w, b.l1, u01.w)};
+        const float r1[4] = {mix2(b.l0, u10.x, b.l1, u11.x), mix2(b.l0, u10.y, b.l1, u11.y),
+                             mix2(b.l0, u10.z, b.l1, u11.z), mix2(b.l0, u10.w, b.l1, u11.w)};
+        float e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = mix2(a.l0, r0[j], a.l1, r1[j]);
+          const float pr = 4 * q + j < C ? __expf(v - l) : 0.f;
+          e[j] = pr - (4 * q + j == tg ? 1.f : 0.f);
+        }
+        d = make_float4(e[0], e[1], e[2], e[3]);
+      }
+      *reinterpret_cast<float4*>(gs + 4 * it) = d;    // (o * ldc + 4 q = 4 it)
+    }
+    __syncthreads();
+    if (t < CE_TS * CE_TS * nq) {
+      const int sp = (int)__umulhi((unsigned)t, magic_nq), q = t - sp * nq;
+      const int h = g.h0 + sp / CE_TS, w = g.w0 + sp % CE_TS;
+      if (h < Hs && w < Ws) {
+        // the 8 x 8 output pixels around (h, w): weights first (zero where the pixel does not interpolate from (h, w)
+        // or lies outside the map — its LDS row is then some other finite row, times zero), then 64 independent reads
+        constexpr int R = 2 * CE_S;
+        float wy[R], wx[R];
+        int ry[R], rx[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          const int oh = S * h - S / 2 + i, ow = S * w - S / 2 + i;
+          const LerpS a = lerp_scale(oh, Hs, inv), bb = lerp_scale(ow, Ws, inv);
+          const bool yin = oh >= 0 && oh < H, xin = ow >= 0 && ow < W;
+          wy[i] = yin ? (a.i0 == h ? a.l0 : 0.f) + (a.i1 == h ? a.l1 : 0.f) : 0.f;
+          wx[i] = xin ? (bb.i0 == w ? bb.l0 : 0.f) + (bb.i1 == w ? bb.l1 : 0.f) : 0.f;
+          ry[i] = (min(max(oh - g.oh_lo, 0), g.nrow - 1)) * g.ncol;
+          rx[i] = min(max(ow - g.ow_lo, 0), g.ncol - 1);
+        }
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* gq = gs + 4 * q;
+#pragma unroll
+        for (int ix = 0; ix < R; ++ix) {
+#pragma unroll
+          for (int iy = 0; iy < R; ++iy) {
+            const float wgt = wy[iy] * wx[ix];
+            const float4 d = *reinterpret_cast<const float4*>(gq + (ry[iy] + rx[ix]) * ldc);
+            acc[0] = __fmaf_rn(wgt, d.x, acc[0]); acc[1] = __fmaf_rn(wgt, d.y, acc[1]);
+            acc[2] = __fmaf_rn(wgt, d.z, acc[2]); acc[3] = __fmaf_rn(wgt, d.w, acc[3]);
+          }
+        }
+        const int c0 = 4 * q;
+        *reinterpret_cast<float4*>(dz + (((size_t)g.n * Hs + h) * Ws + w) * ldc + c0) =
+            make_float4(c0 + 0 < C ? acc[0] * k : 0.f, c0 + 1 < C ? acc[1] * k : 0.f, c0 + 2 < C ? acc[2] * k : 0.f,
+                        c0 + 3 < C ? acc[3] * k : 0.f);
+      }
+    }
+    // (gs is next written after the next tile's first barrier)
+  }
+}
 inline size_t a16(size_t b) { return (b + 15) & ~(size_t)15; }
 inline int gn_slabs(long HW) { return (int)((HW + GN_SLAB_ROWS - 1) / GN_SLAB_ROWS); }
 
@@ -618,6 +786,16 @@ int jtsm_semseg_ce_backward_f32(const float* logits, int ld, int C, const int64_
                "semseg_ce backward: logits and dlogits must be 16-byte aligned");
   const float* lse = reinterpret_cast<const float*>(workspace);
   const long nsrc = (long)N * Hs * Ws;
+  const char* form = getenv("JTSM_CE_BWD_TILED");   // (read per call: the parity test runs both forms in one process)
+  const bool tiled_ok = !form || atoi(form) != 0;
+  const long tiles = (long)N * ((Hs + CE_TS - 1) / CE_TS) * ((Ws + CE_TS - 1) / CE_TS);
+  if (S == CE_S && tiled_ok && tiles < (1L << 31)) {
+    hipLaunchKernelGGL(ce_up_bwd_tiled_kernel, dim3((unsigned)(tiles < 256 ? tiles : 256)), dim3(512), 0,
+                       as_stream(stream), logits, ld, C, (const long*)target, lse, fwd_out, upstream, dlogits, N, Hs, Ws,
+                       ignore_index, (int)tiles);
+    JTSM_CHECK_LAUNCH("semseg_ce backward (tiled)");
+    return JTSM_OK;
+  }
   int blocks = (int)((nsrc + 15) / 16 < 16384 ? (nsrc + 15) / 16 : 16384);
   hipLaunchKernelGGL(ce_up_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), logits, ld, C,
                      (const long*)target, lse, fwd_out, upstream, dlogits, N, Hs, Ws, S, ignore_index);

@@ -304,7 +304,9 @@ def test_fused_upsample_cross_entropy_vs_torch_cpu(cuda):
     from jtsm_amd.layers.elementwise import semseg_cross_entropy
 
     g = torch.Generator().manual_seed(11)
-    for (n, c, hs, ws, scale) in [(2, 54, 16, 24, 4), (1, 7, 5, 3, 2), (1, 54, 8, 8, 4)]:
+    # (x4 runs the LDS-tiled backward: whole tiles, ragged tiles on both edges, maps smaller than one tile)
+    for (n, c, hs, ws, scale) in [(2, 54, 16, 24, 4), (1, 7, 5, 3, 2), (1, 54, 8, 8, 4), (2, 54, 5, 7, 4),
+                                  (1, 54, 3, 1, 4), (1, 13, 9, 2, 4), (1, 54, 1, 1, 4)]:
         z = torch.randn(n, c, hs, ws, generator=g) * 3
         t = torch.randint(0, c, (n, hs * scale, ws * scale), generator=g)
         t[:, :2] = 255
@@ -322,6 +324,28 @@ def test_fused_upsample_cross_entropy_vs_torch_cpu(cuda):
         (loss * 0.7).backward()
         close(wd.grad[:, :c], zr.grad, "ce dlogits")
         assert wd.grad[:, c:].abs().max().item() == 0
+
+
+def test_tiled_cross_entropy_backward_is_the_plain_gather_bit_for_bit(cuda, monkeypatch):
+    """The x4 backward through LDS (one soft-max per output pixel) adds the same products in the same order as the
+    plain gather it replaces: equal bits, at the JTSM size and on ragged maps."""
+    from jtsm_amd.layers.elementwise import semseg_cross_entropy
+
+    g = torch.Generator().manual_seed(12)
+    for (n, c, hs, ws) in [(2, 54, 256, 256), (1, 54, 37, 19), (1, 54, 2, 3)]:
+        z = (torch.randn(n, c + 2, hs, ws, generator=g) * 3).to(cuda).contiguous(memory_format=CL)
+        t = torch.randint(0, c, (n, hs * 4, ws * 4), generator=g)
+        t[:, : hs] = 255
+        t[0, :, 3::7] = 255
+        t = t.to(cuda)
+        grads = []
+        for form in ("1", "0"):
+            monkeypatch.setenv("JTSM_CE_BWD_TILED", form)
+            zd = z.clone().requires_grad_()
+            semseg_cross_entropy(zd[:, :c], t, 4, 255).backward()
+            grads.append(zd.grad.clone())
+        assert torch.equal(grads[0], grads[1]), (n, c, hs, ws, (grads[0] - grads[1]).abs().max().item())
+        assert grads[0].abs().max().item() > 0
 
 
 def test_empty_batch_through_conv_linear_and_mask_head(cuda):
