@@ -586,6 +586,34 @@ int jtsm_near_targets_f32(const float* proposals, const int32_t* bag_offsets, in
                           int bg_label, const float* pgt_box, const int32_t* counts, int Gmax, int top_k,
                           int32_t* near_rows, int32_t* matched_near, void* stream);
 
+/* Label preparation (no arithmetic of the model: the index / presence glue around it, which the reference writes as
+ * dozens of small tensor ops).  Per-image inputs are B <= 16 device pointers with their row counts (host arrays).
+ *
+ * jtsm_pooler_rois_levels_f32 — ROIPooler's two helpers as one pass (detectron2/modeling/poolers.py:22-58
+ *   assign_boxes_to_levels, :68-95 convert_boxes_to_pooler_format; projects/WSL/wsl/modeling/poolers.py:24-109):
+ *   rois (M,5) = [image index, x0, y0, x1, y1]; level (M) = floor(canonical_level + log2(sqrt(area) /
+ *   canonical_box_size + 1e-8)) clamped to [min_level, max_level], minus min_level (NaN -> 0).  Float operations in
+ *   PyTorch's order (its division by a host scalar multiplies by the rounded reciprocal): same levels, bit for bit.
+ * jtsm_roi_scale_f32 — the box head's per-roi factor (projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:607-633):
+ *   out[m] = bins / (nvalid[m] + 1) * (objectness[m] + 1), nvalid = bins of roi m whose MOIPool argmax (channel 0) is
+ *   not -1; argmax (M, bins, C) int32 channels-last.
+ * jtsm_image_labels — image-level labels (projects/WSL/wsl/modeling/roi_heads/roi_heads.py:146-161 get_image_level_gt,
+ *   roi_heads_jtsm.py get_image_level_gt_stuff): oh_things (B, num_classes) 0/1 from each image's gt_classes (int64),
+ *   things_cls (B, num_classes) = the present classes ascending, then the absent ones ascending; things_cnt (B) = how
+ *   many are present.  With sem_seg (B x pixels labels of sem_elem_bytes 8 (int64) or 1 (uint8), clamped to 0..255):
+ *   the same for the stuff labels 1 .. num_stuff - 1 (0 = things, 255 = ignore), columns label - 1, list entries
+ *   column + stuff_offset.  workspace: jtsm_image_labels_workspace_bytes(B). */
+int jtsm_pooler_rois_levels_f32(const float* const* boxes, const int* counts, int B, int min_level, int max_level,
+                                float canonical_box_size, float canonical_level, float* rois, int32_t* level,
+                                void* stream);
+int jtsm_roi_scale_f32(const int32_t* argmax, int bins, int C, const float* const* objectness, const int* counts, int B,
+                       float* out, void* stream);
+size_t jtsm_image_labels_workspace_bytes(int B);
+int jtsm_image_labels(const int64_t* const* gt_classes, const int* counts, int B, int num_classes, const void* sem_seg,
+                      int sem_elem_bytes, long pixels, int num_stuff, int stuff_offset, float* oh_things,
+                      int32_t* things_cls, int32_t* things_cnt, float* oh_stuff, int32_t* stuff_cls, int32_t* stuff_cnt,
+                      void* workspace, void* stream);
+
 /* Mask loss — mask_rcnn_loss (detectron2/modeling/roi_heads/mask_head.py:31-112, used by
  * projects/WSL/wsl/modeling/roi_heads/mask_head.py): mean binary cross-entropy with logits between the
  * ground-truth-class channel of logits (N,side,side,ld) NHWC (num_classes <= ld; gt_classes NULL when

@@ -394,6 +394,114 @@ __global__ __launch_bounds__(1024) void paint_missing_evidence_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Label preparation in three launches (round 3).  What these replace were ~80 PyTorch device launches of a few hundred
+// threads each per step (arange / where / sort / remainder / index_put / sqrt / log2 / floor / clamp / cat ...), 2-5 us
+// apiece on a busy device.  Per-image inputs arrive as up to kMaxImages pointers BY VALUE in the kernel arguments: no
+// concatenation and no table upload.
+constexpr int kMaxImages = 16;
+struct ImageRows {
+  const void* ptr[kMaxImages];
+  int first[kMaxImages + 1];      // first[b] .. first[b + 1]: the rows of image b in the concatenation
+};
+__device__ __forceinline__ int image_of_row(const ImageRows& im, int B, int m) {
+  int b = 0;
+  while (b + 1 < B && m >= im.first[b + 1]) ++b;
+  return b;
+}
+
+// detectron2 poolers.py:22-58 + 61-95 as ONE pass: rois (M,5) = [image, x0, y0, x1, y1] and the 0-based level
+//   floor(canonical_level + log2(sqrt(area) / canonical_size + 1e-8)) clamped to [min_level, max_level] (NaN -> min).
+// The arithmetic is PyTorch's, operation by operation (its division by a host scalar is a multiplication by the
+// rounded reciprocal), so the levels are the ones `assign_boxes_to_levels` computes.
+__global__ __launch_bounds__(256) void pooler_rois_levels_kernel(const ImageRows im, int B, int M, float inv_canonical,
+                                                                 float canonical_level, int min_level, int max_level,
+                                                                 float* __restrict__ rois, int* __restrict__ level) {
+#pragma clang fp contract(off)
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  const int b = image_of_row(im, B, m);
+  const float4 bx = reinterpret_cast<const float4*>(im.ptr[b])[m - im.first[b]];
+  rois[(size_t)m * 5 + 0] = (float)b;
+  rois[(size_t)m * 5 + 1] = bx.x; rois[(size_t)m * 5 + 2] = bx.y;
+  rois[(size_t)m * 5 + 3] = bx.z; rois[(size_t)m * 5 + 4] = bx.w;
+  const float area = (bx.z - bx.x) * (bx.w - bx.y);
+  float lv = floorf(canonical_level + log2f(sqrtf(area) * inv_canonical + 1e-8f));
+  if (lv != lv) lv = (float)min_level;
+  lv = fminf(fmaxf(lv, (float)min_level), (float)max_level);
+  level[m] = (int)lv - min_level;
+}
+
+// roi_heads_jtsm.py:607-633 glue: scale[m] = bins / (nvalid[m] + 1) * (objectness[m] + 1), nvalid = the bins of roi m
+// whose MOIPool arg-max (channel 0) is not -1.  arg: (M, bins, C) int32 (channels-last).  Operation order as in the
+// PyTorch expression it replaces: (bins * (1 / (nvalid + 1))) * (objectness + 1).
+__global__ __launch_bounds__(256) void roi_scale_kernel(const int* __restrict__ arg, int bins, int C, const ImageRows obj,
+                                                        int B, int M, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int nvalid = 0;
+  for (int i = 0; i < bins; ++i) nvalid += arg[((size_t)m * bins + i) * C] != -1;
+  const int b = image_of_row(obj, B, m);
+  const float o = reinterpret_cast<const float*>(obj.ptr[b])[m - obj.first[b]];
+  out[m] = ((float)bins * (1.0f / ((float)nvalid + 1.0f))) * (o + 1.0f);
+}
+
+// which of the labels 0..255 occur in each image's semantic map (values outside are clamped, as the scatter it
+// replaces clamps them).  flags (B,256) int32, zeroed by the caller.
+template <typename T>
+__global__ __launch_bounds__(256) void sem_label_flags_kernel(const T* __restrict__ sem, long pixels, int* __restrict__ flags) {
+  __shared__ int seen[256];
+  seen[threadIdx.x] = 0;
+  __syncthreads();
+  const T* img = sem + (size_t)blockIdx.y * pixels;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (long)gridDim.x * blockDim.x) {
+    long v = (long)img[i];
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    seen[v] = 1;            // (racing stores of the same value)
+  }
+  __syncthreads();
+  if (seen[threadIdx.x]) flags[blockIdx.y * 256 + threadIdx.x] = 1;
+}
+
+// one-hot row, class list (present classes ascending, then the absent ones ascending, each + offset: what
+// sort(where(present, c, c + C)) % C + offset gives) and count of one image.  C <= 256.
+__device__ __forceinline__ void emit_class_list(bool present, int c, int C, int offset, float* __restrict__ oh,
+                                                int* __restrict__ cls, int* __restrict__ cnt, int* wave_count) {
+  int npresent, nabsent;
+  const bool valid = c < C;
+  const int ps = compact256(valid && present, wave_count, npresent);
+  const int as = compact256(valid && !present, wave_count, nabsent);
+  if (valid) {
+    oh[c] = present ? 1.f : 0.f;
+    cls[present ? ps : npresent + as] = c + offset;
+  }
+  if (c == 0) *cnt = npresent;
+}
+__global__ __launch_bounds__(256) void image_class_lists_kernel(const ImageRows things, int C, const int* __restrict__ stuff_flags,
+                                                                int S, int stuff_offset, float* __restrict__ oh_things,
+                                                                int* __restrict__ things_cls, int* __restrict__ things_cnt,
+                                                                float* __restrict__ oh_stuff, int* __restrict__ stuff_cls,
+                                                                int* __restrict__ stuff_cnt) {
+  __shared__ int seen[256];
+  __shared__ int wave_count[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  seen[t] = 0;
+  __syncthreads();
+  const long* gt = reinterpret_cast<const long*>(things.ptr[b]);
+  const int n = things.first[b + 1] - things.first[b];
+  for (int i = t; i < n; i += 256) {
+    const long c = gt[i];
+    if (c >= 0 && c < C) seen[c] = 1;
+  }
+  __syncthreads();
+  emit_class_list(seen[t] != 0, t, C, 0, oh_things + (size_t)b * C, things_cls + (size_t)b * C, things_cnt + b, wave_count);
+  if (stuff_flags)   // stuff label l = 1 .. S - 1 is column l - 1 (0 = things and 255 = ignore do not count)
+    emit_class_list(t + 1 < 256 && stuff_flags[b * 256 + t + 1] != 0, t, S - 1, stuff_offset, oh_stuff + (size_t)b * (S - 1),
+                    stuff_cls + (size_t)b * (S - 1), stuff_cnt + b, wave_count);
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -494,6 +602,81 @@ int jtsm_paint_sem_seg_evidence(const int32_t* target_idx, const int32_t* bag_of
   hipLaunchKernelGGL(paint_missing_evidence_kernel, dim3(B), dim3(1024), 0, st, target_idx, bag_offsets, oh_labels, L,
                      superpixels, classes, counts, G, class_base, H, W, reinterpret_cast<long*>(out), value_counts);
   JTSM_CHECK_LAUNCH("paint_sem_seg_evidence");
+  return JTSM_OK;
+}
+
+namespace {
+int pack_rows(const void* const* ptrs, const int* counts, int B, jtsm::ImageRows& out, int& total) {
+  JTSM_REQUIRE(B >= 1 && B <= jtsm::kMaxImages, "label preparation: 1..%d images per call, got %d", jtsm::kMaxImages, B);
+  total = 0;
+  for (int b = 0; b < jtsm::kMaxImages; ++b) { out.ptr[b] = nullptr; out.first[b] = 0; }
+  for (int b = 0; b < B; ++b) {
+    JTSM_REQUIRE(counts[b] >= 0 && (counts[b] == 0 || ptrs[b]), "label preparation: image %d has %d rows at %p", b, counts[b], ptrs[b]);
+    out.ptr[b] = ptrs[b];
+    out.first[b] = total;
+    total += counts[b];
+  }
+  for (int b = B; b <= jtsm::kMaxImages; ++b) out.first[b] = total;
+  return JTSM_OK;
+}
+}  // namespace
+
+int jtsm_pooler_rois_levels_f32(const float* const* boxes, const int* counts, int B, int min_level, int max_level,
+                                float canonical_box_size, float canonical_level, float* rois, int32_t* level, void* stream) {
+  jtsm::ImageRows im;
+  int M;
+  if (int rc = pack_rows(reinterpret_cast<const void* const*>(boxes), counts, B, im, M)) return rc;
+  JTSM_REQUIRE(canonical_box_size > 0.f && min_level <= max_level, "pooler levels: bad canonical size / level range");
+  for (int b = 0; b < B; ++b)
+    JTSM_REQUIRE((reinterpret_cast<uintptr_t>(boxes[b]) & 15) == 0, "pooler levels: image %d's boxes are not 16-byte aligned", b);
+  if (M == 0) return JTSM_OK;
+  hipLaunchKernelGGL(jtsm::pooler_rois_levels_kernel, dim3(jtsm::ceil_div(M, 256)), dim3(256), 0, jtsm::as_stream(stream), im, B, M,
+                     1.0f / canonical_box_size, canonical_level, min_level, max_level, rois, level);
+  JTSM_CHECK_LAUNCH("pooler_rois_levels");
+  return JTSM_OK;
+}
+
+int jtsm_roi_scale_f32(const int32_t* argmax, int bins, int C, const float* const* objectness, const int* counts, int B,
+                       float* out, void* stream) {
+  jtsm::ImageRows im;
+  int M;
+  if (int rc = pack_rows(reinterpret_cast<const void* const*>(objectness), counts, B, im, M)) return rc;
+  JTSM_REQUIRE(bins > 0 && C > 0, "roi_scale: bins %d, channels %d", bins, C);
+  if (M == 0) return JTSM_OK;
+  hipLaunchKernelGGL(jtsm::roi_scale_kernel, dim3(jtsm::ceil_div(M, 256)), dim3(256), 0, jtsm::as_stream(stream), argmax, bins, C, im,
+                     B, M, out);
+  JTSM_CHECK_LAUNCH("roi_scale");
+  return JTSM_OK;
+}
+
+size_t jtsm_image_labels_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * 256 * sizeof(int); }
+
+int jtsm_image_labels(const int64_t* const* gt_classes, const int* counts, int B, int num_classes, const void* sem_seg,
+                      int sem_elem_bytes, long pixels, int num_stuff, int stuff_offset, float* oh_things,
+                      int32_t* things_cls, int32_t* things_cnt, float* oh_stuff, int32_t* stuff_cls, int32_t* stuff_cnt,
+                      void* workspace, void* stream) {
+  jtsm::ImageRows im;
+  int total;
+  if (int rc = pack_rows(reinterpret_cast<const void* const*>(gt_classes), counts, B, im, total)) return rc;
+  JTSM_REQUIRE(num_classes >= 1 && num_classes <= 256, "image labels: 1..256 thing classes, got %d", num_classes);
+  int* flags = nullptr;
+  if (sem_seg) {
+    JTSM_REQUIRE(num_stuff >= 2 && num_stuff <= 256 && pixels > 0 && workspace && (sem_elem_bytes == 8 || sem_elem_bytes == 1),
+                 "image labels: stuff classes %d, %ld pixels, %d-byte labels", num_stuff, pixels, sem_elem_bytes);
+    flags = reinterpret_cast<int*>(workspace);
+    JTSM_CHECK_HIP(hipMemsetAsync(flags, 0, jtsm_image_labels_workspace_bytes(B), jtsm::as_stream(stream)));
+    const dim3 grid((unsigned)(pixels / 256 / 16 < 1 ? 1 : (pixels / 256 / 16 > 256 ? 256 : pixels / 256 / 16)), B);
+    if (sem_elem_bytes == 8)
+      hipLaunchKernelGGL((jtsm::sem_label_flags_kernel<long>), grid, dim3(256), 0, jtsm::as_stream(stream),
+                         reinterpret_cast<const long*>(sem_seg), pixels, flags);
+    else
+      hipLaunchKernelGGL((jtsm::sem_label_flags_kernel<unsigned char>), grid, dim3(256), 0, jtsm::as_stream(stream),
+                         reinterpret_cast<const unsigned char*>(sem_seg), pixels, flags);
+    JTSM_CHECK_LAUNCH("sem_label_flags");
+  }
+  hipLaunchKernelGGL(jtsm::image_class_lists_kernel, dim3(B), dim3(256), 0, jtsm::as_stream(stream), im, num_classes, flags, num_stuff,
+                     stuff_offset, oh_things, things_cls, things_cnt, oh_stuff, stuff_cls, stuff_cnt);
+  JTSM_CHECK_LAUNCH("image_class_lists");
   return JTSM_OK;
 }
 

@@ -385,6 +385,9 @@ class _SemSegCE(torch.autograd.Function):
         L.check(L.lib().jtsm_semseg_ce_backward_f32(L.ptr(logits), ld, c, L.ptr(target), L.ptr(out), L.ptr(g),
                                                     L.ptr(dfull), L.ptr(wsb), n, hs, ws, scale,
                                                     C.c_long(ignore_index), L.stream()), "semseg_ce_backward")
+        if ld != c:
+            from .conv import ZERO_PADDED
+            setattr(dfull, ZERO_PADDED, True)   # (the kernel wrote zeros into channels c .. ld - 1)
         return dfull.permute(0, 3, 1, 2)[:, :c], None, None, None
 
 

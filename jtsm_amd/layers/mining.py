@@ -163,3 +163,77 @@ def paste_crop_targets(probs, rois, side, height, width, threshold=0.5):
     L.check(L.lib().jtsm_paste_crop_targets_f32(L.ptr(probs), L.ptr(rois), L.ptr(out), n, m, side, height, width,
                                                 L.f32(threshold), L.stream()), "paste_crop_targets")
     return out.to(torch.bool)
+
+
+# ---- label preparation (csrc/mining.hip, round 3): per-image inputs travel as pointers, no concatenation ----------
+MAX_IMAGES = 16
+
+
+def _image_rows(tensors, dtype):
+    """(pointer array, count array) of per-image device tensors for the `B pointers + counts` entry points; the
+    tensors are made contiguous / cast here and returned so that they outlive the launch."""
+    import ctypes as C
+    keep = [t.to(dtype).contiguous() for t in tensors]
+    ptrs = (C.c_void_p * len(keep))(*[t.data_ptr() if t.numel() else None for t in keep])
+    counts = (C.c_int * len(keep))(*[int(t.shape[0]) for t in keep])
+    return ptrs, counts, keep
+
+
+@torch.no_grad()
+def pooler_rois_levels(box_tensors, min_level, max_level, canonical_box_size, canonical_level):
+    """list of per-image (n_i, 4) float32 boxes -> (rois (M,5) float32, level (M,) int32): detectron2's
+    convert_boxes_to_pooler_format + assign_boxes_to_levels in one launch, the same levels bit for bit."""
+    import ctypes as C
+    L.require_gpu(*box_tensors)
+    ptrs, counts, keep = _image_rows([b.reshape(-1, 4) for b in box_tensors], torch.float32)
+    M, dev = sum(int(t.shape[0]) for t in keep), keep[0].device
+    rois = torch.empty((M, 5), dtype=torch.float32, device=dev)
+    level = torch.empty(M, dtype=torch.int32, device=dev)
+    L.check(L.lib().jtsm_pooler_rois_levels_f32(ptrs, counts, len(keep), int(min_level), int(max_level),
+                                                C.c_float(canonical_box_size), C.c_float(canonical_level), L.ptr(rois),
+                                                L.ptr(level), L.stream()), "pooler_rois_levels")
+    return rois, level
+
+
+@torch.no_grad()
+def roi_scale(argmax, objectness_list):
+    """bins / (valid bins + 1) * (objectness + 1) per roi; argmax (M,C,P,P) int32 channels-last (MOIPool's)."""
+    L.require_gpu(argmax)
+    M, Cc, ph, pw = argmax.shape
+    assert argmax.dtype == torch.int32 and argmax.is_contiguous(memory_format=torch.channels_last)
+    ptrs, counts, keep = _image_rows(objectness_list, torch.float32)
+    assert sum(int(t.shape[0]) for t in keep) == M
+    out = torch.empty(M, dtype=torch.float32, device=argmax.device)
+    L.check(L.lib().jtsm_roi_scale_f32(L.ptr(argmax), ph * pw, Cc, ptrs, counts, len(keep), L.ptr(out), L.stream()),
+            "roi_scale")
+    return out
+
+
+@torch.no_grad()
+def image_labels(gt_classes_list, num_classes, gt_sem_seg=None, num_stuff=0, stuff_offset=0):
+    """-> (oh_things (B,C) float32, things_cls (B,C) int32, things_cnt (B,) int32, oh_stuff, stuff_cls, stuff_cnt);
+    the stuff triple is None without `gt_sem_seg` ((B,H,W) int64 or uint8)."""
+    L.require_gpu(*gt_classes_list)
+    B, dev = len(gt_classes_list), gt_classes_list[0].device
+    ptrs, counts, keep = _image_rows(gt_classes_list, torch.int64)
+    import ctypes as C
+
+    def triple(width):      # one allocation carved into (presence (B,width) float32, list (B,width) int32, count (B,) int32)
+        words = torch.empty(B * (2 * width + 1), dtype=torch.int32, device=dev)
+        return (words[:B * width].view(torch.float32).view(B, width), words[B * width:2 * B * width].view(B, width),
+                words[2 * B * width:])
+
+    oh_t, cls_t, cnt_t = triple(num_classes)
+    oh_s = cls_s = cnt_s = sem = ws = None
+    esz = pixels = 0
+    if gt_sem_seg is not None:
+        sem = gt_sem_seg if gt_sem_seg.dtype in (torch.int64, torch.uint8) else gt_sem_seg.to(torch.int64)
+        sem = sem.contiguous()
+        assert sem.shape[0] == B
+        esz, pixels = sem.element_size(), sem[0].numel()
+        oh_s, cls_s, cnt_s = triple(num_stuff - 1)
+        ws = torch.empty(L.lib().jtsm_image_labels_workspace_bytes(B), dtype=torch.uint8, device=dev)
+    L.check(L.lib().jtsm_image_labels(ptrs, counts, B, num_classes, L.ptr(sem), esz, C.c_long(pixels), num_stuff,
+                                      stuff_offset, L.ptr(oh_t), L.ptr(cls_t), L.ptr(cnt_t), L.ptr(oh_s), L.ptr(cls_s),
+                                      L.ptr(cnt_s), L.ptr(ws), L.stream()), "image_labels")
+    return oh_t, cls_t, cnt_t, oh_s, cls_s, cnt_s

@@ -85,11 +85,14 @@ class _MOIPool(Function):
                                           ctx.output_size[1], oh_labels, superpixels)
         ctx.save_for_backward(roi, argmax)
         ctx.mark_non_differentiable(argmax)
+        ctx.set_materialize_grads(False)   # no zero-filled "gradient" for the arg-max output
         return output, argmax
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output, _grad_argmax=None):
+        if grad_output is None:
+            return None, None, None, None, None, None
         rois, argmax = ctx.saved_tensors
         bs, ch, h, w = ctx.input_shape
         grad_input = moi_pool_backward(grad_output, rois, argmax, ctx.spatial_scale,

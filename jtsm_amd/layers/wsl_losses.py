@@ -43,11 +43,14 @@ class _MILLoss(Function):
         ctx.save_for_backward(c, d, bag_offsets, ws)
         ctx.cfg = (ldc, nc, nb, max_bag_rows)
         ctx.mark_non_differentiable(scores, probs)
+        ctx.set_materialize_grads(False)   # no zero-filled "gradients" for the two non-differentiable outputs
         return loss, scores, probs
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_loss, _gs, _gp):
+        if g_loss is None:
+            return None, None, None, None, None, None
         c, d, bag_offsets, ws = ctx.saved_tensors
         ldc, nc, nb, mbr = ctx.cfg
         dc = torch.empty((c.shape[0], nc), dtype=torch.float32, device=c.device)

@@ -21,6 +21,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from ..layers.mining import MAX_IMAGES, pooler_rois_levels
 from ..layers.moi_pool import MOIPool
 from ..layers.roi_align import ROIAlign
 from ..layers.roi_align_rotated import ROIAlignRotated
@@ -127,11 +128,15 @@ class _MOILevels(Function):
         ctx.save_for_backward(rois, roi_level, arg)
         ctx.cfg = (res, [tuple(f.shape) for f in feats], [float(x) for x in scales])
         ctx.mark_non_differentiable(arg)
+        # (left on, autograd hands backward a ZERO gradient for the arg-max output: a 50 M-element int32 fill per step)
+        ctx.set_materialize_grads(False)
         return out, arg
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g, _ga=None):
+        if g is None:
+            return (None,) * (6 + len(ctx.cfg[1]))
         rois, roi_level, arg = ctx.saved_tensors
         res, shapes, scales = ctx.cfg
         g = g.contiguous(memory_format=CL)
@@ -216,7 +221,15 @@ class ROIPooler(nn.Module):
             "unequal value, x[0] batch dim 0 is {}, but box_list has length {}".format(x[0].size(0), len(box_lists))
         if len(box_lists) == 0:
             return torch.zeros((0, x[0].shape[1]) + self.output_size, device=x[0].device, dtype=x[0].dtype)
-        pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
+        # rois and levels in one launch (layers/mining.py: pooler_rois_levels) when the boxes are float32 on the device;
+        # the tensor-op helpers above stay as the definition it is tested against and serve every other case
+        fused = (level_ids is None and len(box_lists) <= MAX_IMAGES and
+                 all(b.tensor.is_cuda and b.tensor.dtype == torch.float32 and b.tensor.shape[-1] == 4 for b in box_lists))
+        if fused:
+            pooler_fmt_boxes, fused_levels = pooler_rois_levels([b.tensor for b in box_lists], self.min_level, self.max_level,
+                                                                self.canonical_box_size, self.canonical_level)
+        else:
+            pooler_fmt_boxes = convert_boxes_to_pooler_format(box_lists)
         moi = superpixels is not None
         if moi:
             labels, sp = moi_label_inputs(oh_labels_list, superpixels)
@@ -224,12 +237,15 @@ class ROIPooler(nn.Module):
             if moi:
                 return self.level_poolers[0](x[0], pooler_fmt_boxes, labels, sp)
             return self.level_poolers[0](x[0], pooler_fmt_boxes)
-        if level_ids is not None:
-            level_assignments = cat(level_ids).to(torch.int64).clamp(0, num_level_assignments - 1)
+        if fused:
+            roi_level = fused_levels
         else:
-            level_assignments = assign_boxes_to_levels(box_lists, self.min_level, self.max_level,
-                                                       self.canonical_box_size, self.canonical_level)
-        roi_level = level_assignments.to(torch.int32).contiguous()
+            if level_ids is not None:
+                level_assignments = cat(level_ids).to(torch.int64).clamp(0, num_level_assignments - 1)
+            else:
+                level_assignments = assign_boxes_to_levels(box_lists, self.min_level, self.max_level,
+                                                           self.canonical_box_size, self.canonical_level)
+            roi_level = level_assignments.to(torch.int32).contiguous()
         rois = pooler_fmt_boxes.to(torch.float32).contiguous()
         if moi:
             return _MOILevels.apply(rois, roi_level, self.output_size[0], self.scales, labels, sp, *x)

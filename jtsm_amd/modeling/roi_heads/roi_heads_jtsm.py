@@ -33,8 +33,10 @@ import torch
 import torch.nn.functional as F
 
 from ...layers.conv import linear_fused, linear_fused_split
-from ...layers.mining import (match_label, mine_top1, near_targets, pad_class_lists, paint_sem_seg,
-                              paint_sem_seg_evidence, paste_crop_targets, rect_mask_targets, row_lse, sp_mask_targets)
+from ...layers.mining import (MAX_IMAGES, image_labels, match_label, mine_top1, near_targets, pad_class_lists,
+                              paint_sem_seg, paint_sem_seg_evidence, paste_crop_targets, rect_mask_targets, row_lse,
+                              sp_mask_targets)
+from ...layers.mining import roi_scale as fused_roi_scale
 from ...layers.roi_align import roi_align
 from ...layers.shape_spec import ShapeSpec
 from ...structures import Boxes, ImageList, Instances
@@ -234,12 +236,20 @@ class JTSMROIHeads(ROIHeads):
         assert targets, "'targets' argument is required during training"
         self.proposals, self.superpixels, self.images = proposals, superpixels, images
         # image-level labels, entirely on the device (presence matrices + padded class lists with counts)
-        self.gt_classes_img_oh = present_things(targets, self.num_classes)
-        self.things_cls, self.things_cnt = class_lists(self.gt_classes_img_oh)
         self.has_stuff = gt_sem_seg is not None
-        if self.has_stuff:
-            self.gt_classes_img_oh_stuff = present_stuff(gt_sem_seg, self.num_classes_stuff)
-            self.stuff_cls, self.stuff_cnt = class_lists(self.gt_classes_img_oh_stuff, offset=self.num_classes)
+        if (len(targets) <= MAX_IMAGES and targets[0].gt_classes.is_cuda and self.num_classes <= 256 and
+                (not self.has_stuff or (gt_sem_seg.dim() == 3 and self.num_classes_stuff <= 256))):
+            # three launches (layers/mining.py: image_labels); the tensor-op helpers below define what it returns
+            (self.gt_classes_img_oh, self.things_cls, self.things_cnt, oh_s, cls_s, cnt_s) = image_labels(
+                [t.gt_classes for t in targets], self.num_classes, gt_sem_seg, self.num_classes_stuff, self.num_classes)
+            if self.has_stuff:
+                self.gt_classes_img_oh_stuff, self.stuff_cls, self.stuff_cnt = oh_s, cls_s, cnt_s
+        else:
+            self.gt_classes_img_oh = present_things(targets, self.num_classes)
+            self.things_cls, self.things_cnt = class_lists(self.gt_classes_img_oh)
+            if self.has_stuff:
+                self.gt_classes_img_oh_stuff = present_stuff(gt_sem_seg, self.num_classes_stuff)
+                self.stuff_cls, self.stuff_cnt = class_lists(self.gt_classes_img_oh_stuff, offset=self.num_classes)
         losses = self._forward_box(features, proposals)
         if self.mask_on:
             self._mask_prepare()
@@ -262,10 +272,14 @@ class JTSMROIHeads(ROIHeads):
         box_features, argmax = self.box_pooler(feats, [x.proposal_boxes for x in proposals],
                                                oh_labels_list=self._evidence[0], superpixels=self._evidence[1])
         with torch.no_grad():
-            bins = argmax.size(2) * argmax.size(3)
-            nvalid = (argmax[:, 0, :, :] != -1).reshape(argmax.size(0), -1).sum(dim=1).to(dtype=torch.float32)
-            roi_scale = bins * (nvalid + 1).reciprocal()
-            roi_scale = roi_scale * torch.cat([x.objectness_logits + 1 for x in proposals], dim=0)
+            if (argmax.is_cuda and argmax.dtype == torch.int32 and len(proposals) <= MAX_IMAGES and
+                    argmax.is_contiguous(memory_format=torch.channels_last)):
+                roi_scale = fused_roi_scale(argmax, [x.objectness_logits for x in proposals])   # one launch
+            else:
+                bins = argmax.size(2) * argmax.size(3)
+                nvalid = (argmax[:, 0, :, :] != -1).reshape(argmax.size(0), -1).sum(dim=1).to(dtype=torch.float32)
+                roi_scale = bins * (nvalid + 1).reciprocal()
+                roi_scale = roi_scale * torch.cat([x.objectness_logits + 1 for x in proposals], dim=0)
         # reference: (features * mask_scale) * (objectness + 1), two passes; here one combined factor, which the box
         # head folds into the plane split in front of fc1 and into fc1's data-gradient epilogue (no multiply pass)
         if getattr(self.box_head, "takes_roi_scale", False):
