@@ -199,8 +199,8 @@ size_t jtsm_moi_pool_backward_levels_workspace_bytes(const int* H, const int* W,
 int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                       const int32_t* argmax, float* const* grad_inputs, const int* H,
                                       const int* W, const float* scales, int nlevels, int B, int C, int M,
-                                      int pooled_h, int pooled_w, void* workspace, size_t workspace_bytes,
-                                      void* stream);
+                                      int pooled_h, int pooled_w, int accumulate, void* workspace,
+                                      size_t workspace_bytes, void* stream);
 
 /* mois (M,H,W) int32 exactly as MoIForward (MOIPool_cuda.cu:138-215) would write it;
  * test/diagnostic entry, same workspace contract as the forward. */
@@ -647,11 +647,14 @@ int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois,
                                       int pooled_w, int sampling_ratio, int aligned, void* stream);
 /* All levels' gradient maps in ONE call (the backward of ROIPooler's level loop, detectron2/modeling/poolers.py:236-247):
  * grad_inputs[l] (nullable: that level needs no gradient) is the (B,H[l],W[l],C) NHWC map of the rois with
- * roi_level[m] == l.  The tiles of every level are workgroups of one launch. */
+ * roi_level[m] == l.  The tiles of every level are workgroups of one launch.
+ * accumulate != 0 (here and in jtsm_moi_pool_backward_levels_f32): the maps already hold a gradient — what autograd
+ * would add afterwards, another consumer's term — and this call adds to it in place (nothing is cleared; every cell's
+ * read-add-write belongs to one thread, still no atomics in the gather forms, still reproducible). */
 int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                        float* const* grad_inputs, const int* H, const int* W, const float* scales,
                                        int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,
-                                       int aligned, void* stream);
+                                       int aligned, int accumulate, void* stream);
 int jtsm_moi_pool_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
                                     int level, const int32_t* oh_labels, const int32_t* superpixels,
                                     float* output, int32_t* argmax, void* workspace, int B, int C,

@@ -1621,10 +1621,12 @@ int jtsm_conv2d_backward_data_f32(const float* dy, const float* w, float* dx,
   p.e.residual = accumulate; p.e.mask = relu_mask;
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
-  if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask) {
+  if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && (!accumulate || accumulate == dx) && !relu_mask) {
     // strided 1x1: only every stride-th input pixel receives gradient.  Zero dX, then run the dense
     // GEMM over the OUTPUT pixels (a 1x1/stride-1 problem on the (Ho,Wo) grid) and scatter its rows.
-    JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
+    // (accumulate == dx: dX holds a gradient already and the scattered rows are added to it in place — the epilogue
+    // reads its residual at the scattered position — while the pixels in between keep what they hold.)
+    if (!accumulate) JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
     p.scatter = 1; p.sc_Ho = p.s.Ho; p.sc_Wo = p.s.Wo; p.sc_H = p.s.H; p.sc_W = p.s.W; p.sc_stride = p.s.stride;
     p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;
     p.M = p.s.Bn * p.s.Ho * p.s.Wo;
@@ -1803,8 +1805,8 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
   JTSM_REQUIRE(NP == 1 || (dx_hi == nullptr) == (dx_lo == nullptr), "conv backward-data bf16x3: give both output planes or neither");
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
-  const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && !accumulate && !relu_mask &&
-                       !gate_plane && !row_scale && dx;
+  const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && (!accumulate || accumulate == dx) &&
+                       !relu_mask && !gate_plane && !row_scale && dx;   // (accumulate == dx: see jtsm_conv2d_backward_data_f32)
   JTSM_REQUIRE(!row_scale || (p.N % 4 == 0 && aligned16(dx)), "conv backward-data: a row scale needs in_c %% 4 == 0");
   if (dx_hi) {   // planes of the finished gradient (e.g. already gated by relu_mask) for the next layer's contractions
     JTSM_REQUIRE(!scatter, "conv backward-data bf16x3: output planes are not produced by the strided 1x1 scatter path");
@@ -1813,7 +1815,7 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
     p.out_hi = dx_hi; p.out_lo = dx_lo;
   }
   if (scatter) {
-    JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
+    if (!accumulate) JTSM_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)p.M * p.N * sizeof(float), st));
     p.scatter = 1; p.sc_Ho = p.s.Ho; p.sc_Wo = p.s.Wo; p.sc_H = p.s.H; p.sc_W = p.s.W; p.sc_stride = p.s.stride;
     p.s.H = p.s.Ho; p.s.W = p.s.Wo; p.s.stride = 1;
     p.M = p.s.Bn * p.s.Ho * p.s.Wo;

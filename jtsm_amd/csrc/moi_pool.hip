@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
     const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
     const int* __restrict__ counts, int nlevels, const int* __restrict__ plan, const int* __restrict__ census,
-    int heavy_min) {
+    int heavy_min, int accumulate) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 cells][256 channels]
   __shared__ int roi_list[256];
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   const int load = census[blockIdx.x];
   const bool fallback = plan[0] > kCensusLimit;   // too many rois on one tile somewhere: the scatter form adds into zeros
   if (load == 0 || fallback) {
+    if (accumulate) return;   // the map holds another consumer's gradient: nothing to add here (the scatter form adds to it)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int i = t; i < kTile * kTile * 64; i += 256) {
       const int cell = i >> 6, y = y0 + cell / kTile, x = x0 + cell % kTile;
@@ -506,7 +507,11 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   __syncthreads();
   for (int y = y0; y <= y1; ++y)
     for (int x = x0; x <= x1; ++x)
-      out[((size_t)y * W + x) * C + c] = acc[((y - y0) * kTile + (x - x0)) * 256 + t];
+      {
+        float* dst = out + ((size_t)y * W + x) * C + c;
+        const float v = acc[((y - y0) * kTile + (x - x0)) * 256 + t];
+        *dst = accumulate ? *dst + v : v;
+      }
 }
 
 constexpr int kCopies = 4;
@@ -515,7 +520,7 @@ constexpr int kPairCapBusy = 2048;
 __global__ __launch_bounds__(1024) void moi_pool_bwd_busy(
     const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
     const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
-    const int* __restrict__ counts, int nlevels, const int* __restrict__ plan) {
+    const int* __restrict__ counts, int nlevels, const int* __restrict__ plan, int accumulate) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [kCopies][kQuad * kQuad cells][256 channels]
   __shared__ int roi_list[256];
@@ -641,7 +646,9 @@ __global__ __launch_bounds__(1024) void moi_pool_bwd_busy(
         const int y = y0 + cell / kQuad, x = x0 + cell % kQuad;
         if (y > y1 || x > x1) continue;
         const float* a = acc + cell * 256 + cc;
-        out[((size_t)y * W + x) * C + cb + cc] = (a[0] + a[kCells * 256]) + (a[2 * kCells * 256] + a[3 * kCells * 256]);
+        float* dst = out + ((size_t)y * W + x) * C + cb + cc;
+        const float v = (a[0] + a[kCells * 256]) + (a[2 * kCells * 256] + a[3 * kCells * 256]);
+        *dst = accumulate ? *dst + v : v;
       }
     }
   }
@@ -948,7 +955,7 @@ size_t jtsm_moi_pool_backward_levels_workspace_bytes(const int* H, const int* W,
 int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                       const int32_t* argmax, float* const* grad_inputs, const int* H, const int* W,
                                       const float* scales, int nlevels, int B, int C, int M, int pooled_h, int pooled_w,
-                                      void* workspace, size_t workspace_bytes, void* stream) {
+                                      int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   JTSM_REQUIRE(nlevels > 0 && nlevels <= kMaxLevels && grad_inputs && H && W, "moi_pool levels backward: bad level table");
   JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0 && C % 4 == 0,
                "moi_pool levels backward: bad sizes (C %% 4 must be 0)");
@@ -990,9 +997,10 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
     // the plan: the census maximum and the heavy tiles (4 quadrant entries each), heaviest first
     hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, st, census, ntile, plan, moi_heavy_min(), 4);
     hipLaunchKernelGGL(moi_pool_bwd_tiled, dim3(blocks, C / 256), dim3(256), kTile * kTile * 256 * sizeof(float), st, lv, tl,
-                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, census, moi_heavy_min());
+                       grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, census, moi_heavy_min(),
+                       accumulate);
     hipLaunchKernelGGL(moi_pool_bwd_busy, dim3(256), dim3(1024), (size_t)kCopies * kQuad * kQuad * 256 * sizeof(float), st,
-                       lv, tl, grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan);
+                       lv, tl, grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, accumulate);
     // (returns at once unless the census sent the gather home)
     hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(std::min(ceil_div((long)M * pooled_h * pooled_w, 4), 8192)), dim3(256), 0,
                        st, lv, grad, rois, argmax, C, M, pooled_h * pooled_w, roi_level, nlevels, plan, kCensusLimit);
@@ -1000,7 +1008,7 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
     return JTSM_OK;
   }
   for (int l = 0; l < nlevels; ++l) {
-    if (!grad_inputs[l]) continue;   // a level whose gradient is not wanted
+    if (!grad_inputs[l] || accumulate) continue;   // a level whose gradient is not wanted / maps that hold a gradient already
     JTSM_CHECK_HIP(hipMemsetAsync(grad_inputs[l], 0, (size_t)B * H[l] * W[l] * C * sizeof(float), st));
   }
   if ((long)M * C == 0) return JTSM_OK;

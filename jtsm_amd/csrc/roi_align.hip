@@ -284,7 +284,7 @@ template <int TILE, int NBLK>
 __global__ __launch_bounds__(256 * NBLK) void align_bwd_gather(
     const float* __restrict__ grad, const float* __restrict__ rois, const AlignLevels lv, int C, int M, int PH, int PW,
     int sr, int aligned, const int* __restrict__ plan, int census_lim, int fan, const int4* __restrict__ reach_in,
-    const int* __restrict__ meta_in) {
+    const int* __restrict__ meta_in, int accumulate) {
 #pragma clang fp contract(off)
   __shared__ int roi_list[256];
   __shared__ float roi_row[256][5];
@@ -491,7 +491,13 @@ __global__ __launch_bounds__(256 * NBLK) void align_bwd_gather(
         const int y = y0 + cell / TILE, x = x0 + cell % TILE;
         if (y > y1 || x > x1 || cc >= nblk * 64) continue;
         const float* src = &copies[1][cell][cc];
-        *reinterpret_cast<float4*>(out + ((size_t)y * W + x) * C + cb0 + cc) = make_float4(src[0], src[1], src[2], src[3]);
+        float4* dst = reinterpret_cast<float4*>(out + ((size_t)y * W + x) * C + cb0 + cc);
+        float4 v = make_float4(src[0], src[1], src[2], src[3]);
+        if (accumulate) {   // the maps hold another consumer's gradient already (same cell, same thread: plain read-add-write)
+          const float4 o = *dst;
+          v = make_float4(o.x + v.x, o.y + v.y, o.z + v.z, o.w + v.w);
+        }
+        *dst = v;
       }
       __syncthreads();                      // the copies are rewritten by the next job
     }
@@ -621,7 +627,7 @@ int launch_forward(const T* in, const T* rois, T* out, int B, int C, int H, int 
 // Gather form with the census guard over a level table: both forms are launched, the device-side census lets one of
 // them return at once.
 static int align_backward_gather(const float* grad, const float* rois, AlignLevels& lv, int B, int C, int M, int PH,
-                                 int PW, int sr, int aligned, const int* roi_level, hipStream_t st) {
+                                 int PW, int sr, int aligned, const int* roi_level, hipStream_t st, bool accumulate = false) {
   int ntile = 0;
   for (int l = 0; l < lv.n; ++l) {
     lv.tiles_x[l] = ceil_div(lv.W[l], kTile);
@@ -631,7 +637,8 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
   }
   lv.first_tile[lv.n] = ntile;
   // every map cleared first: the gather writes only the tiles some roi can reach, the scatter form adds into zeros
-  for (int l = 0; l < lv.n; ++l)
+  // (accumulate: the maps already hold a gradient — both forms add to it and nothing is cleared)
+  for (int l = 0; l < lv.n && !accumulate; ++l)
     JTSM_CHECK_HIP(hipMemsetAsync(lv.gin[l], 0, (size_t)B * lv.H[l] * lv.W[l] * C * sizeof(float), st));
   int* census = nullptr;
   // census, then the launch plan (maximum, number of jobs, C / 64 (tile, channel block) jobs per reachable tile), then
@@ -647,7 +654,7 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
                      roi_level, lv, census, reach, meta);
   hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, st, census, ntile, plan, 1, fan);
   hipLaunchKernelGGL((align_bwd_gather<8, 1>), dim3(std::min(ntile * fan, 512)), dim3(256), 0, st, grad, rois, lv, C, M, PH,
-                     PW, sr, aligned, plan, census_limit(), fan, reach, meta);
+                     PW, sr, aligned, plan, census_limit(), fan, reach, meta, accumulate ? 1 : 0);
   constexpr int V = WideVec<float>::value;
   const int blocks = ceil_div((long)M * PH * PW, 4);
   for (int l = 0; l < lv.n; ++l) {   // the scatter form, level by level (each returns at once unless the census says so)
@@ -668,7 +675,7 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
 template <typename T, bool ROT>
 int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, int W, int M,
                     T scale, int PH, int PW, int sr, int aligned, int layout, void* stream,
-                    const int* roi_level = nullptr, int level = 0) {
+                    const int* roi_level = nullptr, int level = 0, bool accumulate = false) {
   JTSM_REQUIRE(B >= 0 && C >= 0 && H >= 0 && W >= 0 && M >= 0 && PH > 0 && PW > 0,
                "roi_align backward: negative size");
   JTSM_REQUIRE(layout == JTSM_NCHW || layout == JTSM_NHWC, "roi_align: unknown layout %d", layout);
@@ -685,9 +692,9 @@ int launch_backward(const T* grad, const T* rois, T* gin, int B, int C, int H, i
     lv.gin[0] = reinterpret_cast<float*>(gin); lv.H[0] = H; lv.W[0] = W; lv.scale[0] = (float)scale;
     lv.level_id[0] = level;
     return align_backward_gather(reinterpret_cast<const float*>(grad), reinterpret_cast<const float*>(rois), lv, B, C, M,
-                                 PH, PW, sr, aligned, roi_level, st);
+                                 PH, PW, sr, aligned, roi_level, st, accumulate);
   }
-  JTSM_CHECK_HIP(hipMemsetAsync(gin, 0, in_elems * sizeof(T), st));
+  if (!accumulate) JTSM_CHECK_HIP(hipMemsetAsync(gin, 0, in_elems * sizeof(T), st));
   if ((long)M * C * PH * PW == 0) return JTSM_OK;  // empty gradient: zeros (ROIAlign_cuda.cu:402-405)
   JTSM_REQUIRE(grad && rois, "roi_align backward: null pointer");
   if (layout == JTSM_NHWC) {
@@ -1073,7 +1080,7 @@ int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois, cons
 int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                        float* const* grad_inputs, const int* H, const int* W, const float* scales,
                                        int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,
-                                       int aligned, void* stream) {
+                                       int aligned, int accumulate, void* stream) {
   JTSM_REQUIRE(nlevels > 0 && nlevels <= kAlignLevels && grad_inputs && H && W && scales,
                "roi_align levels: bad level table");
   JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0, "roi_align levels: negative size");
@@ -1091,12 +1098,14 @@ int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, con
       lv.gin[k] = grad_inputs[l]; lv.H[k] = H[l]; lv.W[k] = W[l]; lv.scale[k] = scales[l]; lv.level_id[k] = l;
     }
     if (lv.n == 0) return JTSM_OK;
-    return align_backward_gather(grad, rois, lv, B, C, M, pooled_h, pooled_w, sampling_ratio, aligned, roi_level, st);
+    return align_backward_gather(grad, rois, lv, B, C, M, pooled_h, pooled_w, sampling_ratio, aligned, roi_level, st,
+                                 accumulate != 0);
   }
   for (int l = 0; l < nlevels; ++l) {
     if (!grad_inputs[l]) continue;
     const int rc = launch_backward<float, false>(grad, rois, grad_inputs[l], B, C, H[l], W[l], M, scales[l], pooled_h,
-                                                 pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, l);
+                                                 pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, l,
+                                                 accumulate != 0);
     if (rc) return rc;
   }
   return JTSM_OK;

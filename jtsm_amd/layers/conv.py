@@ -14,6 +14,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from . import grad_fan
 
 CL = torch.channels_last
 
@@ -184,6 +185,11 @@ def planes_put(t, buf):
     # planes mirror the flat memory of a DENSE tensor, so any dense view of the same bytes shares them
     _PLANES[(t.data_ptr(), t.numel())] = (t.detach(), t._version, buf)
     _planes_bytes += 8 * t.numel()
+
+
+def planes_forget(t):
+    """A kernel is about to add into t through its raw pointer (no version bump): cached planes of it are stale."""
+    _PLANES.pop((t.data_ptr(), t.numel()), None)
 
 
 def planes_of(t, grad=False):
@@ -545,12 +551,19 @@ def conv2d_forward(x, w, stride=1, pad=0, dil=1, scale=None, bias=None, residual
 
 
 def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, accumulate=None,
-                         relu_mask=None, emit_planes=False):
+                         relu_mask=None, emit_planes=False, into=None):
+    """`into`: a gradient map of x's shape (channels-last fp32) that this data gradient is ADDED to in place — the
+    epilogue's residual operand and its result are the same piece of the same thread (layers/grad_fan.py)."""
     _check(dy, w, kscale, accumulate, relu_mask)
     dy, w = _cl(dy), _cl(w)
     pl = _plan(x_shape, w.shape, stride, pad, dil)
     s = pl.s
-    dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device, memory_format=CL)
+    if into is not None:
+        assert accumulate is None and tuple(into.shape) == tuple(x_shape) and into.is_contiguous(memory_format=CL)
+        planes_forget(into)
+        dx = accumulate = into
+    else:
+        dx = torch.empty(tuple(x_shape), dtype=dy.dtype, device=dy.device, memory_format=CL)
     if accumulate is not None:
         accumulate = _cl(accumulate)
     if relu_mask is not None:
@@ -562,8 +575,8 @@ def conv2d_backward_data(dy, w, x_shape, stride=1, pad=0, dil=1, kscale=None, ac
         gh, gl = _hl(planes_of(dy, grad=True))
         wbuf = _weight_planes(w, True, kscale)   # the per-row scale rides along in the transposing split
         wh, wl = _hl(wbuf)
-        scatter = s.kernel_h == 1 and s.kernel_w == 1 and s.pad == 0 and s.stride > 1 and accumulate is None and \
-            relu_mask is None
+        scatter = s.kernel_h == 1 and s.kernel_w == 1 and s.pad == 0 and s.stride > 1 and \
+            (accumulate is None or into is not None) and relu_mask is None
         dbuf = _planes_buf(dx.numel(), dx.device) if (emit_planes and s.in_c % 8 == 0 and not scatter) else None
         dh, dl = _hl(dbuf)
         if MATH == "f16":
@@ -791,7 +804,7 @@ def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=Fal
 
 
 def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
-                         row_scale=None, kscale=None, both=False):
+                         row_scale=None, kscale=None, both=False, into=None):
     """... kscale: per-output-channel factor folded into the weight rows (FrozenBN).  both: fp32 AND planes."""
     """g: PlaneTensor of the output gradient (gradient planes: times 2^GRAD_SHIFT in fp16 mode); gate: PlaneTensor of
     the ReLU output the result is gated by (or None) -> the input gradient as fp32 tensor (fp32=True) or PlaneTensor."""
@@ -800,7 +813,13 @@ def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=
     if not pl.x3[1]:
         raise RuntimeError("planes_backward_data: shape is not eligible for the plane arithmetic")
     fp32 = fp32 or both
-    dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=g.device, memory_format=CL) if fp32 else None
+    if into is not None:   # add into an existing gradient map in place (see conv2d_backward_data)
+        assert fp32 and not both and accumulate is None and gate is None and tuple(into.shape) == tuple(x_shape) and \
+            into.is_contiguous(memory_format=CL)
+        planes_forget(into)
+        dx = accumulate = into
+    else:
+        dx = torch.empty(tuple(x_shape), dtype=torch.float32, device=g.device, memory_format=CL) if fp32 else None
     dp = PlaneTensor.empty(x_shape, g.device) if (both or not fp32) else None
     gh, gl = _hl(g.buf)
     wh, wl = _hl(_weight_planes(_cl(w), True, kscale))
@@ -1137,6 +1156,9 @@ def _wgrad_bias_call(pl, gh, gl, xh, xl, out, bias_out, row_scale, fresh, device
             C.c_size_t(nbytes), L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_bias_bf16x3")
 
 
+_FAN_CLAIMS = []   # the fan record of the next _ConvFused input (claimed by conv2d_fused on the caller's tensor object)
+
+
 class _ConvFused(Function):
     """y = relu?(conv(x, w) * scale + bias + residual); scale/bias are constants of the op
     (FrozenBN statistics or a conv bias treated by the caller), residual gets dy * relu'."""
@@ -1145,6 +1167,7 @@ class _ConvFused(Function):
     def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True,
                 emit_dx_planes=False):
         y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
+        ctx.fan = _FAN_CLAIMS.pop() if _FAN_CLAIMS else None   # (conv2d_fused claimed the input's fan view, if it is one)
         ctx.emit_dx_planes = emit_dx_planes   # the input's gradient is the dy of another contraction (FPN laterals)
         ctx.cfg = (stride, pad, dil, relu, bias_needs_grad, tuple(x.shape), tuple(w.shape))
         ctx.has_res = residual is not None
@@ -1170,11 +1193,17 @@ class _ConvFused(Function):
         if ctx.needs_input_grad[0]:
             # fold the FrozenBN scale into the weight rows once (a few MB) so the data-gradient GEMM takes
             # the direct-to-LDS path, which cannot rescale operands on the fly
+            # another consumer of x wrote its gradient map already this backward pass: add into it (layers/grad_fan.py)
+            # (a gradient that other consumers add to is not final: its planes are nobody's operand)
+            sink = grad_fan.target(ctx.fan, xs, g.device)
             if MATH != "f32":   # (ineligible shapes fall through to the fp32 kernel's own kscale path)
-                dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale, emit_planes=ctx.emit_dx_planes)
+                dx = conv2d_backward_data(g, w, xs, stride, pad, dil, kscale=scale,
+                                          emit_planes=ctx.emit_dx_planes and ctx.fan is None, into=sink)
             else:
                 w_eff = w if scale is None else (w * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
-                dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil)
+                dx = conv2d_backward_data(g, w_eff, xs, stride, pad, dil, into=sink)
+            if sink is not None or grad_fan.offer(ctx.fan, dx):
+                dx = None      # (in the fan's record: autograd gets it from the fan node)
         want_db = bias_needs_grad and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
             if want_db:   # the bias gradient rides in the weight-gradient contraction
@@ -1222,6 +1251,8 @@ def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, di
     """Autograd-aware fused convolution.  An output-channel count that is not a multiple of 4 (54 sem-seg
     classes, the 1870-wide fused predictor) is zero-padded up for the kernels' 16-byte rows and the
     padding is sliced off the result (its gradient is zero by construction)."""
+    del _FAN_CLAIMS[:]
+    _FAN_CLAIMS.append(grad_fan.claim(x))
     o = w.shape[0]
     if o % 4:
         extra = 4 - o % 4

@@ -172,6 +172,7 @@ def max_pool_3x3_s2(x):
 class _Upsample2Add(torch.autograd.Function):
     @staticmethod
     def forward(ctx, top, lateral):
+        ctx.fan = _UP_CLAIMS.pop() if _UP_CLAIMS else None
         top, lateral = _cl4(top), _cl4(lateral)
         n, c, h, w = lateral.shape
         if top.shape != (n, c, h // 2, w // 2) or h % 2 or w % 2:
@@ -196,6 +197,11 @@ class _Upsample2Add(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gt = torch.empty((n, c, h // 2, w // 2), dtype=g.dtype, device=g.device, memory_format=CL)
             L.check(L.lib().jtsm_sum2x2_f32(L.ptr(g), L.ptr(gt), n, h // 2, w // 2, c, L.stream()), "sum2x2")
+            # `top` (an FPN merged map) is also read by its level's output convolution, which runs backward after this
+            # node and adds into this map (layers/grad_fan.py); were a map there already, autograd adds the two
+            from . import grad_fan
+            if grad_fan.target(ctx.fan, gt.shape, gt.device) is None and grad_fan.offer(ctx.fan, gt):
+                gt = None
         return gt, (g if ctx.needs_input_grad[1] else None)
 
 
@@ -238,8 +244,14 @@ def sum_tensors(xs):
     return _SumTensors.apply(*xs)
 
 
+_UP_CLAIMS = []    # the fan record (layers/grad_fan.py) of the next _Upsample2Add `top`
+
+
 def upsample2_add(top, lateral):
     """lateral + F.interpolate(top, scale_factor=2, mode="nearest")."""
+    from . import grad_fan
+    del _UP_CLAIMS[:]
+    _UP_CLAIMS.append(grad_fan.claim(top))
     return _Upsample2Add.apply(top, lateral)
 
 

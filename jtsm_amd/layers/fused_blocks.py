@@ -15,6 +15,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import conv as K
+from . import grad_fan
 from .elementwise import relu_backward
 
 CL = torch.channels_last
@@ -43,6 +44,7 @@ def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=No
 # consumer's term into it in place (it adds into a fresh tensor instead, which then fails the identity check below
 # and is gated the ordinary way).
 _PREGATED = [None]
+_FAN_CLAIMS = []    # the fan record (layers/grad_fan.py) of the next _BottleneckFn input
 
 
 def _drop_pregated():
@@ -81,6 +83,7 @@ class _BottleneckFn(Function):
     def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, ws, ss, bs, stride1, stride2, pad2, dil2, stride_s,
                 pregate=False):
         ctx.cfg = (stride1, stride2, pad2, dil2, stride_s)
+        ctx.fan = _FAN_CLAIMS.pop() if _FAN_CLAIMS else None   # (bottleneck_fused claimed x's fan view, if it is one)
         # x is the ReLU output of the previous block's node (bottleneck_fused tags it): its gate goes into this
         # block's conv1 data-gradient epilogue
         ctx.pregate = bool(pregate) and ws is None
@@ -177,12 +180,18 @@ class _BottleneckFn(Function):
                     _hand_pregated(dx)
                 else:
                     dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=g3, kscale=s1)
-            elif stride1 == 1 and stride_s == 1:
-                dxs = K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss)
-                dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, accumulate=dxs, kscale=s1)
             else:
-                dx = K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, kscale=s1)
-                dx = dx.add_(K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss))
+                # the input of a stage's first block is a res-stage output, which the FPN lateral reads too: when its
+                # gradient map exists already (layers/grad_fan.py) both paths add into it, and so does the second path
+                # into the first path's map otherwise — no separate addition either way
+                sink = grad_fan.target(ctx.fan, xs, dy.device)
+                if sink is None:
+                    dx = K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss)
+                else:
+                    K.planes_backward_data(g3p, ws, xs, stride_s, 0, 1, fp32=True, kscale=ss, into=sink)
+                K.planes_backward_data(d1, w1, xs, stride1, 0, 1, fp32=True, kscale=s1, into=sink if sink is not None else dx)
+                if sink is not None or grad_fan.offer(ctx.fan, dx):
+                    dx = None
         if ws is not None:   # the first block of a stage is the last of it to run backward: launch the stage's groups
             K.flush_deferred_weight_gradients()
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
@@ -204,6 +213,8 @@ def _plane_block_ok(x, w1, w2, w3, ws):
 def bottleneck_fused(x, w1, sb1, w2, sb2, w3, sb3, ws, sbs, stride1, stride2, pad2, dil2, stride_s):
     ss, bs = sbs if sbs is not None else (None, None)
     pregate = PREGATE and ws is None and getattr(x, "_jtsm_block_relu_out", False)
+    del _FAN_CLAIMS[:]
+    _FAN_CLAIMS.append(grad_fan.claim(x) if ws is not None else None)
     y = _BottleneckFn.apply(x, w1, sb1[0], sb1[1], w2, sb2[0], sb2[1], w3, sb3[0], sb3[1], ws, ss, bs,
                             stride1, stride2, pad2, dil2, stride_s, pregate)
     y._jtsm_block_relu_out = True    # (a tag on this Python object: any op in between yields an untagged tensor)

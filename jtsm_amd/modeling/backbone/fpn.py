@@ -13,6 +13,7 @@ from torch import nn
 
 from ...layers.batch_norm import get_norm
 from ...layers.elementwise import subsample2, upsample2_add
+from ...layers.grad_fan import fan_out
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d
 from .backbone import Backbone
@@ -82,7 +83,13 @@ class FPN(Backbone):
                 merged = upsample2_add(merged, lateral)      # nearest x2 + add, one pass
                 if self._fuse_type == "avg":
                     merged = merged / 2
-            out["p%d" % level] = getattr(self, "fpn_output%d" % level)(merged)
+            if level != self.levels[0][0]:
+                # read twice — by this level's output convolution and by the next finer level's merge: one view each, so
+                # that the two gradient terms meet in one map (layers/grad_fan.py)
+                mine, merged = fan_out(merged, 2)
+            else:
+                mine = merged
+            out["p%d" % level] = getattr(self, "fpn_output%d" % level)(mine)
         if self.top_block is not None:
             src = self.top_block.in_feature
             extra = self.top_block(feats[src] if src in feats else out[src])

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from ...layers.grad_fan import fan_out
 from ...layers.batch_norm import FrozenBatchNorm2d, get_norm
 from ...layers.blocks import CNNBlockBase
 from ...layers.elementwise import max_pool_3x3_s2
@@ -156,7 +157,12 @@ class ResNet(Backbone):
         for name in self.stage_names:
             x = getattr(self, name)(x)
             if name in keep:
-                out[name] = x
+                if name != self.stage_names[-1]:
+                    # read twice — by whoever takes the feature (an FPN lateral) and by the next stage: one view each, so
+                    # that the two gradient terms meet in one map (layers/grad_fan.py)
+                    out[name], x = fan_out(x, 2)
+                else:
+                    out[name] = x
         return out
 
     def freeze(self, freeze_at=0):

@@ -16,6 +16,7 @@ from ..roi_heads import build_roi_heads
 from .build import META_ARCH_REGISTRY
 from .semantic_seg import build_sem_seg_head
 from ...layers.conv import planes_clear
+from ...layers.grad_fan import fan_out
 from ...layers.postprocess import argmax_channels, preprocess_images_u8
 from ..postprocessing import detector_postprocess, sem_seg_postprocess
 from .panoptic_fpn import combine_semantic_and_instance_outputs
@@ -77,8 +78,17 @@ class GeneralizedMCNNWSL(nn.Module):
         superpixels = ImageList.from_tensors([x["superpixels"].to(self.device) for x in batched_inputs],
                                              self.backbone.size_divisibility)
         proposals = [x["proposals"].to(self.device) for x in batched_inputs]
-        _, detector_losses = self.roi_heads(images, features, proposals, gt_instances, gt_sem_seg, superpixels)
-        _, sem_seg_losses = self.sem_seg_head(features, self.roi_heads.pgt_sem_seg)
+        # every FPN level has three readers (box pooler, mask pooler, semantic head): each gets its own view, through
+        # which their backward kernels add into ONE gradient map per level instead of autograd adding three
+        # (layers/grad_fan.py); without it, or for a head that does not take part, the views behave like `features`
+        fans = {k: fan_out(v, 3) for k, v in features.items()}
+        f_box, f_mask, f_sem = ({k: v[i] for k, v in fans.items()} for i in range(3))
+        if getattr(self.roi_heads, "takes_mask_features", False):
+            _, detector_losses = self.roi_heads(images, f_box, proposals, gt_instances, gt_sem_seg, superpixels,
+                                                mask_features=f_mask)
+        else:
+            _, detector_losses = self.roi_heads(images, f_box, proposals, gt_instances, gt_sem_seg, superpixels)
+        _, sem_seg_losses = self.sem_seg_head(f_sem, self.roi_heads.pgt_sem_seg)
         losses = {}
         losses.update(sem_seg_losses)
         losses.update(detector_losses)

@@ -21,6 +21,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .. import _lib as L
+from ..layers import grad_fan
 from ..layers.mining import MAX_IMAGES, pooler_rois_levels
 from ..layers.moi_pool import MOIPool
 from ..layers.roi_align import ROIAlign
@@ -59,9 +60,15 @@ def _feat(x):
     return x.contiguous(memory_format=CL)
 
 
+# the fan records (layers/grad_fan.py) of the feature levels of the next _AlignLevels / _MOILevels call: claimed by
+# ROIPooler.forward on the tensors the caller handed in, picked up by the node's forward (same thread, next statement)
+_CLAIMS = []
+
+
 class _AlignLevels(Function):
     @staticmethod
     def forward(ctx, rois, roi_level, res, sampling_ratio, aligned, scales, *feats):
+        ctx.fans = _CLAIMS.pop() if _CLAIMS else [None] * len(feats)
         feats = [_feat(f) for f in feats]
         M, C = rois.shape[0], feats[0].shape[1]
         out = torch.empty((M, C, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)  # every roi is on exactly one level, whose kernel writes all of its bins
@@ -85,8 +92,14 @@ class _AlignLevels(Function):
         g = g.contiguous(memory_format=CL)
         nl = len(shapes)
         B, Cc = shapes[0][0], shapes[0][1]
-        grads = [torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
-                 if ctx.needs_input_grad[6 + lvl] else None for lvl, shape in enumerate(shapes)]
+        wanted = [bool(ctx.needs_input_grad[6 + lvl]) for lvl in range(nl)]
+        # maps another consumer of the same feature levels already wrote this backward pass (layers/grad_fan.py): add
+        # into them — all levels or none, the call has one switch
+        sinks = [grad_fan.target(ctx.fans[lvl], shapes[lvl], g.device) if wanted[lvl] else None for lvl in range(nl)]
+        accumulate = any(wanted) and all(s is not None for s, w in zip(sinks, wanted) if w)
+        grads = [(sinks[lvl] if accumulate else torch.empty(shapes[lvl], dtype=torch.float32, device=g.device,
+                                                            memory_format=CL)) if wanted[lvl] else None
+                 for lvl in range(nl)]
         Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
         Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
         sc = (C.c_float * nl)(*[float(x) for x in scales])
@@ -95,7 +108,10 @@ class _AlignLevels(Function):
         L.note_bytes(4.0 * (g.numel() + sum(t.numel() for t in grads if t is not None) + rois.numel()))
         L.check(L.lib().jtsm_roi_align_backward_levels_f32(
             L.ptr(g), L.ptr(rois), L.ptr(roi_level), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
-            sampling_ratio, int(aligned), L.stream()), "roi_align_backward_levels")
+            sampling_ratio, int(aligned), int(accumulate), L.stream()), "roi_align_backward_levels")
+        if accumulate:
+            return (None,) * (6 + nl)
+        grads = [None if grad_fan.offer(ctx.fans[lvl], grads[lvl]) else grads[lvl] for lvl in range(nl)]
         return (None, None, None, None, None, None, *grads)
 
 
@@ -104,6 +120,7 @@ class _MOILevels(Function):
 
     @staticmethod
     def forward(ctx, rois, roi_level, res, scales, oh_labels, superpixels, *feats):
+        ctx.fans = _CLAIMS.pop() if _CLAIMS else [None] * len(feats)
         feats = [_feat(f) for f in feats]
         M, Cc = rois.shape[0], feats[0].shape[1]
         Lw = oh_labels.shape[1]
@@ -142,7 +159,11 @@ class _MOILevels(Function):
         g = g.contiguous(memory_format=CL)
         nl = len(shapes)
         B, Cc = shapes[0][0], shapes[0][1]
-        grads = [torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL) for shape in shapes]
+        wanted = [bool(ctx.needs_input_grad[6 + lvl]) for lvl in range(nl)]
+        sinks = [grad_fan.target(ctx.fans[lvl], shapes[lvl], g.device) for lvl in range(nl)]
+        accumulate = all(wanted) and all(s is not None for s in sinks)     # (see _AlignLevels.backward)
+        grads = sinks if accumulate else [torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
+                                          for shape in shapes]
         Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
         Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
         ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads])
@@ -153,8 +174,11 @@ class _MOILevels(Function):
         L.note_bytes(4.0 * (2 * g.numel() + sum(t.numel() for t in grads)))   # gradient + argmax read, maps written
         L.check(lib.jtsm_moi_pool_backward_levels_f32(
             L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
-            L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "moi_pool_backward_levels")
-        grads = [gi if ctx.needs_input_grad[6 + lvl] else None for lvl, gi in enumerate(grads)]
+            int(accumulate), L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "moi_pool_backward_levels")
+        if accumulate:
+            return (None,) * (6 + nl)
+        grads = [gi if wanted[lvl] else None for lvl, gi in enumerate(grads)]
+        grads = [None if grad_fan.offer(ctx.fans[lvl], grads[lvl]) else grads[lvl] for lvl in range(nl)]
         return (None, None, None, None, None, None, *grads)
 
 
@@ -247,9 +271,11 @@ class ROIPooler(nn.Module):
                                                            self.canonical_box_size, self.canonical_level)
             roi_level = level_assignments.to(torch.int32).contiguous()
         rois = pooler_fmt_boxes.to(torch.float32).contiguous()
+        if self.pooler_type == "ROIAlignRotated" and not moi:
+            raise NotImplementedError("multi-level ROIAlignRotated is outside the JTSM path")
+        del _CLAIMS[:]
+        _CLAIMS.append([grad_fan.claim(f) for f in x])
         if moi:
             return _MOILevels.apply(rois, roi_level, self.output_size[0], self.scales, labels, sp, *x)
-        if self.pooler_type == "ROIAlignRotated":
-            raise NotImplementedError("multi-level ROIAlignRotated is outside the JTSM path")
         return _AlignLevels.apply(rois, roi_level, self.output_size[0], self.sampling_ratio,
                                   self.pooler_type == "ROIAlignV2", self.scales, *x)

@@ -224,9 +224,11 @@ class JTSMROIHeads(ROIHeads):
         return out
 
     # ------------------------------------------------------------------ forward
+    takes_mask_features = True     # (forward's `mask_features`: the mask pooler's own views of the feature levels)
+
     def forward(self, images: ImageList, features: Dict[str, torch.Tensor], proposals: List[Instances],
                 targets: Optional[List[Instances]] = None, gt_sem_seg: Optional[torch.Tensor] = None,
-                superpixels: ImageList = None):
+                superpixels: ImageList = None, mask_features: Optional[Dict[str, torch.Tensor]] = None):
         if not self.training:
             # roi_heads_jtsm.py:553-561: K-head averaged detections, then the mask heads on the detected boxes
             self.proposals, self.superpixels, self.images = proposals, superpixels, images
@@ -253,7 +255,7 @@ class JTSMROIHeads(ROIHeads):
         losses = self._forward_box(features, proposals)
         if self.mask_on:
             self._mask_prepare()
-            losses.update(self._forward_mask(features, proposals))
+            losses.update(self._forward_mask(mask_features if mask_features is not None else features, proposals))
         return proposals, losses
 
     def _predictor_gemm(self, x):

@@ -349,7 +349,7 @@ def test_multilevel_moi_pool_backward_gather_matches_oracle_and_scatter(cuda):
     ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads])
     gcl, acl = gd.contiguous(memory_format=torch.channels_last), arg.contiguous(memory_format=torch.channels_last)
     L.check(L.lib().jtsm_moi_pool_backward_levels_f32(L.ptr(gcl), L.ptr(rois), L.ptr(lv), L.ptr(acl), ptrs, Hs, Ws, None,
-                                                      nl, B, Cc, rois.shape[0], 7, 7, None, C.c_size_t(0), L.stream()),
+                                                      nl, B, Cc, rois.shape[0], 7, 7, 0, None, C.c_size_t(0), L.stream()),
             "scatter form")
     for a, s in zip(xs, grads):
         assert torch.allclose(a.grad, s, rtol=1e-5, atol=1e-5)

@@ -34,7 +34,7 @@ def run(rois, level, tiled):
     sc = (C.c_float * nl)(*scales) if tiled else None
     lib = L.lib()
     ws = torch.empty(max(lib.jtsm_moi_pool_backward_levels_workspace_bytes(Hs, Ws, nl, B, M), 16), dtype=torch.uint8, device=dev)
-    f = lambda: L.check(lib.jtsm_moi_pool_backward_levels_f32(L.ptr(g), L.ptr(rois), L.ptr(lv), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, M, res, res,
+    f = lambda: L.check(lib.jtsm_moi_pool_backward_levels_f32(L.ptr(g), L.ptr(rois), L.ptr(lv), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, M, res, res, 0,
                         L.ptr(ws) if tiled else None, C.c_size_t(ws.numel() if tiled else 0), L.stream()))
     for _ in range(3): f()
     ts = []
@@ -70,7 +70,7 @@ for M, spread in [(4000, 1000), (4000, 300), (4000, 60), (4000, 0)]:
     arg = torch.full((M, Cc, res, res), -1, dtype=torch.int32, device=dev).contiguous(memory_format=torch.channels_last)
     grads = [torch.empty(sh, device=dev).contiguous(memory_format=torch.channels_last) for sh in shapes]
     ptrs = (C.c_void_p * nl)(*[t.data_ptr() for t in grads]); sc = (C.c_float * nl)(*scales)
-    L.check(lib.jtsm_moi_pool_backward_levels_f32(L.ptr(g), L.ptr(rois), L.ptr(lv), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, M, res, res, L.ptr(ws), C.c_size_t(nb), L.stream()))
+    L.check(lib.jtsm_moi_pool_backward_levels_f32(L.ptr(g), L.ptr(rois), L.ptr(lv), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, M, res, res, 0, L.ptr(ws), C.c_size_t(nb), L.stream()))
     torch.cuda.synchronize()
     ints = ws.view(torch.int32)
     ntile = sum(B * ((sh[2] + 7) // 8) * ((sh[3] + 7) // 8) for sh in shapes)
