@@ -237,6 +237,7 @@ class _MaskTowerFn(Function):
 
     @staticmethod
     def forward(ctx, x, want_features, *params):
+        ctx.fan = _FAN_CLAIMS.pop() if _FAN_CLAIMS else None   # (mask_tower_fused claimed x's fan view, if it is one)
         k = (len(params) - 4) // 2
         hs = [K.PlaneTensor.of(x)]
         for j in range(k):
@@ -303,7 +304,10 @@ class _MaskTowerFn(Function):
             if j > 0:
                 g = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j])
             elif ctx.needs_input_grad[0]:
-                dx = K.planes_backward_data(g, w, ctx.xshape, 1, 1, 1, fp32=True)
+                sink = grad_fan.target(ctx.fan, ctx.xshape, g.buf.device)     # (the other head's map: add into it)
+                dx = K.planes_backward_data(g, w, ctx.xshape, 1, 1, 1, fp32=True, into=sink)
+                if sink is not None or grad_fan.offer(ctx.fan, dx):
+                    dx = None
         if k == 0 and ctx.needs_input_grad[0]:
             raise NotImplementedError("mask tower without 3x3 layers")   # (mask_tower_ok requires k >= 1)
         by_width = {}
@@ -338,6 +342,8 @@ def mask_tower_fused(x, convs, deconv, predictor, want_features=True):
     params = []
     for c in convs:
         params += [c.weight, c.bias]
+    del _FAN_CLAIMS[:]
+    _FAN_CLAIMS.append(grad_fan.claim(x))
     return _MaskTowerFn.apply(x, bool(want_features), *params, deconv.weight, deconv.bias, predictor.weight,
                               predictor.bias)
 

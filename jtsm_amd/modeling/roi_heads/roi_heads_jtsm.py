@@ -33,6 +33,7 @@ import torch
 import torch.nn.functional as F
 
 from ...layers.conv import linear_fused, linear_fused_split
+from ...layers.grad_fan import fan_out
 from ...layers.mining import (MAX_IMAGES, image_labels, match_label, mine_top1, near_targets, pad_class_lists,
                               paint_sem_seg, paint_sem_seg_evidence, paste_crop_targets, rect_mask_targets, row_lse,
                               sp_mask_targets)
@@ -426,7 +427,9 @@ class JTSMROIHeads(ROIHeads):
         fg_box_lists = [Boxes(b) for b in fg_boxes.split(per_image)]
         mask_features = self.mask_pooler(feats, fg_box_lists)
         self.aux.update(fg_rois=torch.cat([img_of.to(torch.float32)[:, None], fg_boxes], dim=1), fg_classes=gt_classes)
-        pred_mask_logits, _ = self.mask_head.layers(mask_features)
+        # the pooled features are read by every mask head: one view each, their gradients meet in one map (layers/grad_fan.py)
+        views = list(fan_out(mask_features, 1 + len(self.mask_refinery)))
+        pred_mask_logits, _ = self.mask_head.layers(views.pop())
         losses = {"loss_mask": mask_rcnn_loss(pred_mask_logits, gt_classes, gt_masks)}
         for k, head in enumerate(self.mask_refinery):
             with torch.no_grad():
@@ -437,6 +440,6 @@ class JTSMROIHeads(ROIHeads):
                 else:
                     gt_masks = sel > 0.0                                        # sigmoid > 0.5
                 self.aux["mask_targets_r%d" % k] = gt_masks
-            pred_mask_logits, _ = head.layers(mask_features)
+            pred_mask_logits, _ = head.layers(views.pop())
             losses["loss_mask_r" + str(k)] = mask_rcnn_loss(pred_mask_logits, gt_classes, gt_masks)
         return losses
