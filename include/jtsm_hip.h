@@ -614,6 +614,14 @@ int jtsm_image_labels(const int64_t* const* gt_classes, const int* counts, int B
                       int32_t* things_cls, int32_t* things_cnt, float* oh_stuff, int32_t* stuff_cls, int32_t* stuff_cnt,
                       void* workspace, void* stream);
 
+/* The foreground proposals of the mask branch (projects/WSL/wsl/modeling/roi_heads/roi_heads_jtsm.py:754-948:
+ * `select_foreground_proposals` + the gathers that follow it): rows with labels[r] != bg_label, in row order, with
+ * their box, class (int64), image, matched near target (matched nullable) and (image, box) roi; counts[b] (int64) =
+ * foreground rows of image b.  The fg_* buffers hold R entries, of which the first sum(counts) are written. */
+int jtsm_fg_compact(const int32_t* labels, int bg_label, const int32_t* bag_offsets, int B, int R, const float* boxes,
+                    const int32_t* matched, int32_t* fg_rows, float* fg_boxes, int64_t* fg_classes, int32_t* fg_img,
+                    int32_t* fg_matched, float* fg_rois, int64_t* counts, void* stream);
+
 /* Mask loss — mask_rcnn_loss (detectron2/modeling/roi_heads/mask_head.py:31-112, used by
  * projects/WSL/wsl/modeling/roi_heads/mask_head.py): mean binary cross-entropy with logits between the
  * ground-truth-class channel of logits (N,side,side,ld) NHWC (num_classes <= ld; gt_classes NULL when

@@ -502,6 +502,48 @@ __global__ __launch_bounds__(256) void image_class_lists_kernel(const ImageRows 
                     stuff_cls + (size_t)b * (S - 1), stuff_cnt + b, wave_count);
 }
 
+
+// The mask branch trains on the foreground proposals only (roi_heads_jtsm.py:754-948): their rows, in row order, with
+// what the branch reads of them — one workgroup, an ordered compaction 1024 rows at a time.  fg_* hold `total` valid
+// entries (a host-side slice after the count has crossed: no kernel), counts[b] = foreground rows of image b.
+__global__ __launch_bounds__(1024) void fg_compact_kernel(const int* __restrict__ labels, int bg_label, const int* __restrict__ bag_offsets,
+                                                          int B, int R, const float* __restrict__ boxes,
+                                                          const int* __restrict__ matched, int* __restrict__ fg_rows,
+                                                          float* __restrict__ fg_boxes, long* __restrict__ fg_classes,
+                                                          int* __restrict__ fg_img, int* __restrict__ fg_matched,
+                                                          float* __restrict__ fg_rois, long* __restrict__ counts) {
+  __shared__ int wave_count[16];
+  __shared__ int per_image[64];
+  const int t = threadIdx.x;
+  if (t < 64) per_image[t] = 0;
+  __syncthreads();
+  int filled = 0;
+  for (int base = 0; base < R; base += 1024) {
+    const int r = base + t;
+    const int lab = r < R ? labels[r] : bg_label;
+    const bool fg = lab != bg_label;
+    int cnt;
+    const int slot = filled + compact_wg<16>(fg, wave_count, cnt);
+    if (fg) {
+      int b = 0;
+      while (b + 1 < B && r >= bag_offsets[b + 1]) ++b;
+      const float4 bx = reinterpret_cast<const float4*>(boxes)[r];
+      fg_rows[slot] = r;
+      reinterpret_cast<float4*>(fg_boxes)[slot] = bx;
+      fg_classes[slot] = lab;
+      fg_img[slot] = b;
+      if (matched) fg_matched[slot] = matched[r];
+      fg_rois[(size_t)slot * 5 + 0] = (float)b;
+      fg_rois[(size_t)slot * 5 + 1] = bx.x; fg_rois[(size_t)slot * 5 + 2] = bx.y;
+      fg_rois[(size_t)slot * 5 + 3] = bx.z; fg_rois[(size_t)slot * 5 + 4] = bx.w;
+      atomicAdd(&per_image[b], 1);
+    }
+    filled += cnt;
+  }
+  __syncthreads();
+  if (t < B) counts[t] = per_image[t];
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -677,6 +719,21 @@ int jtsm_image_labels(const int64_t* const* gt_classes, const int* counts, int B
   hipLaunchKernelGGL(jtsm::image_class_lists_kernel, dim3(B), dim3(256), 0, jtsm::as_stream(stream), im, num_classes, flags, num_stuff,
                      stuff_offset, oh_things, things_cls, things_cnt, oh_stuff, stuff_cls, stuff_cnt);
   JTSM_CHECK_LAUNCH("image_class_lists");
+  return JTSM_OK;
+}
+
+int jtsm_fg_compact(const int32_t* labels, int bg_label, const int32_t* bag_offsets, int B, int R, const float* boxes,
+                    const int32_t* matched, int32_t* fg_rows, float* fg_boxes, int64_t* fg_classes, int32_t* fg_img,
+                    int32_t* fg_matched, float* fg_rois, int64_t* counts, void* stream) {
+  JTSM_REQUIRE(B >= 1 && B <= 64 && R >= 0, "fg_compact: 1..64 images, got %d (rows %d)", B, R);
+  JTSM_REQUIRE(labels && bag_offsets && boxes && fg_rows && fg_boxes && fg_classes && fg_img && fg_rois && counts &&
+               (!matched || fg_matched), "fg_compact: null pointer");
+  JTSM_REQUIRE((reinterpret_cast<uintptr_t>(boxes) & 15) == 0 && (reinterpret_cast<uintptr_t>(fg_boxes) & 15) == 0,
+               "fg_compact: boxes must be 16-byte aligned");
+  hipLaunchKernelGGL(jtsm::fg_compact_kernel, dim3(1), dim3(1024), 0, jtsm::as_stream(stream), labels, bg_label, bag_offsets, B, R,
+                     boxes, matched, fg_rows, fg_boxes, reinterpret_cast<long*>(fg_classes), fg_img, fg_matched, fg_rois,
+                     reinterpret_cast<long*>(counts));
+  JTSM_CHECK_LAUNCH("fg_compact");
   return JTSM_OK;
 }
 

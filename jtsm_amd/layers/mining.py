@@ -116,7 +116,7 @@ def rect_mask_targets(rois, rects, side, height, width, erode=2.0):
     out = torch.empty((n, side, side), dtype=torch.uint8, device=rois.device)
     L.check(L.lib().jtsm_rect_mask_targets_f32(L.ptr(rois), L.ptr(rects), L.ptr(out), n, side, height, width,
                                                L.f32(erode), L.stream()), "rect_mask_targets")
-    return out.to(torch.bool)
+    return out.view(torch.bool)      # (0 / 1 bytes: the same memory read as bool, no pass)
 
 
 @torch.no_grad()
@@ -149,7 +149,7 @@ def sp_mask_targets(rois, oh_rows, img_of, oh_labels, superpixels, side):
                                              L.ptr(img_of.to(torch.int32).contiguous()), L.ptr(oh_labels),
                                              oh_labels.shape[1], L.ptr(superpixels), L.ptr(out), n, side, h, w,
                                              L.stream()), "sp_mask_targets")
-    return out.to(torch.bool)
+    return out.view(torch.bool)      # (0 / 1 bytes: the same memory read as bool, no pass)
 
 
 @torch.no_grad()
@@ -162,7 +162,7 @@ def paste_crop_targets(probs, rois, side, height, width, threshold=0.5):
     out = torch.empty((n, side, side), dtype=torch.uint8, device=rois.device)
     L.check(L.lib().jtsm_paste_crop_targets_f32(L.ptr(probs), L.ptr(rois), L.ptr(out), n, m, side, height, width,
                                                 L.f32(threshold), L.stream()), "paste_crop_targets")
-    return out.to(torch.bool)
+    return out.view(torch.bool)      # (0 / 1 bytes: the same memory read as bool, no pass)
 
 
 # ---- label preparation (csrc/mining.hip, round 3): per-image inputs travel as pointers, no concatenation ----------
@@ -237,3 +237,25 @@ def image_labels(gt_classes_list, num_classes, gt_sem_seg=None, num_stuff=0, stu
                                       stuff_offset, L.ptr(oh_t), L.ptr(cls_t), L.ptr(cnt_t), L.ptr(oh_s), L.ptr(cls_s),
                                       L.ptr(cnt_s), L.ptr(ws), L.stream()), "image_labels")
     return oh_t, cls_t, cnt_t, oh_s, cls_s, cnt_s
+
+
+@torch.no_grad()
+def fg_compact(labels, bg_label, bag_offsets, boxes, matched=None):
+    """The foreground rows (labels != bg_label) in row order with what the mask branch reads of them, in ONE launch:
+    -> dict(rows (R,) int32, boxes (R,4), classes (R,) int64, img (R,) int32, matched (R,) int32 | None,
+    rois (R,5) float32, counts (B,) int64); of the R-long buffers the first counts.sum() entries are valid (slice
+    them once the counts are on the host)."""
+    L.require_gpu(labels, boxes)
+    assert labels.dtype == torch.int32 and bag_offsets.dtype == torch.int32
+    boxes = boxes.to(torch.float32).contiguous()
+    R, B, dev = labels.shape[0], bag_offsets.numel() - 1, labels.device
+    out = dict(rows=torch.empty(R, dtype=torch.int32, device=dev), boxes=torch.empty((R, 4), dtype=torch.float32, device=dev),
+               classes=torch.empty(R, dtype=torch.int64, device=dev), img=torch.empty(R, dtype=torch.int32, device=dev),
+               matched=torch.empty(R, dtype=torch.int32, device=dev) if matched is not None else None,
+               rois=torch.empty((R, 5), dtype=torch.float32, device=dev),
+               counts=torch.empty(B, dtype=torch.int64, device=dev))
+    L.check(L.lib().jtsm_fg_compact(L.ptr(labels.contiguous()), int(bg_label), L.ptr(bag_offsets), B, R, L.ptr(boxes),
+                                    L.ptr(matched), L.ptr(out["rows"]), L.ptr(out["boxes"]), L.ptr(out["classes"]),
+                                    L.ptr(out["img"]), L.ptr(out["matched"]), L.ptr(out["rois"]), L.ptr(out["counts"]),
+                                    L.stream()), "fg_compact")
+    return out

@@ -34,7 +34,7 @@ import torch.nn.functional as F
 
 from ...layers.conv import linear_fused, linear_fused_split
 from ...layers.grad_fan import fan_out
-from ...layers.mining import (MAX_IMAGES, image_labels, match_label, mine_top1, near_targets, pad_class_lists,
+from ...layers.mining import (MAX_IMAGES, fg_compact, image_labels, match_label, mine_top1, near_targets, pad_class_lists,
                               paint_sem_seg, paint_sem_seg_evidence, paste_crop_targets, rect_mask_targets, row_lse,
                               sp_mask_targets)
 from ...layers.mining import roi_scale as fused_roi_scale
@@ -385,21 +385,21 @@ class JTSMROIHeads(ROIHeads):
             lab["near_rows"], lab["matched_near"] = near_targets(all_boxes, offsets, lab["labels"], self.num_classes, pg,
                                                                  things_cnt, self.mask_mined_top_k)
         with torch.no_grad():
-            is_fg = lab["labels"] != self.num_classes
-            ends = torch.tensor(list(torch.tensor(counts).cumsum(0)), dtype=torch.int64)       # host-known row ranges
-            csum = torch.cat([is_fg.new_zeros(1, dtype=torch.int64), is_fg.cumsum(0)])
-            per_image_dev = csum[ends.to(is_fg.device, non_blocking=True)] - csum[(ends - torch.tensor(counts)).to(is_fg.device, non_blocking=True)]
+            # the foreground rows, compacted in row order with everything the branch reads of them, and the per-image
+            # counts — one launch (layers/mining.py: fg_compact); after the counts have crossed, slices
+            sel = fg_compact(lab["labels"], self.num_classes, offsets, all_boxes,
+                             lab["matched_near"] if self.mask_targets == "evidence" else lab["matched"])
             host = getattr(self, "_fg_counts_host", None)
             if host is None or host.numel() != len(counts):
                 host = self._fg_counts_host = torch.empty(len(counts), dtype=torch.int64).pin_memory()
-            host.copy_(per_image_dev, non_blocking=True)
+            host.copy_(sel["counts"], non_blocking=True)
             ready = torch.cuda.Event()
             ready.record()
-        self._mask_pending = (pg, lab, is_fg, host, ready)
+        self._mask_pending = (pg, lab, sel, host, ready)
 
     def _forward_mask(self, features, instances):
         all_boxes, offsets, things_cls, things_cnt, counts = self._mining
-        pg, lab, is_fg, host, ready = self._mask_pending
+        pg, lab, sel, host, ready = self._mask_pending
         self._mask_pending = None
         height, width = self.images.tensor.shape[-2:]
         feats = [features[f] for f in self.mask_in_features]
@@ -407,26 +407,24 @@ class JTSMROIHeads(ROIHeads):
             # the head trains on foreground proposals only: a data-dependent count -> the step's one sync
             ready.synchronize()
             per_image = host.tolist()
-            fg = torch.nonzero_static(is_fg, size=sum(per_image))[:, 0]
-            gt_classes = lab["labels"][fg].to(torch.int64)
-            fg_boxes = all_boxes[fg]
-            img_of = torch.bucketize(fg, offsets[1:].to(torch.int64), right=True)          # image of each fg row
+            n_fg = sum(per_image)
+            fg, gt_classes, fg_boxes, img_of = sel["rows"][:n_fg], sel["classes"][:n_fg], sel["boxes"][:n_fg], sel["img"][:n_fg]
             # targets: the matched pseudo-GT rectangle (shrunk by 2 px) cropped to the proposal at 28x28 with
             # ROIAlign(1.0, sampling 0, aligned) and thresholded at 0.5 (structures/masks.py:169-200) — analytic kernel
             side = 2 * self.mask_pooler.output_size[0]
             if self.mask_targets == "evidence":
                 # the matched near target's superpixel-evidence mask, cropped to the proposal (never rasterised)
                 oh_all, sp = self._evidence
-                gt_masks = sp_mask_targets(fg_boxes, lab["matched_near"][fg], img_of, oh_all, sp, side)
-                self.aux["near_rows"], self.aux["matched_near"] = lab["near_rows"], lab["matched_near"][fg]
+                gt_masks = sp_mask_targets(fg_boxes, sel["matched"][:n_fg], img_of, oh_all, sp, side)
+                self.aux["near_rows"], self.aux["matched_near"] = lab["near_rows"], sel["matched"][:n_fg]
             else:
                 G = things_cls.shape[1]
-                matched = pg["boxes"].reshape(-1, 4)[img_of * G + lab["matched"][fg].to(torch.int64)]
+                matched = pg["boxes"].reshape(-1, 4)[img_of.to(torch.int64) * G + sel["matched"][:n_fg].to(torch.int64)]
                 gt_masks = rect_mask_targets(fg_boxes, matched, side, height, width)
             self.aux["mask_targets"] = gt_masks
         fg_box_lists = [Boxes(b) for b in fg_boxes.split(per_image)]
         mask_features = self.mask_pooler(feats, fg_box_lists)
-        self.aux.update(fg_rois=torch.cat([img_of.to(torch.float32)[:, None], fg_boxes], dim=1), fg_classes=gt_classes)
+        self.aux.update(fg_rois=sel["rois"][:n_fg], fg_classes=gt_classes)
         # the pooled features are read by every mask head: one view each, their gradients meet in one map (layers/grad_fan.py)
         views = list(fan_out(mask_features, 1 + len(self.mask_refinery)))
         pred_mask_logits, _ = self.mask_head.layers(views.pop())

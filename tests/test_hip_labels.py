@@ -102,3 +102,27 @@ def test_label_preparation_rejects_too_many_images(cuda):
 
     with pytest.raises(RuntimeError):
         pooler_rois_levels([torch.zeros(1, 4, device=cuda)] * (MAX_IMAGES + 1), 2, 5, 224, 4)
+
+
+def test_fg_compact_is_nonzero_plus_gathers(cuda):
+    from jtsm_amd.layers.mining import fg_compact
+
+    g = torch.Generator().manual_seed(6)
+    for (counts, p_fg) in (([2000, 2000], 0.08), ([5, 0, 1300, 1], 0.5), ([3000], 0.0), ([1100], 1.0)):
+        R, bg = sum(counts), 80
+        labels = torch.where(torch.rand(R, generator=g) < p_fg, torch.randint(0, bg, (R,), generator=g), torch.tensor(bg))
+        labels = labels.to(torch.int32).to(cuda)
+        boxes = _boxes(g, R).to(cuda)
+        matched = torch.randint(0, 100, (R,), generator=g, dtype=torch.int32).to(cuda)
+        offs = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32).to(cuda)
+        out = fg_compact(labels, bg, offs, boxes, matched)
+        fg = torch.nonzero(labels != bg)[:, 0]
+        n = fg.numel()
+        per_image = [int(((fg >= offs[b]) & (fg < offs[b + 1])).sum()) for b in range(len(counts))]
+        assert out["counts"].tolist() == per_image and sum(per_image) == n
+        img = torch.bucketize(fg, offs[1:].to(torch.int64), right=True)
+        assert torch.equal(out["rows"][:n].to(torch.int64), fg)
+        assert torch.equal(out["boxes"][:n], boxes[fg]) and torch.equal(out["classes"][:n], labels[fg].to(torch.int64))
+        assert torch.equal(out["img"][:n].to(torch.int64), img) and torch.equal(out["matched"][:n], matched[fg])
+        assert torch.equal(out["rois"][:n], torch.cat([img.to(torch.float32)[:, None], boxes[fg]], dim=1))
+        assert fg_compact(labels, bg, offs, boxes)["matched"] is None
