@@ -367,7 +367,7 @@ class JTSMROIHeads(ROIHeads):
             losses.update(refinery.losses((z, d), all_boxes, lab["labels"], lab["boxes"], lab["weights"]))
             prev_logits, prev_deltas = z.detach(), (d.detach() if d is not None else None)
             self.aux["pgt_idx_r%d" % k] = pg["idx"]          # (B, num_classes) padded; valid: [:things_cnt[b]]
-            self.aux["labels_r%d" % k] = lab["labels"].to(torch.int64)
+            self.aux["labels_r%d" % k] = lab["labels"]       # (R,) int32
         self.aux["things_cnt"] = things_cnt
         self._last_branch = (prev_logits, prev_deltas)
         return losses

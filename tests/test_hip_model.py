@@ -82,7 +82,7 @@ def test_integer_artefacts_bit_exact(step):
         pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
         for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
             assert cnt[i] == b.numel() and torch.equal(pad[i, :cnt[i]], b)
-        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+        assert torch.equal(aux["labels_r%d" % k].cpu().to(torch.int64), aux0["labels_r%d" % k])
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
     assert torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
     assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
@@ -234,7 +234,7 @@ def _check_against_oracle(model, losses, losses0, aux0):
         pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
         for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
             assert cnt[i] == b.numel() and torch.equal(pad[i, :cnt[i]], b)
-        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+        assert torch.equal(aux["labels_r%d" % k].cpu().to(torch.int64), aux0["labels_r%d" % k])
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
     assert torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
     assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
@@ -432,7 +432,7 @@ def test_ragged_batch_losses_and_labels(cuda):
         pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
         for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
             assert torch.equal(pad[i, :cnt[i]], b)
-        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+        assert torch.equal(aux["labels_r%d" % k].cpu().to(torch.int64), aux0["labels_r%d" % k])
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"])
     assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
 

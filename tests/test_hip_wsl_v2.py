@@ -166,7 +166,7 @@ def test_dc5_composite_matches_oracle(cuda, depth, conv_math, loss_bar):
         pad = aux["pgt_idx_r%d" % k].cpu().to(torch.int64)
         for i, b in enumerate(aux0["pgt_idx_r%d" % k]):
             assert cnt[i] == b.numel() and torch.equal(pad[i, :cnt[i]], b)
-        assert torch.equal(aux["labels_r%d" % k].cpu(), aux0["labels_r%d" % k])
+        assert torch.equal(aux["labels_r%d" % k].cpu().to(torch.int64), aux0["labels_r%d" % k])
     assert torch.equal(aux["fg_rois"].cpu(), aux0["fg_rois"]) and torch.equal(aux["fg_classes"].cpu(), aux0["fg_classes"])
     assert torch.equal(model.roi_heads.pgt_sem_seg.cpu(), aux0["sem_target"])
     a, b = aux["pooled_argmax"].cpu().contiguous(), aux0["pooled_argmax"]
