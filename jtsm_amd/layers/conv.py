@@ -1230,6 +1230,8 @@ class _LeadingChannels(Function):
     the PADDED width with zero padding (the fused up-sample + cross-entropy does, and says so with ZERO_PADDED) gets
     that buffer passed through instead."""
 
+    passed_through = 0     # (tests: how many backward calls took the zero-padded buffer as it was)
+
     @staticmethod
     def forward(ctx, y, o):
         ctx.full = y.shape[1]
@@ -1242,6 +1244,7 @@ class _LeadingChannels(Function):
                 base.shape[3] == ctx.full and base.is_contiguous() and g.data_ptr() == base.data_ptr() and
                 tuple(g.shape) == (base.shape[0], g.shape[1], base.shape[1], base.shape[2]) and
                 g.stride() == (base.stride(0), 1, base.stride(1), base.stride(2))):
+            _LeadingChannels.passed_through += 1
             return base.permute(0, 3, 1, 2), None
         return torch.nn.functional.pad(g, (0, 0, 0, 0, 0, ctx.full - g.shape[1])), None
 

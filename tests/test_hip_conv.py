@@ -326,6 +326,43 @@ def test_fused_upsample_cross_entropy_vs_torch_cpu(cuda):
         assert wd.grad[:, c:].abs().max().item() == 0
 
 
+def test_padded_predictor_hands_the_cross_entropy_gradient_through(cuda):
+    """54 classes on 56-wide rows (semantic_seg.py:179-188 behind a 1x1 predictor): the slice behind the channel
+    padding takes the loss's zero-padded gradient buffer as it is — same gradients as the torch ops, no zeros + copy."""
+    import torch.nn.functional as F
+
+    from jtsm_amd.layers import conv as K
+    from jtsm_amd.layers.elementwise import semseg_cross_entropy
+
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 128, 24, 40, generator=g)
+    w = torch.randn(54, 128, 1, 1, generator=g) * 0.05
+    b = torch.randn(54, generator=g) * 0.1
+    t = torch.randint(0, 54, (2, 96, 160), generator=g)
+    t[:, :3] = 255
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.cross_entropy(F.interpolate(F.conv2d(xr, wr, br), scale_factor=4, mode="bilinear", align_corners=False), t,
+                          ignore_index=255)
+    ref.backward()
+    xd = x.to(cuda).contiguous(memory_format=CL).requires_grad_()
+    wd = w.to(cuda).contiguous(memory_format=CL).requires_grad_()
+    bd = b.to(cuda).requires_grad_()
+    before = K._LeadingChannels.passed_through
+    y = K.conv2d_fused(xd, wd, None, bd, None, 1, 0, 1, False, True)
+    assert tuple(y.shape) == (2, 54, 24, 40)
+    loss = semseg_cross_entropy(y, t.to(cuda), 4, 255)
+    loss.backward()
+    assert K._LeadingChannels.passed_through == before + 1
+    close(loss, ref, "loss")
+    close(xd.grad, xr.grad, "dx")
+    close(wd.grad, wr.grad, "dw")
+    close(bd.grad, br.grad, "db")
+    # a consumer that knows nothing of the padding still gets the ordinary (padded) gradient
+    y2 = K.conv2d_fused(xd, wd, None, bd, None, 1, 0, 1, False, True)
+    (y2 * 2.0).sum().backward()
+    assert K._LeadingChannels.passed_through == before + 1
+
+
 def test_tiled_cross_entropy_backward_is_the_plain_gather_bit_for_bit(cuda, monkeypatch):
     """The x4 backward through LDS (one soft-max per output pixel) adds the same products in the same order as the
     plain gather it replaces: equal bits, at the JTSM size and on ragged maps."""
