@@ -6,8 +6,7 @@ import sys
 
 path, key = sys.argv[1], sys.argv[2]
 lines = open(path).read().split("\n")
-start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and key in l and l.rstrip().endswith(("E", ":")) or
-             (l.startswith("_ZN") and key in l and ": " in l))
+start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and key in l)
 end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i])
 body = lines[start:end]
 for l in body:
