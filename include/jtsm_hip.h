@@ -404,6 +404,32 @@ int jtsm_conv2d_backward_data_ex_f16(const uint16_t* dy_h, const uint16_t* wt_h,
                                      const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
                                      const float* relu_mask, const uint16_t* gate_plane, int grad_shift, void* workspace,
                                      size_t workspace_bytes, void* stream);
+
+/* The same data gradients (and the transposed convolution's), also leaving the COLUMN SUMS of the finished, gated
+ * result: colsum (rows x in_c floats, rows = jtsm_conv_bf16x3_colsum_rows(s, role); role 0 for the transposed
+ * convolution's conv shape, 1 for a data gradient; 0 rows: not available for this shape) holds one partial sum per row
+ * tile of the launch, which the caller adds up in order (jtsm_colsum_fold_f32) — the bias gradient of the layer below
+ * (ATen convolution_backward's grad_bias, detectron2/layers/wrappers.py:76-78), taken where that layer's output
+ * gradient is written instead of by a pass over it (sums of the fp32 values: no plane shift in them). */
+int jtsm_conv_bf16x3_colsum_rows(const jtsm_conv_shape* s, int role);
+int jtsm_conv2d_backward_data_colsum_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                            const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                            const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                            const float* relu_mask, const uint16_t* gate_plane, float* colsum,
+                                            void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_conv2d_backward_data_colsum_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                         const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                         const float* relu_mask, const uint16_t* gate_plane, int grad_shift, float* colsum,
+                                         void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_conv_transpose2x2_backward_data_colsum_bf16x3(const uint16_t* g_hi, const uint16_t* g_lo, const uint16_t* w_hi,
+                                                       const uint16_t* w_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                                       int batch, int h, int w, int in_c, int out_c,
+                                                       const float* relu_mask, const uint16_t* gate_plane, float* colsum,
+                                                       void* workspace, size_t workspace_bytes, void* stream);
+int jtsm_conv_transpose2x2_backward_data_colsum_f16(const uint16_t* g_h, const uint16_t* w_h, float* dx, uint16_t* dx_h,
+                                                    int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
+                                                    const uint16_t* gate_plane, int grad_shift, float* colsum,
+                                                    void* workspace, size_t workspace_bytes, void* stream);
 /* Streaming passes that end in operand planes (hi + lo bf16, or lo == NULL: one fp16 plane of v * 2^shift; all
  * pointers 16-byte aligned, element counts multiples of 8):
  *   jtsm_relu_backward_split_scaled_f32  g = y > 0 ? dy * scale : 0 (+ planes of g): the backward of ReLU followed by
@@ -473,6 +499,9 @@ int jtsm_relu_backward_split_f32(const float* dy, const float* y, float* g, uint
 int jtsm_relu_backward_f32(const float* dy, const float* y, float* g, long n, void* stream);
 /* out[c] = sum_r g[r*C + c]  — bias gradient of a conv / linear layer. */
 int jtsm_channel_sum_f32(const float* g, float* out, long rows, int C, void* stream);
+/* The same for n <= 16 small (rows[b] x width) matrices in one launch, rows added in order: out (n, width) — folds the
+ * per-row-tile column sums of jtsm_conv2d_backward_data_colsum_* of several layers at once. */
+int jtsm_colsum_fold_f32(const float* const* parts, const int* rows, int n, int width, float* out, void* stream);
 /* The same without atomics (bitwise reproducible) and ~4x faster on large inputs: row slabs are summed into
  * `workspace` (jtsm_channel_sum_workspace_bytes, 16-byte aligned) and folded in slab order, for any C and any
  * number of rows.  Falls back to the (atomic) form above only when the workspace is missing or too small. */

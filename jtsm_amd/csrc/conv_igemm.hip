@@ -94,6 +94,10 @@ struct Params {
   // (the result itself when there is one slice), folded into bias_out[M] by the finishing pass.
   float* bias_slab;
   float* bias_out;
+  // FWD / DGRAD, unsplit, wide epilogue: per-row-tile column sums of the FINISHED result (after scale / residual / gate),
+  // colsum[row tile][N] — the bias gradient of the layer whose output gradient this launch produces, taken where that
+  // gradient is written instead of by a pass over it afterwards (the caller folds the row tiles in order).
+  float* colsum;
   ConvShape s;
   Epilogue e;
 };
@@ -542,6 +546,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
     if (e.bias) bi_col = *reinterpret_cast<const float4*>(e.bias + nb_col);
   }
   const bool piped = !raw && (e.residual || e.mask || p.mask_plane);
+  float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);    // (p.colsum) this thread's four columns over its rows, in row order
   int pm[U];
   float4 prr[U], pmk[U];
   float2 pmp[U];           // (four 16-bit gate words of a plane)
@@ -596,6 +601,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
         const size_t o = locate(m, n, nb);
         if (p.C) *reinterpret_cast<float4*>(p.C + o) = v;
         if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, v, p.out_shift);
+        csum.x += v.x; csum.y += v.y; csum.z += v.z; csum.w += v.w;
       }
       continue;
     }
@@ -636,7 +642,24 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
         const size_t o = locate(om[u], n, nb);
         if (p.C) *reinterpret_cast<float4*>(p.C + o) = out[u];
         if (p.out_hi) emit_planes4(p.out_hi, p.out_lo, o, out[u], p.out_shift);
+        csum.x += out[u].x; csum.y += out[u].y; csum.z += out[u].z; csum.w += out[u].w;
       }
+    }
+  }
+  if (p.colsum && !raw) {
+    // the NT / CPR threads that share four columns, added in thread order: no atomics, reproducible
+    __syncthreads();                                   // (the LDS window is free again)
+    float4* red = reinterpret_cast<float4*>(tile);
+    red[tid] = csum;
+    __syncthreads();
+    if (tid < CPR && n_ok) {
+      float4 t = red[tid];
+#pragma unroll
+      for (int k = 1; k < NT / CPR; ++k) {
+        const float4 q = red[tid + k * CPR];
+        t.x += q.x; t.y += q.y; t.z += q.z; t.w += q.w;
+      }
+      *reinterpret_cast<float4*>(p.colsum + (size_t)(m0 / BM) * p.N + n) = t;
     }
   }
   if (!(raw && p.tickets)) return;
@@ -1725,6 +1748,7 @@ struct FwdExtras {
   const uint16_t* mask_plane = nullptr;   // the same gate read from the activation's hi / fp16 plane (Params::mask_plane)
   int in_shift = 0, out_shift = 0;
   int shuffle_c = 0, shuffle_h = 0, shuffle_w = 0;   // Params::shuffle_*
+  float* colsum = nullptr;                            // Params::colsum
 };
 
 template <int NP>
@@ -1754,6 +1778,8 @@ static int x3_forward(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t
   p.e.mask = ex.mask; p.mask_plane = ex.mask_plane; p.in_shift = ex.in_shift; p.out_shift = ex.out_shift;
   JTSM_REQUIRE(!ex.mask_plane || aligned16(ex.mask_plane), "conv forward bf16x3: the gate plane must be 16-byte aligned");
   p.shuffle_c = ex.shuffle_c; p.shuffle_h = ex.shuffle_h; p.shuffle_w = ex.shuffle_w;
+  p.colsum = ex.colsum;
+  JTSM_REQUIRE(!ex.colsum || (aligned16(ex.colsum) && !ex.shuffle_c), "conv forward bf16x3: column sums need a 16-byte aligned buffer (and no pixel shuffle)");
   JTSM_REQUIRE(!ex.mask || aligned16(ex.mask), "conv forward bf16x3: the gate must be 16-byte aligned");
   if (ex.shuffle_c) {   // only the wide epilogue knows the pixel-shuffle map, and a K split's finishing pass does not
     JTSM_REQUIRE(p.N == 4 * ex.shuffle_c && ex.shuffle_c % 4 == 0 && aligned16(y) && (!bias || aligned16(bias)) &&
@@ -1777,7 +1803,8 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
                             const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
                             const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask, int grad_shift,
                             void* workspace, size_t workspace_bytes, void* stream,
-                            const uint16_t* gate_plane = nullptr, const float* row_scale = nullptr) {
+                            const uint16_t* gate_plane = nullptr, const float* row_scale = nullptr,
+                            float* colsum = nullptr) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1807,6 +1834,8 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
   if (!workspace) workspace_bytes = 0;
   const bool scatter = p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1 && (!accumulate || accumulate == dx) &&
                        !relu_mask && !gate_plane && !row_scale && dx;   // (accumulate == dx: see jtsm_conv2d_backward_data_f32)
+  JTSM_REQUIRE(!colsum || (aligned16(colsum) && !scatter), "conv backward-data: column sums need a 16-byte aligned buffer (not the strided 1x1 scatter)");
+  p.colsum = colsum;
   JTSM_REQUIRE(!row_scale || (p.N % 4 == 0 && aligned16(dx)), "conv backward-data: a row scale needs in_c %% 4 == 0");
   if (dx_hi) {   // planes of the finished gradient (e.g. already gated by relu_mask) for the next layer's contractions
     JTSM_REQUIRE(!scatter, "conv backward-data bf16x3: output planes are not produced by the strided 1x1 scatter path");
@@ -2241,6 +2270,65 @@ int jtsm_conv2d_backward_data_ex_f16(const uint16_t* dy_h, const uint16_t* wt_h,
                                      size_t workspace_bytes, void* stream) {
   return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, relu_mask, grad_shift,
                              workspace, workspace_bytes, stream, gate_plane, row_scale);
+}
+
+// The same data gradients, also leaving the column sums of the finished (gated) result per row tile: the bias gradient
+// of the layer below, taken where its output gradient is written.  colsum: jtsm_conv_bf16x3_colsum_rows(s, role) x in_c
+// floats; the caller adds the rows up (jtsm_channel_sum_f32) in order.
+int jtsm_conv_bf16x3_colsum_rows(const jtsm_conv_shape* s, int role) {
+  if (check_shape(s) || (role != FWD && role != DGRAD)) return 0;
+  Params p = {};
+  p.s = to_shape(s);
+  if (p.s.Ho <= 0 || p.s.Wo <= 0 || !x3_eligible(role, p.s)) return 0;
+  if (role == FWD) { p.M = p.s.Bn * p.s.Ho * p.s.Wo; p.N = p.s.Cout; p.K = p.s.KH * p.s.KW * p.s.Cin; }
+  else {
+    if (p.s.KH == 1 && p.s.KW == 1 && p.s.pad == 0 && p.s.stride > 1) return 0;   // (the scatter form)
+    p.M = p.s.Bn * p.s.H * p.s.W; p.N = p.s.Cin; p.K = p.s.KH * p.s.KW * p.s.Cout;
+  }
+  if (p.M <= 0 || p.N % 4) return 0;
+  const int c = x3_tile_choice(p);
+  return ceil_div(p.M, c == 0 ? 128 : (c == 3 ? 64 : 256));
+}
+int jtsm_conv2d_backward_data_colsum_bf16x3(const uint16_t* dy_hi, const uint16_t* dy_lo, const uint16_t* wt_hi,
+                                            const uint16_t* wt_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                            const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                            const float* relu_mask, const uint16_t* gate_plane, float* colsum,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(colsum, "conv backward-data colsum: null colsum");
+  return x3_backward_data<2>(dy_hi, dy_lo, wt_hi, wt_lo, dx, dx_hi, dx_lo, s, accumulate, relu_mask, 0, workspace,
+                             workspace_bytes, stream, gate_plane, row_scale, colsum);
+}
+int jtsm_conv2d_backward_data_colsum_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                         const jtsm_conv_shape* s, const float* row_scale, const float* accumulate,
+                                         const float* relu_mask, const uint16_t* gate_plane, int grad_shift, float* colsum,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_REQUIRE(colsum, "conv backward-data colsum: null colsum");
+  return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, accumulate, relu_mask, grad_shift,
+                             workspace, workspace_bytes, stream, gate_plane, row_scale, colsum);
+}
+int jtsm_conv_transpose2x2_backward_data_colsum_bf16x3(const uint16_t* g_hi, const uint16_t* g_lo, const uint16_t* w_hi,
+                                                       const uint16_t* w_lo, float* dx, uint16_t* dx_hi, uint16_t* dx_lo,
+                                                       int batch, int h, int w, int in_c, int out_c,
+                                                       const float* relu_mask, const uint16_t* gate_plane, float* colsum,
+                                                       void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_CT_DIMS_OK("conv_transpose2x2 backward-data");
+  JTSM_REQUIRE(colsum, "conv_transpose2x2 backward-data colsum: null colsum");
+  const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
+  FwdExtras ex; ex.mask = relu_mask; ex.mask_plane = gate_plane; ex.colsum = colsum;
+  return x3_forward<2>(g_hi, g_lo, w_hi, w_lo, dx, dx_hi, dx_lo, &g, nullptr, nullptr, nullptr, 0, workspace,
+                       workspace_bytes, stream, ex);
+}
+int jtsm_conv_transpose2x2_backward_data_colsum_f16(const uint16_t* g_h, const uint16_t* w_h, float* dx, uint16_t* dx_h,
+                                                    int batch, int h, int w, int in_c, int out_c, const float* relu_mask,
+                                                    const uint16_t* gate_plane, int grad_shift, float* colsum,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+  JTSM_CT_DIMS_OK("conv_transpose2x2 backward-data");
+  JTSM_REQUIRE(colsum && grad_shift >= 0 && grad_shift <= 24, "conv_transpose2x2 backward-data colsum f16: null colsum / bad grad_shift");
+  const jtsm_conv_shape g = ct_conv_shape(batch, h, w, in_c, out_c);
+  FwdExtras ex; ex.mask = relu_mask; ex.mask_plane = gate_plane; ex.in_shift = grad_shift; ex.out_shift = grad_shift;
+  ex.colsum = colsum;
+  return x3_forward<1>(g_h, nullptr, w_h, nullptr, dx, dx_h, nullptr, &g, nullptr, nullptr, nullptr, 0, workspace,
+                       workspace_bytes, stream, ex);
 }
 
 // dW and db in one contraction (conv_x3.h: x3_bias_mma): db[out_c] = sum over pixels of dy, from the same planes.

@@ -1258,6 +1258,7 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
   // aim at one full round of resident workgroups (measured: tools/sweeps/x3_sweep.py)
   int splits = plan_splits(ntiles, ktiles, round_blocks);
   if (splits > 1 && (size_t)splits * p.M * p.ldc * sizeof(float) > workspace_bytes) splits = 1;
+  if (p.colsum) splits = 1;   // (column sums are taken where the finished result is written: one K slice)
   if (splits > 1) {
     p.ktiles_per_split = ceil_div(ktiles, splits);
     splits = ceil_div(ktiles, p.ktiles_per_split);
@@ -1267,8 +1268,8 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
-  JTSM_REQUIRE((!p.mask_plane && !p.scale_rows && p.C) || p.wide,
-               "conv bf16x3: a gate plane, a row scale or a planes-only result needs N %% 4 == 0 and 16-byte aligned tensors");
+  JTSM_REQUIRE((!p.mask_plane && !p.scale_rows && p.C && !p.colsum) || p.wide,
+               "conv bf16x3: a gate plane, a row scale, column sums or a planes-only result need N %% 4 == 0 and 16-byte aligned tensors");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
   const bool fused = use_fused_finish(p, ntiles, splits, st);
   if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= x3_nbuf1_stages(ROLE))
@@ -1389,7 +1390,7 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
 
 template <int ROLE, int NP = 2>
 int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  if (x3_halo_ok(ROLE, p)) {
+  if (!p.colsum && x3_halo_ok(ROLE, p)) {   // (column sums: the generic kernel's row tiles)
     if (x3_tile_choice(p) == 2) return launch_x3_halo<ROLE, true, NP>(p, q, workspace, workspace_bytes, st);
     return launch_x3_halo<ROLE, false, NP>(p, q, workspace, workspace_bytes, st);
   }

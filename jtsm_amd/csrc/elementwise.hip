@@ -565,6 +565,50 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __rest
   }
 }
 
+
+// Column sums of up to 16 small matrices in ONE launch (the per-row-tile partial sums the data-gradient epilogues leave
+// for a bias gradient, conv_igemm.hip: Params::colsum): block b adds the rows of matrix b — out[b][c] = sum_r
+// part[b][r][c].  Pointers and row counts by value: no table upload.
+constexpr int kFoldMax = 16;
+struct FoldParts {
+  const float* part[kFoldMax];
+  int rows[kFoldMax];
+};
+__global__ __launch_bounds__(1024) void colsum_fold_kernel(const FoldParts f, int width, float* __restrict__ out) {
+  // thread = (16-byte column piece, row group): G = 1024 / (width / 4) row groups each add every G-th row in order with
+  // eight loads in flight, then the groups are added in group order through LDS — a fixed order, reproducible
+  __shared__ float4 red[1024];
+  const int b = blockIdx.x, t = threadIdx.x, cpr = width >> 2, G = 1024 / cpr;
+  const int cg = t % cpr, rg = t / cpr;
+  const int rows = f.rows[b];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rg < G) {
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(f.part[b]) + cg;
+    int r = rg;
+    for (; r + 7 * G < rows; r += 8 * G) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * G) * cpr];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; r < rows; r += G) {
+      const float4 v = p[(size_t)r * cpr];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[t] = acc;
+  __syncthreads();
+  if (t < cpr) {
+    float4 s = red[t];
+    for (int g = 1; g < G; ++g) {
+      const float4 q = red[t + g * cpr];
+      s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
+    }
+    reinterpret_cast<float4*>(out + (size_t)b * width)[t] = s;
+  }
+}
+
 }  // namespace
 }  // namespace jtsm
 
@@ -906,6 +950,20 @@ int jtsm_maxpool2x2_backward_f32(const float* x, const float* gy, float* gx, int
   hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, gy, gx, N, H, W, C, stride,
                      mp2_out(H, stride), mp2_out(W, stride), total);
   JTSM_CHECK_LAUNCH("maxpool2x2 backward");
+  return JTSM_OK;
+}
+
+int jtsm_colsum_fold_f32(const float* const* parts, const int* rows, int n, int width, float* out, void* stream) {
+  JTSM_REQUIRE(n >= 1 && n <= jtsm::kFoldMax && width > 0 && parts && rows && out, "colsum_fold: 1..%d matrices", jtsm::kFoldMax);
+  jtsm::FoldParts f = {};
+  for (int b = 0; b < n; ++b) {
+    JTSM_REQUIRE(parts[b] && rows[b] >= 0, "colsum_fold: matrix %d", b);
+    f.part[b] = parts[b];
+    f.rows[b] = rows[b];
+  }
+  JTSM_REQUIRE(width % 4 == 0 && width <= 4096, "colsum_fold: width %% 4 == 0 and <= 4096, got %d", width);
+  hipLaunchKernelGGL(jtsm::colsum_fold_kernel, dim3(n), dim3(1024), 0, jtsm::as_stream(stream), f, width, out);
+  JTSM_CHECK_LAUNCH("colsum_fold");
   return JTSM_OK;
 }
 

@@ -803,8 +803,89 @@ def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=Fal
     return y if fp32 else yp
 
 
+def _colsum_partials(pl, role, width, device):
+    """(rows, width) buffer for the per-row-tile column sums of a data-gradient launch, or None when the shape has none."""
+    rows = L.lib().jtsm_conv_bf16x3_colsum_rows(C.byref(pl.s), role)
+    return torch.empty((rows, width), dtype=torch.float32, device=device) if rows > 0 else None
+
+
+class ColsumBatch(object):
+    """Bias gradients taken in data-gradient epilogues (planes_backward_data(bias_out=batch.slot(key))): the launches
+    leave per-row-tile partial sums, `finish()` adds them up — all layers of one width in ONE launch — and returns
+    {key: (width,) tensor}."""
+
+    def __init__(self):
+        self.items = []          # (key, partial (rows, width))
+
+    def slot(self, key):
+        return _ColsumSlot(self, key)
+
+    def finish(self):
+        out = {}
+        by_width = {}
+        for key, part in self.items:
+            by_width.setdefault(part.shape[1], []).append((key, part))
+        for width, group in by_width.items():
+            for i0 in range(0, len(group), 16):
+                chunk = group[i0:i0 + 16]
+                sums = torch.empty((len(chunk), width), dtype=torch.float32, device=chunk[0][1].device)
+                ptrs = (C.c_void_p * len(chunk))(*[p.data_ptr() for _, p in chunk])
+                rows = (C.c_int * len(chunk))(*[int(p.shape[0]) for _, p in chunk])
+                L.check(L.lib().jtsm_colsum_fold_f32(ptrs, rows, len(chunk), width, L.ptr(sums), L.stream()), "colsum_fold")
+                for k, (key, _) in enumerate(chunk):
+                    out[key] = sums[k]
+        self.items = []
+        return out
+
+
+class _ColsumSlot(object):
+    __slots__ = ("batch", "key")
+
+    def __init__(self, batch, key):
+        self.batch, self.key = batch, key
+
+    def take(self, part):
+        self.batch.items.append((self.key, part))
+
+
 def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
-                         row_scale=None, kscale=None, both=False, into=None):
+                         row_scale=None, kscale=None, both=False, into=None, bias_out=None):
+    """bias_out (a ColsumBatch slot): ALSO the column sums of the finished (gated) result — the bias gradient of the
+    layer whose output gradient this call produces — taken in the epilogue that writes it.  Returns (result, True)
+    then, or (result, False) when this shape cannot (the caller sums the planes afterwards)."""
+    if bias_out is not None:
+        return _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out)
+    return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, fp32, accumulate, row_scale, kscale, both, into)
+
+
+def _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out):
+    pl = _plan(x_shape, w.shape, stride, pad, dil)
+    part = _colsum_partials(pl, 1, x_shape[1], g.device) if pl.x3[1] else None
+    if part is None:
+        return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, False, None, None, kscale, False, None), False
+    dp = PlaneTensor.empty(x_shape, g.device)
+    gh, gl = _hl(g.buf)
+    wh, wl = _hl(_weight_planes(_cl(w), True, kscale))
+    dh, dl = _hl(dp.buf)
+    gate_h = _hl(gate.buf)[0] if gate is not None else None
+    nbytes = pl.ws[1]
+    ws = _scratch(nbytes, g.device)
+    lib = L.lib()
+    extra = 0.5 * dp.numel if gate is not None else 0
+    if MATH == "f16":
+        L.check(_timed(_x3_variant(pl.s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_colsum_f16(
+            gh, wh, None, dh, pl.ref, None, None, None, gate_h, GRAD_SHIFT, L.ptr(part), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, extra, dp.numel, True, False), "conv2d_backward_data_colsum_f16")
+    else:
+        L.check(_timed(_x3_variant(pl.s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_colsum_bf16x3(
+            gh, gl, wh, wl, None, dh, dl, pl.ref, None, None, None, gate_h, L.ptr(part), L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, extra, dp.numel, True, False), "conv2d_backward_data_colsum_bf16x3")
+    bias_out.take(part)
+    return dp, True
+
+
+def _planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
+                          row_scale=None, kscale=None, both=False, into=None):
     """... kscale: per-output-channel factor folded into the weight rows (FrozenBN).  both: fp32 AND planes."""
     """g: PlaneTensor of the output gradient (gradient planes: times 2^GRAD_SHIFT in fp16 mode); gate: PlaneTensor of
     the ReLU output the result is gated by (or None) -> the input gradient as fp32 tensor (fp32=True) or PlaneTensor."""
@@ -1059,13 +1140,34 @@ def planes_conv_transpose2x2_forward(x, w, bias=None, relu=False, fp32=False):
     return (y, yp) if fp32 else yp
 
 
-def planes_conv_transpose2x2_backward_data(g, w, gate=None):
-    """PlaneTensor g (N, out, 2H, 2W) -> PlaneTensor of dx (N, in, H, W), gated by the PlaneTensor `gate`."""
+def planes_conv_transpose2x2_backward_data(g, w, gate=None, bias_out=None):
+    """PlaneTensor g (N, out, 2H, 2W) -> PlaneTensor of dx (N, in, H, W), gated by the PlaneTensor `gate`.
+    bias_out (in,): see planes_backward_data — then returns (dx, whether bias_out was written)."""
     n, o, h2, w2 = g.shape
     i = w.shape[0]
     h, wd = h2 // 2, w2 // 2
     pl = _plan(g.shape, (i, o, 2, 2), 2, 0, 1)
     dp = PlaneTensor.empty((n, i, h, wd), g.device)
+    part = _colsum_partials(pl, 0, i, g.device) if bias_out is not None else None
+    if part is not None:
+        gh, gl = _hl(g.buf)
+        wh, wl = _hl(_weight_planes(w))
+        dh, dl = _hl(dp.buf)
+        gate_h = _hl(gate.buf)[0] if gate is not None else None
+        nbytes = pl.ws[0]
+        ws = _scratch(nbytes, g.device)
+        lib = L.lib()
+        extra = 0.5 * dp.numel if gate is not None else 0
+        if MATH == "f16":
+            L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_colsum_f16(
+                gh, wh, None, dh, n, h, wd, i, o, None, gate_h, GRAD_SHIFT, L.ptr(part), L.ptr(ws), C.c_size_t(nbytes),
+                L.stream()), pl.desc, extra, dp.numel, True, False), "conv_transpose2x2_backward_data_colsum_f16")
+        else:
+            L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_colsum_bf16x3(
+                gh, gl, wh, wl, None, dh, dl, n, h, wd, i, o, None, gate_h, L.ptr(part), L.ptr(ws), C.c_size_t(nbytes),
+                L.stream()), pl.desc, extra, dp.numel, True, False), "conv_transpose2x2_backward_data_colsum_bf16x3")
+        bias_out.take(part)
+        return dp, True
     gh, gl = _hl(g.buf)
     wh, wl = _hl(_weight_planes(w))
     dh, dl = _hl(dp.buf)
@@ -1082,7 +1184,7 @@ def planes_conv_transpose2x2_backward_data(g, w, gate=None):
         L.check(_timed(_x3_variant(pl.s, 0), pl.flops, lambda: lib.jtsm_conv_transpose2x2_backward_data_bf16x3(
             gh, gl, wh, wl, None, dh, dl, n, h, wd, i, o, None, gate_h, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
             pl.desc, extra, dp.numel, True, False), "conv_transpose2x2_backward_data_bf16x3")
-    return dp
+    return (dp, False) if bias_out is not None else dp
 
 
 def planes_conv_transpose2x2_backward_weight(g, x, w):

@@ -24,6 +24,7 @@ CL = torch.channels_last
 ENABLED = True
 MASK_TOWER = os.environ.get("JTSM_MASK_TOWER", "1") != "0"   # (A/B switch for the mask-head node alone)
 PREGATE = os.environ.get("JTSM_BLOCK_PREGATE", "1") != "0"   # (A/B switch: block-output gates in the next block's epilogue)
+BIAS_COLSUM = os.environ.get("JTSM_BIAS_COLSUM", "1") != "0"  # (A/B switch: mask-tower bias gradients in the data-gradient epilogues)
 
 
 def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=None, emit_planes=False):
@@ -266,6 +267,7 @@ class _MaskTowerFn(Function):
         grads = [None] * (2 * k + 4)
         if dlogits is None and du is None:
             return (None, None) + tuple(grads)
+        sums, deconv_summed = K.ColsumBatch(), False
         # ---- predictor; its data gradient lands gated by the upsampler's ReLU, as planes
         if dlogits is not None:
             dl = dlogits.contiguous(memory_format=CL)
@@ -276,19 +278,34 @@ class _MaskTowerFn(Function):
                 grads[2 * k + 3] = dbp
             elif dbp is not None:
                 grads[2 * k + 3] = channel_sum(dl)
-            gu = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up, accumulate=du)
+            # (a bias gradient is the column sum of its layer's output gradient: taken in the epilogue of the launch that
+            # WRITES that gradient — bias_out of the planes_* data gradients — where the shape allows, otherwise from
+            # the gradient planes in one batched pass at the end)
+            if BIAS_COLSUM and need[2 * k + 1] and du is None:
+                gu, deconv_summed = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up,
+                                                           bias_out=sums.slot(2 * k + 1))
+            else:
+                gu = K.planes_backward_data(gl, wp, up.shape, 1, 0, 1, gate=up, accumulate=du)
         else:   # a gradient into the upsampled features only (the logits unused): the plain ReLU gate, with planes
             gu = K.PlaneTensor.of(relu_backward(du.contiguous(memory_format=CL), ctx.u, emit_planes=True), grad=True)
-        # ---- transposed convolution (bias gradients: all layers' gradient planes are summed in ONE launch at the end)
-        bias_of = []                                   # (slot in grads, gradient planes)
+        # ---- transposed convolution
+        bias_of = []                                   # (slot in grads, gradient planes) still to be summed
+        x_device = gu.buf.device
         if need[2 * k]:
             grads[2 * k] = K.planes_conv_transpose2x2_backward_weight(gu, hs[k], wd)
-        if need[2 * k + 1]:
+        if need[2 * k + 1] and not deconv_summed:
             bias_of.append((2 * k + 1, gu))
-        g = K.planes_conv_transpose2x2_backward_data(gu, wd, gate=hs[k] if k > 0 else None)
-        # ---- the 3x3 tower, last layer first (bias gradients inside the weight-gradient contractions)
+
+        def wants_sum(j):    # layer j's bias gradient is not produced inside its weight-gradient contraction
+            return BIAS_COLSUM and j >= 0 and need[2 * j + 1] and not (need[2 * j] and K.wgrad_bias_fits(hs[j].shape, ws[j].shape, 1, 1, 1))
+
+        summed = False                                 # the column sum of the current g has been delivered
+        if wants_sum(k - 1):
+            g, summed = K.planes_conv_transpose2x2_backward_data(gu, wd, gate=hs[k], bias_out=sums.slot(2 * (k - 1) + 1))
+        else:
+            g = K.planes_conv_transpose2x2_backward_data(gu, wd, gate=hs[k] if k > 0 else None)
+        # ---- the 3x3 tower, last layer first
         dx = None
-        x_device = gu.device
         for j in range(k - 1, -1, -1):
             w = ws[j]
             inside = need[2 * j] and need[2 * j + 1] and K.wgrad_bias_fits(hs[j].shape, w.shape, 1, 1, 1)
@@ -298,11 +315,16 @@ class _MaskTowerFn(Function):
                     grads[2 * j] = K.planes_backward_weight_deferred(g, hs[j], w, 1, 1, 1)
                 else:
                     grads[2 * j] = K.planes_backward_weight(g, hs[j], w, 1, 1, 1, bias_out=db)
-                grads[2 * j + 1] = db
-            if need[2 * j + 1] and not inside:      # (256x256-tile layers: one batched sum over the planes at the end)
+                    grads[2 * j + 1] = db
+            if need[2 * j + 1] and not inside and not summed:
                 bias_of.append((2 * j + 1, g))
+            summed = False
             if j > 0:
-                g = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j])
+                if wants_sum(j - 1):
+                    g, summed = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j],
+                                                       bias_out=sums.slot(2 * (j - 1) + 1))
+                else:
+                    g = K.planes_backward_data(g, w, hs[j].shape, 1, 1, 1, gate=hs[j])
             elif ctx.needs_input_grad[0]:
                 sink = grad_fan.target(ctx.fan, ctx.xshape, g.buf.device)     # (the other head's map: add into it)
                 dx = K.planes_backward_data(g, w, ctx.xshape, 1, 1, 1, fp32=True, into=sink)
@@ -310,6 +332,8 @@ class _MaskTowerFn(Function):
                     dx = None
         if k == 0 and ctx.needs_input_grad[0]:
             raise NotImplementedError("mask tower without 3x3 layers")   # (mask_tower_ok requires k >= 1)
+        for slot, db in sums.finish().items():      # the epilogues' partial sums, all layers in one launch
+            grads[slot] = db
         by_width = {}
         for slot, gp in bias_of:
             by_width.setdefault(gp.shape[1], []).append((slot, gp))
