@@ -578,22 +578,24 @@ __global__ __launch_bounds__(1024) void colsum_fold_kernel(const FoldParts f, in
   // thread = (16-byte column piece, row group): G = 1024 / (width / 4) row groups each add every G-th row in order with
   // eight loads in flight, then the groups are added in group order through LDS — a fixed order, reproducible
   __shared__ float4 red[1024];
-  const int b = blockIdx.x, t = threadIdx.x, cpr = width >> 2, G = 1024 / cpr;
+  // (blockIdx.y: a block of at most 128 columns, so that a 256-wide matrix gets 2 x 32 row groups)
+  const int b = blockIdx.x, t = threadIdx.x, wpr = width >> 2;                 // float4 pieces per row
+  const int c0 = blockIdx.y * 32, cpr = min(32, wpr - c0), G = 1024 / cpr;     // this block's pieces, its row groups
   const int cg = t % cpr, rg = t / cpr;
   const int rows = f.rows[b];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (rg < G) {
-    const float4* __restrict__ p = reinterpret_cast<const float4*>(f.part[b]) + cg;
+    const float4* __restrict__ p = reinterpret_cast<const float4*>(f.part[b]) + c0 + cg;
     int r = rg;
     for (; r + 7 * G < rows; r += 8 * G) {
       float4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * G) * cpr];
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(r + u * G) * wpr];
 #pragma unroll
       for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
     }
     for (; r < rows; r += G) {
-      const float4 v = p[(size_t)r * cpr];
+      const float4 v = p[(size_t)r * wpr];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
   }
@@ -605,7 +607,7 @@ __global__ __launch_bounds__(1024) void colsum_fold_kernel(const FoldParts f, in
       const float4 q = red[t + g * cpr];
       s.x += q.x; s.y += q.y; s.z += q.z; s.w += q.w;
     }
-    reinterpret_cast<float4*>(out + (size_t)b * width)[t] = s;
+    reinterpret_cast<float4*>(out + (size_t)b * width)[c0 + t] = s;
   }
 }
 
@@ -962,7 +964,8 @@ int jtsm_colsum_fold_f32(const float* const* parts, const int* rows, int n, int 
     f.rows[b] = rows[b];
   }
   JTSM_REQUIRE(width % 4 == 0 && width <= 4096, "colsum_fold: width %% 4 == 0 and <= 4096, got %d", width);
-  hipLaunchKernelGGL(jtsm::colsum_fold_kernel, dim3(n), dim3(1024), 0, jtsm::as_stream(stream), f, width, out);
+  hipLaunchKernelGGL(jtsm::colsum_fold_kernel, dim3(n, jtsm::ceil_div(width, 128)), dim3(1024), 0, jtsm::as_stream(stream), f,
+                     width, out);
   JTSM_CHECK_LAUNCH("colsum_fold");
   return JTSM_OK;
 }

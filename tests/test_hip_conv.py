@@ -326,6 +326,55 @@ def test_fused_upsample_cross_entropy_vs_torch_cpu(cuda):
         assert wd.grad[:, c:].abs().max().item() == 0
 
 
+def _plane_values(pt):
+    """fp32 values a PlaneTensor stands for (gradient planes: times 2^GRAD_SHIFT in fp16 mode — left in, both sides alike)."""
+    buf = pt.buf
+    if K.MATH == "f16":
+        return buf[:pt.numel].view(torch.float16).float()
+    half = buf.numel() // 2
+    return buf[:pt.numel].view(torch.bfloat16).float() + buf[half:half + pt.numel].view(torch.bfloat16).float()
+
+
+def test_bias_gradient_from_the_data_gradient_epilogue(cuda):
+    """A layer's bias gradient = the column sums of its output gradient, taken by the launch that WRITES that gradient
+    (planes_backward_data(bias_out=...)): the same planes as the plain call, the sums those of the planes' pass."""
+    if K.MATH == "f32":
+        pytest.skip("plane arithmetics only")
+    g = torch.Generator().manual_seed(21)
+    for (n, c, h, w, o, k, pad) in ((37, 256, 14, 14, 256, 3, 1), (9, 256, 28, 28, 80, 1, 0), (5, 64, 12, 20, 96, 3, 1)):
+        dy = K.PlaneTensor.of((torch.randn(n, o, h, w, generator=g) * 0.1).to(cuda).contiguous(memory_format=CL), grad=True)
+        wt = (torch.randn(o, c, k, k, generator=g) * 0.05).to(cuda).contiguous(memory_format=CL)
+        gate = K.PlaneTensor.of(torch.randn(n, c, h, w, generator=g).to(cuda).contiguous(memory_format=CL))
+        plain = K.planes_backward_data(dy, wt, (n, c, h, w), 1, pad, 1, gate=gate)
+        batch = K.ColsumBatch()
+        got, summed = K.planes_backward_data(dy, wt, (n, c, h, w), 1, pad, 1, gate=gate, bias_out=batch.slot("b"))
+        # (the launch that sums runs one K slice on the generic tiling, the plain call may split K: same values to rounding)
+        assert float((_plane_values(got) - _plane_values(plain)).abs().max()) <= (2e-3 if K.MATH == "f16" else 3e-5) * float(_plane_values(plain).abs().max())
+        if not summed:
+            assert batch.finish() == {}
+            continue
+        db = batch.finish()["b"]
+        ref = K.planes_channel_sum(plain)
+        # (ref sums the 16-bit planes, db the fp32 values they were rounded from: fp16 planes round at 2^-11)
+        bar = 2e-3 if K.MATH == "f16" else 2e-4
+        assert float((db - ref).abs().max()) <= bar * float(ref.abs().max()) + 1e-6, (n, c, h, w)
+        batch2 = K.ColsumBatch()
+        K.planes_backward_data(dy, wt, (n, c, h, w), 1, pad, 1, gate=gate, bias_out=batch2.slot("b"))
+        assert torch.equal(batch2.finish()["b"], db)                         # reproducible bit for bit
+    # the fold alone: ragged row counts, several widths
+    import ctypes as C
+
+    from jtsm_amd import _lib as L
+    for width in (4, 80, 256, 1024):
+        parts = [torch.randn(r, width, generator=g).to(cuda) for r in (1, 7, 965, 130, 2)]
+        out = torch.empty(len(parts), width, device=cuda)
+        ptrs = (C.c_void_p * len(parts))(*[p.data_ptr() for p in parts])
+        rows = (C.c_int * len(parts))(*[p.shape[0] for p in parts])
+        L.check(L.lib().jtsm_colsum_fold_f32(ptrs, rows, len(parts), width, L.ptr(out), L.stream()), "colsum_fold")
+        for p, o_ in zip(parts, out):
+            assert torch.allclose(o_.cpu(), p.cpu().double().sum(0).float(), rtol=1e-5, atol=1e-4)
+
+
 def test_padded_predictor_hands_the_cross_entropy_gradient_through(cuda):
     """54 classes on 56-wide rows (semantic_seg.py:179-188 behind a 1x1 predictor): the slice behind the channel
     padding takes the loss's zero-padded gradient buffer as it is — same gradients as the torch ops, no zeros + copy."""
