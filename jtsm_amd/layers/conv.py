@@ -854,15 +854,17 @@ def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=
     layer whose output gradient this call produces — taken in the epilogue that writes it.  Returns (result, True)
     then, or (result, False) when this shape cannot (the caller sums the planes afterwards)."""
     if bias_out is not None:
-        return _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out)
+        assert not fp32 and not both and accumulate is None and into is None
+        return _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out, row_scale)
     return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, fp32, accumulate, row_scale, kscale, both, into)
 
 
-def _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out):
+def _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out, row_scale=None):
     pl = _plan(x_shape, w.shape, stride, pad, dil)
     part = _colsum_partials(pl, 1, x_shape[1], g.device) if pl.x3[1] else None
     if part is None:
-        return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, False, None, None, kscale, False, None), False
+        return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, False, None, row_scale, kscale, False,
+                                     None), False
     dp = PlaneTensor.empty(x_shape, g.device)
     gh, gl = _hl(g.buf)
     wh, wl = _hl(_weight_planes(_cl(w), True, kscale))
@@ -874,12 +876,12 @@ def _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, 
     extra = 0.5 * dp.numel if gate is not None else 0
     if MATH == "f16":
         L.check(_timed(_x3_variant(pl.s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_colsum_f16(
-            gh, wh, None, dh, pl.ref, None, None, None, gate_h, GRAD_SHIFT, L.ptr(part), L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc, extra, dp.numel, True, False), "conv2d_backward_data_colsum_f16")
+            gh, wh, None, dh, pl.ref, L.ptr(row_scale), None, None, gate_h, GRAD_SHIFT, L.ptr(part), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, extra, dp.numel, True, False), "conv2d_backward_data_colsum_f16")
     else:
         L.check(_timed(_x3_variant(pl.s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_colsum_bf16x3(
-            gh, gl, wh, wl, None, dh, dl, pl.ref, None, None, None, gate_h, L.ptr(part), L.ptr(ws), C.c_size_t(nbytes),
-            L.stream()), pl.desc, extra, dp.numel, True, False), "conv2d_backward_data_colsum_bf16x3")
+            gh, gl, wh, wl, None, dh, dl, pl.ref, L.ptr(row_scale), None, None, gate_h, L.ptr(part), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, extra, dp.numel, True, False), "conv2d_backward_data_colsum_bf16x3")
     bias_out.take(part)
     return dp, True
 

@@ -423,22 +423,37 @@ class _FcStackFn(Function):
         grads = [None] * (2 * k)
         dy = dout.contiguous().view(ys[-1].shape)
         dx = None
+        sums = K.ColsumBatch()
+        gp = summed = keep = None     # (the next layer's gated gradient planes, when its data gradient produced them)
         for j in range(k - 1, -1, -1):
             w = ws[j]
             w4 = w.view(w.shape[0], w.shape[1], 1, 1)
-            g, gbuf = relu_backward_scaled(dy, ys[j], ctx.inv_keep)
-            gp = K.PlaneTensor(gbuf, ys[j].shape)
+            if gp is None:
+                g, gbuf = relu_backward_scaled(dy, ys[j], ctx.inv_keep)
+                gp, summed = K.PlaneTensor(gbuf, ys[j].shape), False
             if need[4 + 2 * j]:
-                db = torch.empty(w.shape[0], dtype=torch.float32, device=g.device) if need[5 + 2 * j] else None
+                db = torch.empty(w.shape[0], dtype=torch.float32, device=dy.device) if (need[5 + 2 * j] and not summed) else None
                 grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1, bias_out=db).view(w.shape)
-                grads[2 * j + 1] = db
-            elif need[5 + 2 * j]:
-                grads[2 * j + 1] = channel_sum(g.view(g.shape[0], -1))
+                if not summed:
+                    grads[2 * j + 1] = db
+            elif need[5 + 2 * j] and not summed:
+                grads[2 * j + 1] = K.planes_channel_sum(gp)
             if j > 0:
-                dy = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, fp32=True)
+                if BIAS_COLSUM and need[5 + 2 * (j - 1)] and ctx.inv_keep > 0:
+                    # layer j - 1's gated gradient straight from this data gradient's epilogue: the ReLU-and-dropout gate
+                    # read off the planes of its (dropped-out) output, the 1 / (1 - p) as a row factor, the bias
+                    # gradient as the column sums — no fp32 copy, no gate pass, no pass for the sum
+                    if keep is None:
+                        keep = torch.full((hs[j].shape[0],), ctx.inv_keep, dtype=torch.float32, device=dy.device)
+                    gp, summed = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, gate=hs[j], row_scale=keep,
+                                                        bias_out=sums.slot(2 * (j - 1) + 1))
+                else:
+                    dy, gp = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, fp32=True), None
             elif need[0]:
                 dx = K.planes_backward_data(gp, w4, hs[0].shape, 1, 0, 1, fp32=True, row_scale=ctx.row_scale)
                 dx = dx.view(dx.shape[0], -1)
+        for slot, db in sums.finish().items():
+            grads[slot] = db
         return (dx, None, None, None) + tuple(grads)
 
 
