@@ -382,10 +382,16 @@ class _FcStackFn(Function):
     exactly where the unit was kept and active), and the input gradient leaves fc_1's data-gradient launch already
     multiplied by row_scale (epilogue).  No torch multiply, dropout or masked-scale kernels.
 
-    apply(x (R, K) dense, row_scale (R,) | None, p, seeds, w_1, b_1, ..., w_k, b_k) -> h_k (R, out_k)."""
+    An optional TAIL — one more linear layer on h_k without ReLU or dropout, e.g. every predictor that reads the box
+    features as one concatenated weight — rides in the same node, so that its data gradient can leave its launch
+    already gated, rescaled and as planes with fc_k's bias gradient as its column sums (otherwise h_k's gradient
+    arrives from outside as an fp32 tensor and takes a gate pass and a pass for the sum).
+
+    apply(x (R, K) dense, row_scale (R,) | None, p, seeds, tail_w (T, out_k) | None, tail_b (T,) | None,
+          w_1, b_1, ..., w_k, b_k) -> (h_k (R, out_k), tail output (R, T) | None)."""
 
     @staticmethod
-    def forward(ctx, x, row_scale, p, seeds, *params):
+    def forward(ctx, x, row_scale, p, seeds, tail_w, tail_b, *params):
         from .elementwise import dropout_split_, split_rowscale
 
         k = len(params) // 2
@@ -407,24 +413,53 @@ class _FcStackFn(Function):
             ys.append(y)
         out = ys[-1].view(r, -1)
         K.planes_put(out, hs[-1].buf)              # the predictor GEMM behind the stack finds its operand planes
-        ctx.k, ctx.hs, ctx.inv_keep = k, hs[:-1], 1.0 / (1.0 - p)
+        tail_out = None
+        if tail_w is not None:
+            t4 = tail_w.view(tail_w.shape[0], tail_w.shape[1], 1, 1)
+            tail_out = K.planes_forward(hs[-1], t4, 1, 0, 1, tail_b, False, fp32=True).view(r, -1)
+        ctx.k, ctx.hs, ctx.inv_keep = k, (hs if tail_w is not None else hs[:-1]), 1.0 / (1.0 - p)
         ctx.row_scale = row_scale
-        ctx.save_for_backward(*ys, *params[0::2])
-        return out
+        ctx.has_tail = tail_w is not None
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*ys, *params[0::2], *([tail_w] if tail_w is not None else []))
+        return out, tail_out
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dout):
+    def backward(ctx, dout, dtail=None):
         from .elementwise import channel_sum, relu_backward_scaled
 
         k, hs = ctx.k, ctx.hs
-        ys, ws = ctx.saved_tensors[:k], ctx.saved_tensors[k:]
-        need = ctx.needs_input_grad
+        ys, ws = ctx.saved_tensors[:k], ctx.saved_tensors[k:2 * k]
+        need = ctx.needs_input_grad[2:]            # (tail_w, tail_b, w_1, b_1, ...: need[4 + 2 j] is w_j's as before)
         grads = [None] * (2 * k)
-        dy = dout.contiguous().view(ys[-1].shape)
+        g_tw = g_tb = None
+        if dout is None and dtail is None:
+            return (None,) * (6 + 2 * k)
+        dev = (dout if dout is not None else dtail).device
+        dy = dout.contiguous().view(ys[-1].shape) if dout is not None else None
         dx = None
         sums = K.ColsumBatch()
         gp = summed = keep = None     # (the next layer's gated gradient planes, when its data gradient produced them)
+        if ctx.has_tail and dtail is not None:
+            tw = ctx.saved_tensors[2 * k]
+            t4 = tw.view(tw.shape[0], tw.shape[1], 1, 1)
+            dl = dtail.contiguous().view(dtail.shape[0], dtail.shape[1], 1, 1)
+            gl = K.PlaneTensor.of(dl, grad=True)
+            if need[2]:
+                g_tb = torch.empty(tw.shape[0], dtype=torch.float32, device=dev) if need[3] else None
+                g_tw = K.planes_backward_weight(gl, hs[k], t4, 1, 0, 1, bias_out=g_tb).view(tw.shape)
+            elif need[3]:
+                g_tb = channel_sum(dl.view(dl.shape[0], -1))
+            if dy is None and BIAS_COLSUM and need[5 + 2 * (k - 1)]:
+                # h_k is read by the tail alone: its gradient leaves the tail's data gradient gated, rescaled, as planes,
+                # with fc_k's bias gradient as the column sums
+                keep = torch.full((hs[k].shape[0],), ctx.inv_keep, dtype=torch.float32, device=dev)
+                gp, summed = K.planes_backward_data(gl, t4, hs[k].shape, 1, 0, 1, gate=hs[k], row_scale=keep,
+                                                    bias_out=sums.slot(2 * (k - 1) + 1))
+            else:
+                dt = K.planes_backward_data(gl, t4, hs[k].shape, 1, 0, 1, fp32=True)
+                dy = dt if dy is None else dy + dt
         for j in range(k - 1, -1, -1):
             w = ws[j]
             w4 = w.view(w.shape[0], w.shape[1], 1, 1)
@@ -432,7 +467,7 @@ class _FcStackFn(Function):
                 g, gbuf = relu_backward_scaled(dy, ys[j], ctx.inv_keep)
                 gp, summed = K.PlaneTensor(gbuf, ys[j].shape), False
             if need[4 + 2 * j]:
-                db = torch.empty(w.shape[0], dtype=torch.float32, device=dy.device) if (need[5 + 2 * j] and not summed) else None
+                db = torch.empty(w.shape[0], dtype=torch.float32, device=dev) if (need[5 + 2 * j] and not summed) else None
                 grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1, bias_out=db).view(w.shape)
                 if not summed:
                     grads[2 * j + 1] = db
@@ -444,17 +479,17 @@ class _FcStackFn(Function):
                     # read off the planes of its (dropped-out) output, the 1 / (1 - p) as a row factor, the bias
                     # gradient as the column sums — no fp32 copy, no gate pass, no pass for the sum
                     if keep is None:
-                        keep = torch.full((hs[j].shape[0],), ctx.inv_keep, dtype=torch.float32, device=dy.device)
+                        keep = torch.full((hs[j].shape[0],), ctx.inv_keep, dtype=torch.float32, device=dev)
                     gp, summed = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, gate=hs[j], row_scale=keep,
                                                         bias_out=sums.slot(2 * (j - 1) + 1))
                 else:
                     dy, gp = K.planes_backward_data(gp, w4, hs[j].shape, 1, 0, 1, fp32=True), None
-            elif need[0]:
+            elif ctx.needs_input_grad[0]:
                 dx = K.planes_backward_data(gp, w4, hs[0].shape, 1, 0, 1, fp32=True, row_scale=ctx.row_scale)
                 dx = dx.view(dx.shape[0], -1)
         for slot, db in sums.finish().items():
             grads[slot] = db
-        return (dx, None, None, None) + tuple(grads)
+        return (dx, None, None, None, g_tw, g_tb) + tuple(grads)
 
 
 def fc_stack_ok(x2d, fcs):
@@ -465,9 +500,21 @@ def fc_stack_ok(x2d, fcs):
     return all(fc.bias is not None and fc.out_features % 32 == 0 and fc.in_features % 32 == 0 for fc in fcs)
 
 
-def fc_stack_fused(x2d, fcs, row_scale=None, p=0.0):
+def fc_stack_fused(x2d, fcs, row_scale=None, p=0.0, tail=None):
+    """tail = (weights, biases) of linear layers that read the stack's output (every predictor of the box head): run
+    as ONE more GEMM inside the node (see _FcStackFn); then returns (features, [one output per tail layer])."""
     seeds = tuple(int(torch.randint(0, 2 ** 62, (1,)).item()) for _ in fcs) if p > 0 else None
     params = []
     for fc in fcs:
         params += [fc.weight, fc.bias]
-    return _FcStackFn.apply(x2d, row_scale, float(p), seeds, *params)
+    if tail is None:
+        return _FcStackFn.apply(x2d, row_scale, float(p), seeds, None, None, *params)[0]
+    weights, biases = list(tail[0]), list(tail[1])
+    sizes = [w.shape[0] for w in weights]
+    pad = (-sum(sizes)) % 4                      # (16-byte rows: as layers/conv.py linear_fused_split pads)
+    if pad:
+        weights.append(weights[0].new_zeros((pad, weights[0].shape[1])))
+        biases.append(biases[0].new_zeros(pad))
+    out, y = _FcStackFn.apply(x2d, row_scale, float(p), seeds, torch.cat(weights), torch.cat(biases), *params)
+    outs = K._ColumnSplit.apply(y, *(sizes + ([pad] if pad else [])))
+    return out, list(outs[:len(sizes)])

@@ -11,6 +11,8 @@ import torch
 from torch import nn
 
 from ...layers.fused_blocks import fc_stack_fused, fc_stack_ok
+
+_FC_TAIL = __import__("os").environ.get("JTSM_FC_TAIL", "1") != "0"   # (A/B switch: the predictors' GEMM inside the stack's node)
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d, Linear
 from ...utils.registry import Registry
@@ -75,14 +77,19 @@ class DiscriminativeAdaptionNeck(nn.Module):
         if key in state_dict:
             state_dict[key] = module._hwc_cols(state_dict[key], False)
 
-    def forward(self, x, roi_scale=None):
+    def forward(self, x, roi_scale=None, tail=None):
         """roi_scale (R,), optional: the per-roi factor the features are multiplied by first
-        (roi_heads_jtsm.py:607-633) — folded into the fused stack's plane split and data-gradient epilogue."""
+        (roi_heads_jtsm.py:607-633) — folded into the fused stack's plane split and data-gradient epilogue.
+        tail = (weights, biases) of the linear layers that read the features (the box predictors), optional: run as
+        one more GEMM of the same autograd node when the fused stack takes the call — the return value is then
+        (features, [one output per tail layer]); otherwise the features alone, and the caller applies its layers."""
         if x.dim() == 4:
             if x.shape[2] * x.shape[3] > 1:
                 x = x.permute(0, 2, 3, 1)               # (h,w,c) order: a view of a channels_last tensor
             x = x.reshape(x.shape[0], -1)
         if fc_stack_ok(x, self.fcs):                    # one autograd node (layers/fused_blocks.py: _FcStackFn)
+            if tail is not None and _FC_TAIL and all(w.shape[1] == self.fcs[-1].out_features for w in tail[0]):
+                return fc_stack_fused(x, self.fcs, roi_scale, self.dropout_p if self.training else 0.0, tail=tail)
             return fc_stack_fused(x, self.fcs, roi_scale, self.dropout_p if self.training else 0.0)
         if roi_scale is not None:
             x = x * roi_scale.view(-1, 1)

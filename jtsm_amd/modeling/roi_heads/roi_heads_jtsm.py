@@ -259,11 +259,15 @@ class JTSMROIHeads(ROIHeads):
             losses.update(self._forward_mask(mask_features if mask_features is not None else features, proposals))
         return proposals, losses
 
-    def _predictor_gemm(self, x):
-        """cls, det and every refinement head in one GEMM; returns the column slices."""
+    def _predictor_layers(self):
         mods = [self.box_predictor.cls, self.box_predictor.det]
         for r in self.box_refinery:
             mods += [r.cls_score] + ([r.bbox_pred] if r.has_reg else [])
+        return mods
+
+    def _predictor_gemm(self, x):
+        """cls, det and every refinement head in one GEMM; returns the column slices."""
+        mods = self._predictor_layers()
         return linear_fused_split(x, [m.weight for m in mods], [m.bias for m in mods])
 
     def _box_features(self, features, proposals):
@@ -286,7 +290,12 @@ class JTSMROIHeads(ROIHeads):
         # reference: (features * mask_scale) * (objectness + 1), two passes; here one combined factor, which the box
         # head folds into the plane split in front of fc1 and into fc1's data-gradient epilogue (no multiply pass)
         if getattr(self.box_head, "takes_roi_scale", False):
-            box_features = self.box_head(box_features, roi_scale=roi_scale)
+            # (the predictors' GEMM rides in the box head's node when that is the fused stack: `tail`)
+            mods = self._predictor_layers()
+            res = self.box_head(box_features, roi_scale=roi_scale, tail=([m.weight for m in mods], [m.bias for m in mods]))
+            if isinstance(res, tuple):
+                return res[1], argmax
+            box_features = res
         else:
             box_features = self.box_head(box_features * roi_scale.view(-1, 1, 1, 1))
         return self._predictor_gemm(box_features), argmax
