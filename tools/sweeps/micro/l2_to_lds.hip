@@ -106,13 +106,17 @@ void run(const char* A, const char* B, long plane_bytes, int K, int ntm, int ntn
   }
   CHECK(hipGetLastError());
   const double bytes = (double)ntm * ntn * stages * 65536.0;
+  const int wgs = ntm * ntn < 256 ? ntm * ntn : 256;     // CUs at work
   printf("%-44s %8.1f us  %6.2f TB/s  %5.1f GB/s per CU  %5.1f B/clk/CU at 2.4 GHz\n", what, best * 1e3, bytes / best / 1e9,
-         bytes / best / 1e6 / 256, bytes / best / 1e6 / 256 / 2.4);
+         bytes / best / 1e6 / wgs, bytes / best / 1e6 / wgs / 2.4);
 }
 
-int main() {
-  const int K = 4096, ntm = 16, ntn = 16;       // 256 workgroups; A, B: 4096 rows x 4096 k, two planes each
-  const long plane_bytes = (long)ntm * 256 * K * 2;
+int main(int argc, char** argv) {
+  // K (elements per row: the row pitch is 2 K bytes — a power of two by default, as the fully connected layers' operands
+  // have; try 4160 for a pitch that is not) and the tile grid (ntm x ntn workgroups: fewer than 256 = a part of the chip)
+  const int K = argc > 1 ? atoi(argv[1]) : 4096, ntm = argc > 2 ? atoi(argv[2]) : 16, ntn = argc > 3 ? atoi(argv[3]) : 16;
+  printf("K %d (row pitch %d B), %d x %d workgroups\n", K, 2 * K, ntm, ntn);
+  const long plane_bytes = (long)(ntm > ntn ? ntm : ntn) * 256 * K * 2;
   char *A, *B; float* sink;
   CHECK(hipMalloc(&A, 2 * plane_bytes)); CHECK(hipMalloc(&B, 2 * plane_bytes)); CHECK(hipMalloc(&sink, 64));
   CHECK(hipMemset(A, 1, 2 * plane_bytes)); CHECK(hipMemset(B, 2, 2 * plane_bytes));
