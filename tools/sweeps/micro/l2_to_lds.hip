@@ -21,7 +21,7 @@ __device__ __forceinline__ void dma16b(const void* g, void* lds) {
 // operand: planes hi, lo of [rows][K] bf16 (K * 2 bytes per row).  Workgroup (tm, tn): A rows tm*256.., B rows tn*256..
 template <int MODE, int DEPTH>
 __global__ __launch_bounds__(512, 2) void deliver(const char* __restrict__ A, const char* __restrict__ B, long plane_bytes,
-                                                  int K, int stages, int ntn, float* __restrict__ sink, int paired) {
+                                                  int K, int stages, int ntn, float* __restrict__ sink, int paired, int rot) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int tile = blockIdx.x;
@@ -39,13 +39,17 @@ __global__ __launch_bounds__(512, 2) void deliver(const char* __restrict__ A, co
     src[4 + 2 * j] = B + offB; src[4 + 2 * j + 1] = B + (paired ? 64 : plane_bytes) + offB;
   }
   const long step = paired ? 128 : 64;
+  // rot: workgroup w walks K from stage (rot * w) % stages on, wrapping — so that the chip does not ask every L2 channel
+  // for the same k offset of (power-of-two-pitched) rows at the same time
+  const int t_rot = rot ? (int)(((long)blockIdx.x * rot) % stages) : 0;
+#define ST(t) (((t) + t_rot) % stages)
   f4 acc = {0.f, 0.f, 0.f, 0.f};
   if (MODE == 0) {
     constexpr int STAGE = 65536;
     auto issue = [&](int t) {
       char* St = lds + (t % DEPTH) * STAGE;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dma16b(src[i] + (long)t * step, St + (wave * 8 + i) * 1024);
+      for (int i = 0; i < 8; ++i) dma16b(src[i] + (long)ST(t) * step, St + (wave * 8 + i) * 1024);
     };
     for (int t = 0; t < DEPTH - 1 && t < stages; ++t) issue(t);
     for (int t = 0; t < stages; ++t) {
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void deliver(const char* __restrict__ A, co
     f4 r[DEPTH][8];
     auto issue = [&](int t, int set) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) r[set][i] = *reinterpret_cast<const f4*>(src[i] + (long)t * step);
+      for (int i = 0; i < 8; ++i) r[set][i] = *reinterpret_cast<const f4*>(src[i] + (long)ST(t) * step);
     };
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) if (d < stages) issue(d, d);
@@ -90,6 +94,8 @@ __global__ __launch_bounds__(512, 2) void deliver(const char* __restrict__ A, co
 
 template <int MODE, int DEPTH>
 void run(const char* A, const char* B, long plane_bytes, int K, int ntm, int ntn, float* sink, const char* what, int paired = 0) {
+  extern int g_rot;
+  const int rot = g_rot;
   const int stages = K / 32;
   const int ldsb = MODE == 0 ? DEPTH * 65536 : (MODE == 1 ? 131072 : 0);
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(deliver<MODE, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
@@ -98,7 +104,7 @@ void run(const char* A, const char* B, long plane_bytes, int K, int ntm, int ntn
   float best = 1e9f;
   for (int rep = 0; rep < 5; ++rep) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL((deliver<MODE, DEPTH>), dim3(ntm * ntn), dim3(512), ldsb, 0, A, B, plane_bytes, K, stages, ntn, sink, paired);
+    hipLaunchKernelGGL((deliver<MODE, DEPTH>), dim3(ntm * ntn), dim3(512), ldsb, 0, A, B, plane_bytes, K, stages, ntn, sink, paired, rot);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -111,11 +117,13 @@ void run(const char* A, const char* B, long plane_bytes, int K, int ntm, int ntn
          bytes / best / 1e6 / wgs, bytes / best / 1e6 / wgs / 2.4);
 }
 
+int g_rot = 0;
 int main(int argc, char** argv) {
+  g_rot = argc > 4 ? atoi(argv[4]) : 0;
   // K (elements per row: the row pitch is 2 K bytes — a power of two by default, as the fully connected layers' operands
   // have; try 4160 for a pitch that is not) and the tile grid (ntm x ntn workgroups: fewer than 256 = a part of the chip)
   const int K = argc > 1 ? atoi(argv[1]) : 4096, ntm = argc > 2 ? atoi(argv[2]) : 16, ntn = argc > 3 ? atoi(argv[3]) : 16;
-  printf("K %d (row pitch %d B), %d x %d workgroups\n", K, 2 * K, ntm, ntn);
+  printf("K %d (row pitch %d B), %d x %d workgroups, K order rotated by %d stages per workgroup\n", K, 2 * K, ntm, ntn, g_rot);
   const long plane_bytes = (long)(ntm > ntn ? ntm : ntn) * 256 * K * 2;
   char *A, *B; float* sink;
   CHECK(hipMalloc(&A, 2 * plane_bytes)); CHECK(hipMalloc(&B, 2 * plane_bytes)); CHECK(hipMalloc(&sink, 64));
