@@ -682,6 +682,17 @@ int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois,
                                       const int32_t* roi_level, int level, float* grad_input, int B,
                                       int C, int H, int W, int M, float spatial_scale, int pooled_h,
                                       int pooled_w, int sampling_ratio, int aligned, void* stream);
+/* Rotated boxes (M,6) on one FPN level: ROIPooler's level loop with pooler_type "ROIAlignRotated"
+ * (detectron2/modeling/poolers.py:160-165,230-249; ROIAlignRotated.h:7-27 per level).  accumulate != 0: grad_input
+ * already holds a gradient and is added to (nothing is cleared). */
+int jtsm_roi_align_rotated_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
+                                             int level, float* output, int B, int C, int H, int W, int M,
+                                             float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                             void* stream);
+int jtsm_roi_align_rotated_backward_level_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                              int level, float* grad_input, int B, int C, int H, int W, int M,
+                                              float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                              int accumulate, void* stream);
 /* All levels' gradient maps in ONE call (the backward of ROIPooler's level loop, detectron2/modeling/poolers.py:236-247):
  * grad_inputs[l] (nullable: that level needs no gradient) is the (B,H[l],W[l],C) NHWC map of the rois with
  * roi_level[m] == l.  The tiles of every level are workgroups of one launch.

@@ -1077,6 +1077,27 @@ int jtsm_roi_align_backward_level_f32(const float* grad, const float* rois, cons
                                        pooled_w, sampling_ratio, aligned, JTSM_NHWC, stream, roi_level, level);
 }
 
+// Rotated boxes on one FPN level (the level loop of ROIPooler.forward runs for every pooler type,
+// detectron2/modeling/poolers.py:160-165,230-249): rois are (M,6), the launch serves the rois with roi_level[m] == level.
+// The backward is the scatter form (float atomics) on that level's map; accumulate != 0 adds into a map that already
+// holds a gradient instead of clearing it first.
+int jtsm_roi_align_rotated_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
+                                             int level, float* output, int B, int C, int H, int W, int M,
+                                             float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                             void* stream) {
+  JTSM_REQUIRE(roi_level || M == 0, "roi_align_rotated level: null roi_level");
+  return launch_forward<float, true>(input, rois, output, B, C, H, W, M, spatial_scale, pooled_h, pooled_w,
+                                     sampling_ratio, 1, JTSM_NHWC, stream, roi_level, level);
+}
+int jtsm_roi_align_rotated_backward_level_f32(const float* grad, const float* rois, const int32_t* roi_level,
+                                              int level, float* grad_input, int B, int C, int H, int W, int M,
+                                              float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio,
+                                              int accumulate, void* stream) {
+  JTSM_REQUIRE(roi_level || M == 0, "roi_align_rotated level: null roi_level");
+  return launch_backward<float, true>(grad, rois, grad_input, B, C, H, W, M, spatial_scale, pooled_h, pooled_w,
+                                      sampling_ratio, 1, JTSM_NHWC, stream, roi_level, level, accumulate != 0);
+}
+
 int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                        float* const* grad_inputs, const int* H, const int* W, const float* scales,
                                        int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,

@@ -44,7 +44,8 @@ def assign_boxes_to_levels(box_lists, min_level, max_level, canonical_box_size, 
 
 
 def convert_boxes_to_pooler_format(box_lists):
-    """list[Boxes] -> (M,5) [batch index, x0, y0, x1, y1] (poolers.py:61-95)."""
+    """list[Boxes] -> (M,5) [batch index, x0, y0, x1, y1]; list[RotatedBoxes] -> (M,6) [batch index, x_ctr, y_ctr,
+    width, height, angle] (poolers.py:61-95)."""
     def fmt_box_list(box_tensor, batch_index):
         repeated_index = torch.full((len(box_tensor), 1), batch_index, dtype=box_tensor.dtype,
                                     device=box_tensor.device)
@@ -68,7 +69,11 @@ _CLAIMS = []
 class _AlignLevels(Function):
     @staticmethod
     def forward(ctx, rois, roi_level, res, sampling_ratio, aligned, scales, *feats):
+        """aligned: False / True = ROIAlign / ROIAlignV2 on (M,5) rois; "rotated" = ROIAlignRotated on (M,6) rois."""
         ctx.fans = _CLAIMS.pop() if _CLAIMS else [None] * len(feats)
+        rotated = aligned == "rotated"
+        if rois.shape[1] != (6 if rotated else 5):
+            raise RuntimeError("pooler rois must be (M, %d), got %s" % (6 if rotated else 5, tuple(rois.shape)))
         feats = [_feat(f) for f in feats]
         M, C = rois.shape[0], feats[0].shape[1]
         out = torch.empty((M, C, res, res), dtype=torch.float32, device=rois.device, memory_format=CL)  # every roi is on exactly one level, whose kernel writes all of its bins
@@ -77,6 +82,11 @@ class _AlignLevels(Function):
             # algorithmic bytes: this level's share of the output + the level's map read once (an upper
             # bound on the unique feature bytes touched) + the rois
             L.note_bytes(4.0 * (out.numel() / len(feats) + f.numel() + rois.numel()))
+            if rotated:
+                L.check(L.lib().jtsm_roi_align_rotated_forward_level_f32(
+                    L.ptr(f), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(out), B, C, H, W, M, L.f32(sc), res, res,
+                    sampling_ratio, L.stream()), "roi_align_rotated_forward_level")
+                continue
             L.check(L.lib().jtsm_roi_align_forward_level_f32(
                 L.ptr(f), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(out), B, C, H, W, M, L.f32(sc), res, res,
                 sampling_ratio, int(aligned), L.stream()), "roi_align_forward_level")
@@ -100,6 +110,20 @@ class _AlignLevels(Function):
         grads = [(sinks[lvl] if accumulate else torch.empty(shapes[lvl], dtype=torch.float32, device=g.device,
                                                             memory_format=CL)) if wanted[lvl] else None
                  for lvl in range(nl)]
+        if aligned == "rotated":
+            # the scatter form, level by level (no planned gather for rotated sample grids)
+            for lvl in range(nl):
+                if grads[lvl] is None:
+                    continue
+                L.note_bytes(4.0 * (g.numel() / nl + grads[lvl].numel() + rois.numel()))
+                L.check(L.lib().jtsm_roi_align_rotated_backward_level_f32(
+                    L.ptr(g), L.ptr(rois), L.ptr(roi_level), lvl, L.ptr(grads[lvl]), B, Cc, shapes[lvl][2],
+                    shapes[lvl][3], rois.shape[0], L.f32(scales[lvl]), res, res, sampling_ratio, int(accumulate),
+                    L.stream()), "roi_align_rotated_backward_level")
+            if accumulate:
+                return (None,) * (6 + nl)
+            grads = [None if grad_fan.offer(ctx.fans[lvl], grads[lvl]) else grads[lvl] for lvl in range(nl)]
+            return (None, None, None, None, None, None, *grads)
         Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
         Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
         sc = (C.c_float * nl)(*[float(x) for x in scales])
@@ -271,11 +295,9 @@ class ROIPooler(nn.Module):
                                                            self.canonical_box_size, self.canonical_level)
             roi_level = level_assignments.to(torch.int32).contiguous()
         rois = pooler_fmt_boxes.to(torch.float32).contiguous()
-        if self.pooler_type == "ROIAlignRotated" and not moi:
-            raise NotImplementedError("multi-level ROIAlignRotated is outside the JTSM path")
         del _CLAIMS[:]
         _CLAIMS.append([grad_fan.claim(f) for f in x])
         if moi:
             return _MOILevels.apply(rois, roi_level, self.output_size[0], self.scales, labels, sp, *x)
-        return _AlignLevels.apply(rois, roi_level, self.output_size[0], self.sampling_ratio,
-                                  self.pooler_type == "ROIAlignV2", self.scales, *x)
+        mode = "rotated" if self.pooler_type == "ROIAlignRotated" else self.pooler_type == "ROIAlignV2"
+        return _AlignLevels.apply(rois, roi_level, self.output_size[0], self.sampling_ratio, mode, self.scales, *x)

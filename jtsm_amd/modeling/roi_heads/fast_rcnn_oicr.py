@@ -10,7 +10,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ...layers.postprocess import fast_rcnn_inference_device, oicr_predict
-from ...layers.wrappers import Linear
+from ...layers.wrappers import Linear, cat
 from ...layers.wsl_losses import oicr_loss
 from ...structures import Boxes, Instances
 from ..box_regression import Box2BoxTransform
@@ -86,9 +86,27 @@ class OICROutputLayers(nn.Module):
         return scores, torch.zeros(scores.shape[0], self.num_bbox_reg_classes * self.box_dim, dtype=scores.dtype,
                                    device=scores.device)
 
-    def losses(self, predictions, proposal_boxes, gt_classes, gt_boxes, gt_weights):
-        """predictions = (logits (R,K+1), deltas (R,4K)); the rest are cat'ed over images."""
+    def losses(self, predictions, proposals, gt_classes=None, gt_boxes=None, gt_weights=None):
+        """predictions = (logits (R,K+1), deltas (R,4K)).  Two ways in:
+
+        * the reference's `losses(predictions, proposals)` (fast_rcnn_oicr.py:562-586, OICROutputs.__init__ :180-250):
+          `proposals` is a list[Instances] with `proposal_boxes`, `gt_classes`, `gt_weights` and (optionally, an image
+          without targets has none: the proposal boxes stand in, :232-236) `gt_boxes`;
+        * the fused form JTSMROIHeads uses: `proposals` is the (R,4) tensor of proposal boxes cat'ed over the images and
+          the three label tensors are passed beside it (they come straight from the labelling kernel)."""
         scores, deltas = predictions
+        if isinstance(proposals, (list, tuple)):
+            if not len(proposals):
+                zero = 0.0 * scores.sum()
+                k = "_r" + str(self.refine_k)
+                return {"loss_cls" + k: zero, **({"loss_box_reg" + k: 0.0 * deltas.sum()} if self.has_reg else {})}
+            proposal_boxes = cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+            assert not proposal_boxes.requires_grad, "Proposals should not require gradients!"
+            gt_classes = cat([p.gt_classes for p in proposals], dim=0)
+            gt_boxes = cat([(p.gt_boxes if p.has("gt_boxes") else p.proposal_boxes).tensor for p in proposals], dim=0)
+            gt_weights = cat([p.gt_weights for p in proposals], dim=0)
+        else:
+            proposal_boxes = proposals
         lc, lb = oicr_loss(scores, deltas if self.has_reg else None, gt_classes, gt_weights,
                            proposal_boxes if self.has_reg else None, gt_boxes if self.has_reg else None)
         k = "_r" + str(self.refine_k)

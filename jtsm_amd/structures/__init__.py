@@ -2,5 +2,6 @@
 from .boxes import Boxes, pairwise_iou
 from .image_list import ImageList
 from .instances import Instances
+from .rotated_boxes import RotatedBoxes
 
-__all__ = ["Boxes", "pairwise_iou", "ImageList", "Instances"]
+__all__ = ["Boxes", "pairwise_iou", "ImageList", "Instances", "RotatedBoxes"]

@@ -126,6 +126,71 @@ def test_oicr_forward_backward(cuda, R, with_box):
         rel_close(dd.grad, d.grad, what="dd")
 
 
+@pytest.mark.parametrize("reg", [True, False])
+def test_oicr_output_layers_reference_shaped_surface(cuda, reg):
+    """OICROutputLayers.forward(x) -> (scores, deltas) and .losses(predictions, proposals) with a list[Instances]
+    carrying proposal_boxes / gt_classes / gt_boxes / gt_weights (fast_rcnn_oicr.py:534-586, OICROutputs :180-380):
+    values and the gradients that reach cls_score / bbox_pred against the oracle's weighted CE + weighted L1 on
+    copies of the same weights; an image WITHOUT gt_boxes (all background: the proposal boxes stand in, :232-236);
+    the same numbers as the fused tensor form JTSMROIHeads calls; an empty proposal list."""
+    from jtsm_amd.modeling.box_regression import Box2BoxTransform
+    from jtsm_amd.modeling.roi_heads.fast_rcnn_oicr import OICROutputLayers
+    from jtsm_amd.structures import Boxes, Instances
+
+    g = torch.Generator().manual_seed(23)
+    counts, feat, K = [61, 9, 130], 64, OM.NUM_THINGS
+    R = sum(counts)
+    head = OICROutputLayers(feat, num_classes=K, box2box_transform=Box2BoxTransform(weights=(10.0, 10.0, 5.0, 5.0)),
+                            refine_k=1, refine_reg=[False, reg, False, False]).to(cuda)
+    with torch.no_grad():
+        head.cls_score.weight.mul_(30)
+        head.bbox_pred.weight.mul_(100)
+    x = torch.randn(R, feat, generator=g)
+    labels = torch.randint(0, K + 1, (R,), generator=g)
+    labels[torch.rand(R, generator=g) < 0.6] = K
+    labels[:2] = torch.tensor([-1, 3])
+    w = torch.rand(R, generator=g)
+    w[torch.rand(R, generator=g) < 0.2] = 0.0
+    prop = torch.rand(R, 4, generator=g) * 200
+    prop[:, 2:] += prop[:, :2] + 4
+    gt = prop + torch.randn(R, 4, generator=g) * 3
+    gt[:, 2:] = torch.max(gt[:, 2:], gt[:, :2] + 2)
+    s1 = slice(counts[0], counts[0] + counts[1])
+    labels[s1] = K                                   # the second image has no target: no gt_boxes field
+    gt[s1] = prop[s1]
+    props = []
+    for i, (b, c, t, ww) in enumerate(zip(prop.split(counts), labels.split(counts), gt.split(counts), w.split(counts))):
+        inst = Instances((256, 256), proposal_boxes=Boxes(b.to(cuda)), gt_classes=c.to(cuda), gt_weights=ww.to(cuda))
+        if i != 1:
+            inst.gt_boxes = Boxes(t.to(cuda))
+        props.append(inst)
+    wc, bc = head.cls_score.weight.detach().cpu().clone().requires_grad_(), head.cls_score.bias.detach().cpu().clone().requires_grad_()
+    wb, bb = head.bbox_pred.weight.detach().cpu().clone().requires_grad_(), head.bbox_pred.bias.detach().cpu().clone().requires_grad_()
+    z0 = F.linear(x, wc, bc)
+    d0 = F.linear(x, wb, bb) if reg else torch.zeros(R, 4 * K)
+    lc0, lb0 = OM.oicr_losses(z0, d0, prop, dict(classes=labels, boxes=gt, weights=w))
+    (lc0 + (lb0 if reg else 0)).backward()
+    pred = head(x.to(cuda))
+    assert pred[0].shape == (R, K + 1) and pred[1].shape == (R, 4 * K)
+    if not reg:
+        assert float(pred[1].abs().sum()) == 0.0
+    out = head.losses(pred, props)
+    assert set(out) == ({"loss_cls_r1", "loss_box_reg_r1"} if reg else {"loss_cls_r1"})
+    rel_close(out["loss_cls_r1"], lc0, what="loss_cls")
+    if reg:
+        rel_close(out["loss_box_reg_r1"], lb0, what="loss_box_reg")
+    sum(out.values()).backward()
+    rel_close(head.cls_score.weight.grad, wc.grad, what="d cls_score.weight")
+    rel_close(head.cls_score.bias.grad, bc.grad, what="d cls_score.bias")
+    if reg:
+        rel_close(head.bbox_pred.weight.grad, wb.grad, what="d bbox_pred.weight")
+    fused = head.losses(pred, prop.to(cuda), labels.to(cuda), gt.to(cuda), w.to(cuda))
+    for k in out:
+        assert float(fused[k]) == float(out[k]), k
+    empty = head.losses((pred[0][:0], pred[1][:0]), [])
+    assert all(float(v) == 0.0 for v in empty.values())
+
+
 def test_fused_mining_and_labelling_vs_oracle(cuda):
     """mine_top1 + match_label (jtsm_amd/csrc/mining.hip) against oracle/model.py's per-image torch
     restatement of get_pgt_top_k / label_and_sample_proposals: winning rows, labels and matched indices

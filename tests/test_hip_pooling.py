@@ -289,6 +289,69 @@ def test_fpn_level_assignment_and_multilevel_pooling_match_oracle(cuda):
         assert np.allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def test_multilevel_roi_align_rotated_pooler_matches_oracle_and_v2_at_zero_degrees(cuda):
+    """ROIPooler's level loop with pooler_type "ROIAlignRotated" (detectron2/modeling/poolers.py:160-165,230-249) on a
+    4-level pyramid: (1) rotated boxes at random angles — the level of each box from width x height
+    (RotatedBoxes.area), forward bit-exact against the C oracle's rotated kernel run level by level (gather / pool /
+    scatter as the reference does), backward 1e-5; (2) the reference's own pooler test
+    (tests/modeling/test_roi_pooler.py:15-60): ROIAlignV2 on (x0,y0,x1,y1) boxes equals ROIAlignRotated on the same
+    boxes as (cx,cy,w,h,0 deg) within its atol 1e-4 — here on four levels, forward and backward."""
+    from jtsm_amd.modeling.poolers import ROIPooler, assign_boxes_to_levels, convert_boxes_to_pooler_format
+    from jtsm_amd.structures import Boxes, RotatedBoxes
+    from oracle import model as OM
+
+    rng = np.random.default_rng(77)
+    M, B, Cc, res = 400, 2, 8, 7
+    r = _fpn_like_rois(rng, M, B, 1024)
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    feats = [rng.standard_normal((B, Cc, 256 >> i, 256 >> i)).astype(np.float32) for i in range(4)]
+
+    def rot(r, angles):
+        return np.concatenate([(r[:, 1:3] + r[:, 3:5]) / 2, r[:, 3:5] - r[:, 1:3], angles[:, None]], 1).astype(np.float32)
+
+    ang = rng.uniform(-180, 180, M).astype(np.float32)
+    ang[:4] = [0, 90, 180, 270]
+    rb = rot(r, ang)
+    rboxes = [RotatedBoxes(torch.from_numpy(rb[r[:, 0] == b]).to(cuda)) for b in range(B)]
+    order = np.concatenate([np.nonzero(r[:, 0] == b)[0] for b in range(B)])
+    r, rb = r[order], rb[order]                                    # rows in the pooler's (image-major) order
+    lv = assign_boxes_to_levels(rboxes, 2, 5, 224, 4).cpu()
+    assert torch.equal(lv, OM.assign_levels(torch.from_numpy(r[:, 1:])))     # same w x h -> same level
+    assert set(lv.tolist()) == {0, 1, 2, 3}
+    fmt = convert_boxes_to_pooler_format(rboxes)
+    assert tuple(fmt.shape) == (M, 6) and np.array_equal(fmt.cpu().numpy()[:, 1:], rb)
+
+    pooler = ROIPooler(res, scales, 0, "ROIAlignRotated")
+    xs = [dev(f, cuda, True).requires_grad_() for f in feats]
+    y = pooler(xs, rboxes)
+    g = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+    y.backward(dev(g, cuda, True))
+    rois6 = np.concatenate([r[:, :1], rb], 1).astype(np.float32)
+    y0 = np.zeros((M, Cc, res, res), np.float32)
+    for l, f in enumerate(feats):
+        sel = np.nonzero(lv.numpy() == l)[0]
+        y0[sel] = P.roi_align_rotated_forward(f, rois6[sel], scales[l], res, res, 0)
+        gx0 = P.roi_align_rotated_backward(np.ascontiguousarray(g[sel]), rois6[sel], scales[l], res, res, B, Cc,
+                                           f.shape[2], f.shape[3], 0)
+        gx = xs[l].grad.cpu().numpy()
+        assert np.allclose(gx, gx0, rtol=1e-5, atol=1e-5 * np.abs(gx0).max()), (l, np.abs(gx - gx0).max())
+    assert np.array_equal(y.detach().cpu().numpy(), y0)
+
+    # (2) V2 == rotated at 0 degrees
+    boxes = [Boxes(torch.from_numpy(r[r[:, 0] == b][:, 1:]).to(cuda)) for b in range(B)]
+    zero = [RotatedBoxes(torch.from_numpy(rot(r[r[:, 0] == b], np.zeros(int((r[:, 0] == b).sum()), np.float32))).to(cuda))
+            for b in range(B)]
+    out = []
+    for kind, bl in (("ROIAlignV2", boxes), ("ROIAlignRotated", zero)):
+        xs = [dev(f, cuda, True).requires_grad_() for f in feats]
+        yk = ROIPooler(res, scales, 0, kind)(xs, bl)
+        yk.backward(dev(g, cuda, True))
+        out.append((yk.detach().cpu().numpy(), [x.grad.cpu().numpy() for x in xs]))
+    assert np.allclose(out[0][0], out[1][0], atol=1e-4)
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.allclose(a, b, atol=1e-4 * max(1.0, np.abs(a).max()))
+
+
 def test_multilevel_moi_pool_backward_gather_matches_oracle_and_scatter(cuda):
     """The gather form of the multi-level MOIPool backward (one workgroup per 8x8-cell tile, LDS accumulation in
     roi / bin order; 256-channel maps) against (1) the oracle's per-level scatter, (2) the library's own atomic
