@@ -698,11 +698,16 @@ int jtsm_roi_align_rotated_backward_level_f32(const float* grad, const float* ro
  * roi_level[m] == l.  The tiles of every level are workgroups of one launch.
  * accumulate != 0 (here and in jtsm_moi_pool_backward_levels_f32): the maps already hold a gradient — what autograd
  * would add afterwards, another consumer's term — and this call adds to it in place (nothing is cleared; every cell's
- * read-add-write belongs to one thread, still no atomics in the gather forms, still reproducible). */
+ * read-add-write belongs to one thread, still no atomics in the gather forms, still reproducible).
+ * workspace: jtsm_roi_align_backward_levels_workspace_bytes(H, W, nlevels, B, C, M) bytes of caller-owned device memory,
+ * 16-byte aligned (tile census, launch plan, per-roi reach tables) — no allocation inside the library; NULL makes the
+ * call take stream-ordered scratch of its own. */
+size_t jtsm_roi_align_backward_levels_workspace_bytes(const int* H, const int* W, int nlevels, int B, int C, int M);
 int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                        float* const* grad_inputs, const int* H, const int* W, const float* scales,
                                        int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,
-                                       int aligned, int accumulate, void* stream);
+                                       int aligned, int accumulate, void* workspace, size_t workspace_bytes,
+                                       void* stream);
 int jtsm_moi_pool_forward_level_f32(const float* input, const float* rois, const int32_t* roi_level,
                                     int level, const int32_t* oh_labels, const int32_t* superpixels,
                                     float* output, int32_t* argmax, void* workspace, int B, int C,

@@ -39,7 +39,8 @@ def lib():
                      "jtsm_paint_sem_seg_workspace_bytes", "jtsm_mask_bce_workspace_bytes",
                      "jtsm_moi_pool_backward_levels_workspace_bytes", "jtsm_channel_sum_workspace_bytes",
                      "jtsm_pool_f16_workspace_bytes", "jtsm_moi_pool_f16_workspace_bytes",
-                     "jtsm_conv_bf16x3_wgrad_group_workspace_bytes", "jtsm_image_labels_workspace_bytes"):
+                     "jtsm_conv_bf16x3_wgrad_group_workspace_bytes", "jtsm_image_labels_workspace_bytes",
+                     "jtsm_roi_align_backward_levels_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_size_t
     if TIMING is not None:

@@ -626,8 +626,24 @@ int launch_forward(const T* in, const T* rois, T* out, int B, int C, int H, int 
 
 // Gather form with the census guard over a level table: both forms are launched, the device-side census lets one of
 // them return at once.
+// census (one int per tile) + launch plan + per roi: reach + meta
+static size_t align_gather_head_bytes(int ntile, int C) {
+  return ((size_t)ntile * (1 + C / 64) * sizeof(int) + 4 * sizeof(int) + 15) & ~(size_t)15;
+}
+static size_t align_gather_bytes(int ntile, int C, int M) {
+  return align_gather_head_bytes(ntile, C) + (size_t)M * (sizeof(int4) + sizeof(int));
+}
+// stream-ordered scratch of a call whose entry point has no workspace argument (the reference-shaped ones): released on
+// every path out of the function
+struct AsyncScratch {
+  void* p = nullptr;
+  hipStream_t st = nullptr;
+  ~AsyncScratch() { if (p) (void)hipFreeAsync(p, st); }
+};
+
 static int align_backward_gather(const float* grad, const float* rois, AlignLevels& lv, int B, int C, int M, int PH,
-                                 int PW, int sr, int aligned, const int* roi_level, hipStream_t st, bool accumulate = false) {
+                                 int PW, int sr, int aligned, const int* roi_level, hipStream_t st, bool accumulate = false,
+                                 void* workspace = nullptr, size_t workspace_bytes = 0) {
   int ntile = 0;
   for (int l = 0; l < lv.n; ++l) {
     lv.tiles_x[l] = ceil_div(lv.W[l], kTile);
@@ -636,16 +652,24 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
     ntile += B * lv.tiles_x[l] * lv.tiles_y[l];
   }
   lv.first_tile[lv.n] = ntile;
+  const size_t need = align_gather_bytes(ntile, C, M);
+  AsyncScratch own;
+  own.st = st;
+  if (workspace) {
+    JTSM_REQUIRE(workspace_bytes >= need && ((uintptr_t)workspace & 15) == 0,
+                 "roi_align backward: workspace of %zu bytes (16-byte aligned) needed, got %zu", need, workspace_bytes);
+  } else {
+    JTSM_CHECK_HIP(hipMallocAsync(&own.p, need, st));
+  }
   // every map cleared first: the gather writes only the tiles some roi can reach, the scatter form adds into zeros
   // (accumulate: the maps already hold a gradient — both forms add to it and nothing is cleared)
   for (int l = 0; l < lv.n && !accumulate; ++l)
     JTSM_CHECK_HIP(hipMemsetAsync(lv.gin[l], 0, (size_t)B * lv.H[l] * lv.W[l] * C * sizeof(float), st));
-  int* census = nullptr;
   // census, then the launch plan (maximum, number of jobs, C / 64 (tile, channel block) jobs per reachable tile), then
   // per roi: reach + meta
+  int* census = reinterpret_cast<int*>(workspace ? workspace : own.p);
   const int fan = C / 64;
-  const size_t head = ((size_t)ntile * (1 + fan) * sizeof(int) + 4 * sizeof(int) + 15) & ~(size_t)15;
-  JTSM_CHECK_HIP(hipMallocAsync(reinterpret_cast<void**>(&census), head + (size_t)M * (sizeof(int4) + sizeof(int)), st));
+  const size_t head = align_gather_head_bytes(ntile, C);
   JTSM_CHECK_HIP(hipMemsetAsync(census, 0, (size_t)ntile * sizeof(int), st));
   int* plan = census + ntile;
   int4* reach = reinterpret_cast<int4*>(reinterpret_cast<char*>(census) + head);   // cell reach (16-byte aligned)
@@ -668,8 +692,7 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
                          plan, census_limit());
   }
   JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
-  JTSM_CHECK_HIP(hipFreeAsync(census, st));
-  return JTSM_OK;
+  return JTSM_OK;      // (own scratch: released by AsyncScratch, also on the error returns above)
 }
 
 template <typename T, bool ROT>
@@ -1098,10 +1121,18 @@ int jtsm_roi_align_rotated_backward_level_f32(const float* grad, const float* ro
                                       sampling_ratio, 1, JTSM_NHWC, stream, roi_level, level, accumulate != 0);
 }
 
+size_t jtsm_roi_align_backward_levels_workspace_bytes(const int* H, const int* W, int nlevels, int B, int C, int M) {
+  if (!H || !W || nlevels <= 0 || B <= 0 || C <= 0 || M < 0) return 0;
+  long ntile = 0;
+  for (int l = 0; l < nlevels; ++l) ntile += (long)B * ceil_div(W[l], kTile) * ceil_div(H[l], kTile);
+  return align_gather_bytes((int)ntile, C, M);
+}
+
 int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, const int32_t* roi_level,
                                        float* const* grad_inputs, const int* H, const int* W, const float* scales,
                                        int nlevels, int B, int C, int M, int pooled_h, int pooled_w, int sampling_ratio,
-                                       int aligned, int accumulate, void* stream) {
+                                       int aligned, int accumulate, void* workspace, size_t workspace_bytes,
+                                       void* stream) {
   JTSM_REQUIRE(nlevels > 0 && nlevels <= kAlignLevels && grad_inputs && H && W && scales,
                "roi_align levels: bad level table");
   JTSM_REQUIRE(B >= 0 && C >= 0 && M >= 0 && pooled_h > 0 && pooled_w > 0, "roi_align levels: negative size");
@@ -1120,7 +1151,7 @@ int jtsm_roi_align_backward_levels_f32(const float* grad, const float* rois, con
     }
     if (lv.n == 0) return JTSM_OK;
     return align_backward_gather(grad, rois, lv, B, C, M, pooled_h, pooled_w, sampling_ratio, aligned, roi_level, st,
-                                 accumulate != 0);
+                                 accumulate != 0, workspace, workspace_bytes);
   }
   for (int l = 0; l < nlevels; ++l) {
     if (!grad_inputs[l]) continue;

@@ -170,6 +170,7 @@ class GradientExchange(object):
         self._in_backward = False
         self._next = 0                     # the next bucket (index) whose collective may be issued
         self._seen = []                    # parameters in the order their gradients became ready (first backward)
+        self._counted = set()              # parameters whose gradient this backward has counted already
         self._rebucket = bool(rebucket) and os.environ.get("JTSM_DP_REBUCKET", "1") != "0"
         self.rebucketed = False
         self.issue_log = None              # tests: set to [] to record the bucket index of every collective issued
@@ -247,8 +248,16 @@ class GradientExchange(object):
 
     # ---- per-parameter hook: runs right after autograd has stored p.grad
     def _hook(self, p):
-        if p.grad is None:           # (autograd runs the hook also when a node handed it no gradient — a weight whose
-            return                   # gradient is queued for the grouped launch, layers/conv.py: it comes again)
+        from ..layers import conv
+        # autograd runs the hook also when a node handed it no gradient — a weight whose gradient is queued for the
+        # grouped launch (layers/conv.py) comes again from _deliver_grad.  `.grad is None` alone does not tell: with
+        # zero_grad(set_to_none=False), or in a second backward before the optimizer step, `.grad` still holds the
+        # previous gradient
+        if p.grad is None or conv.deferred_pending(p):
+            return
+        if p in self._counted:       # once per backward: a second call must not count the bucket down again
+            return
+        self._counted.add(p)
         b, view = self._slot[p]
         g = p.grad
         if g.data_ptr() != view.data_ptr():
@@ -308,6 +317,7 @@ class GradientExchange(object):
         for b in self.buckets:
             b.pending = len(b.params)
         self._next = 0
+        self._counted = set()
         if self.comm_stream is not None:
             torch.cuda.current_stream(self.device).wait_stream(self.comm_stream)
         for p in self._slot:

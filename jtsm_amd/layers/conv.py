@@ -979,7 +979,27 @@ def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_sc
 DEFER_WGRAD = os.environ.get("JTSM_DEFER_WGRAD", "1") != "0"
 GROUP_MAX = 8
 _DEFERRED = []
-_DEFER_ARMED = [False]
+_DEFERRED_PENDING = {}     # id(weight) -> queued launches not delivered yet (engine/dp.py ignores autograd's hook for them)
+STALE_DROPPED = [0]        # (tests) queued launches of an aborted backward dropped at the next forward
+
+
+def deferred_pending(w):
+    """True while a weight gradient of `w` sits in the queue: autograd still runs the parameter's post-accumulate hooks
+    when the node handed it nothing (torch 2.10), and whatever `.grad` holds then is NOT this backward's gradient."""
+    return _DEFERRED_PENDING.get(id(w), 0) > 0
+
+
+def _drop_stale_deferred():
+    """Start of a forward (planes_clear): a backward that aborted (an exception, out of memory) never ran its engine
+    callbacks — its queue would pin that step's operand planes and be added into the NEXT step's gradients."""
+    global _DEFERRED
+    if _DEFERRED:
+        STALE_DROPPED[0] += len(_DEFERRED)
+        _DEFERRED = []
+    _DEFERRED_PENDING.clear()
+
+
+CLEAR_HOOKS.append(_drop_stale_deferred)
 
 
 def defer_weight_gradients(on):
@@ -993,13 +1013,16 @@ def planes_backward_weight_deferred(g, x, w, stride=1, pad=0, dil=1, row_scale=N
     off, not a leaf parameter, no backward in progress), compute it now and return it."""
     if not (DEFER_WGRAD and MATH != "f32" and w.is_leaf and w.requires_grad and w._base is None):
         return planes_backward_weight(g, x, w, stride, pad, dil, row_scale=row_scale)
-    if not _DEFER_ARMED[0]:
+    if not _DEFERRED:
+        # the queue is empty: (re-)arm the end-of-backward flush for THIS backward pass.  Keyed to the queue, not to a
+        # sticky flag — a flag left set by an aborted backward would never queue a callback again; a second callback in
+        # one backward (after a stage's own flush emptied the queue) finds nothing to do
         try:
             torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_weight_gradients)
         except RuntimeError:     # not inside a backward pass: nothing would flush the queue
             return planes_backward_weight(g, x, w, stride, pad, dil, row_scale=row_scale)
-        _DEFER_ARMED[0] = True
     _DEFERRED.append((g, x, w, stride, pad, dil, row_scale))
+    _DEFERRED_PENDING[id(w)] = _DEFERRED_PENDING.get(id(w), 0) + 1
     return None
 
 
@@ -1011,6 +1034,11 @@ def _deliver_grad(w, dw):
         w.grad = dw
     else:
         w.grad.add_(dw)
+    left = _DEFERRED_PENDING.get(id(w), 1) - 1
+    if left > 0:                 # a weight queued more than once in this backward: the hooks run behind the last term
+        _DEFERRED_PENDING[id(w)] = left
+        return
+    _DEFERRED_PENDING.pop(id(w), None)
     hooks = getattr(w, "_post_accumulate_grad_hooks", None)
     if hooks:
         for hook in list(hooks.values()):
@@ -1020,7 +1048,6 @@ def _deliver_grad(w, dw):
 @torch.no_grad()
 def flush_deferred_weight_gradients():
     global _DEFERRED
-    _DEFER_ARMED[0] = False
     if not _DEFERRED:
         return
     items, _DEFERRED = _DEFERRED, []
@@ -1260,18 +1287,15 @@ def _wgrad_bias_call(pl, gh, gl, xh, xl, out, bias_out, row_scale, fresh, device
             C.c_size_t(nbytes), L.stream()), pl.desc, 0, out.numel()), "conv2d_backward_weight_bias_bf16x3")
 
 
-_FAN_CLAIMS = []   # the fan record of the next _ConvFused input (claimed by conv2d_fused on the caller's tensor object)
-
-
 class _ConvFused(Function):
     """y = relu?(conv(x, w) * scale + bias + residual); scale/bias are constants of the op
     (FrozenBN statistics or a conv bias treated by the caller), residual gets dy * relu'."""
 
     @staticmethod
     def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True,
-                emit_dx_planes=False):
+                emit_dx_planes=False, fan=None):
         y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
-        ctx.fan = _FAN_CLAIMS.pop() if _FAN_CLAIMS else None   # (conv2d_fused claimed the input's fan view, if it is one)
+        ctx.fan = fan   # (layers/grad_fan.py: conv2d_fused claimed the input's fan view, if it is one)
         ctx.emit_dx_planes = emit_dx_planes   # the input's gradient is the dy of another contraction (FPN laterals)
         ctx.cfg = (stride, pad, dil, relu, bias_needs_grad, tuple(x.shape), tuple(w.shape))
         ctx.has_res = residual is not None
@@ -1321,7 +1345,7 @@ class _ConvFused(Function):
             dw = dw.as_strided(w.shape, w.stride())
         if ctx.has_res and ctx.needs_input_grad[4]:
             dres = g
-        return dx, dw, None, db, dres, None, None, None, None, None, None, None
+        return dx, dw, None, db, dres, None, None, None, None, None, None, None, None
 
 
 ZERO_PADDED = "_jtsm_zero_padded_channels"   # set on a gradient buffer whose trailing (padding) channels are zero
@@ -1358,8 +1382,7 @@ def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, di
     """Autograd-aware fused convolution.  An output-channel count that is not a multiple of 4 (54 sem-seg
     classes, the 1870-wide fused predictor) is zero-padded up for the kernels' 16-byte rows and the
     padding is sliced off the result (its gradient is zero by construction)."""
-    del _FAN_CLAIMS[:]
-    _FAN_CLAIMS.append(grad_fan.claim(x))
+    fan = grad_fan.claim(x)
     o = w.shape[0]
     if o % 4:
         extra = 4 - o % 4
@@ -1370,10 +1393,10 @@ def conv2d_fused(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, di
             bias = torch.cat([bias, bias.new_zeros(extra)])
         if residual is not None:
             residual = torch.nn.functional.pad(residual, (0, 0, 0, 0, 0, extra))
-        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, False, False)
+        y = _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, False, False, fan)
         return _LeadingChannels.apply(y, o)
     return _ConvFused.apply(x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes,
-                            emit_dx_planes)
+                            emit_dx_planes, fan)
 
 
 def linear_fused(x, w, bias=None, relu=False, bias_needs_grad=True):

@@ -171,8 +171,8 @@ def max_pool_3x3_s2(x):
 
 class _Upsample2Add(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, top, lateral):
-        ctx.fan = _UP_CLAIMS.pop() if _UP_CLAIMS else None
+    def forward(ctx, top, lateral, fan=None):
+        ctx.fan = fan   # (layers/grad_fan.py: upsample2_add claimed `top`'s fan view, if it is one)
         top, lateral = _cl4(top), _cl4(lateral)
         n, c, h, w = lateral.shape
         if top.shape != (n, c, h // 2, w // 2) or h % 2 or w % 2:
@@ -202,7 +202,7 @@ class _Upsample2Add(torch.autograd.Function):
             from . import grad_fan
             if grad_fan.target(ctx.fan, gt.shape, gt.device) is None and grad_fan.offer(ctx.fan, gt):
                 gt = None
-        return gt, (g if ctx.needs_input_grad[1] else None)
+        return gt, (g if ctx.needs_input_grad[1] else None), None
 
 
 class _SumTensors(torch.autograd.Function):
@@ -244,15 +244,10 @@ def sum_tensors(xs):
     return _SumTensors.apply(*xs)
 
 
-_UP_CLAIMS = []    # the fan record (layers/grad_fan.py) of the next _Upsample2Add `top`
-
-
 def upsample2_add(top, lateral):
     """lateral + F.interpolate(top, scale_factor=2, mode="nearest")."""
     from . import grad_fan
-    del _UP_CLAIMS[:]
-    _UP_CLAIMS.append(grad_fan.claim(top))
-    return _Upsample2Add.apply(top, lateral)
+    return _Upsample2Add.apply(top, lateral, grad_fan.claim(top))
 
 
 class _Subsample2(torch.autograd.Function):

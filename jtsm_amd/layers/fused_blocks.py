@@ -45,7 +45,6 @@ def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=No
 # consumer's term into it in place (it adds into a fresh tensor instead, which then fails the identity check below
 # and is gated the ordinary way).
 _PREGATED = [None]
-_FAN_CLAIMS = []    # the fan record (layers/grad_fan.py) of the next _BottleneckFn input
 
 
 def _drop_pregated():
@@ -82,9 +81,9 @@ class _BottleneckFn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, ws, ss, bs, stride1, stride2, pad2, dil2, stride_s,
-                pregate=False):
+                pregate=False, fan=None):
         ctx.cfg = (stride1, stride2, pad2, dil2, stride_s)
-        ctx.fan = _FAN_CLAIMS.pop() if _FAN_CLAIMS else None   # (bottleneck_fused claimed x's fan view, if it is one)
+        ctx.fan = fan   # (layers/grad_fan.py: bottleneck_fused claimed x's fan view, if it is one)
         # x is the ReLU output of the previous block's node (bottleneck_fused tags it): its gate goes into this
         # block's conv1 data-gradient epilogue
         ctx.pregate = bool(pregate) and ws is None
@@ -147,7 +146,7 @@ class _BottleneckFn(Function):
                 dx = dx.add_(_dgrad(g3, ws, ss, xs, stride_s, 0, 1))
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
                 None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None,
-                None)
+                None, None)
 
     @staticmethod
     def _backward_planes(ctx, dy):
@@ -197,7 +196,7 @@ class _BottleneckFn(Function):
             K.flush_deferred_weight_gradients()
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
                 None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None,
-                None)
+                None, None)
 
 
 def _plane_block_ok(x, w1, w2, w3, ws):
@@ -214,10 +213,9 @@ def _plane_block_ok(x, w1, w2, w3, ws):
 def bottleneck_fused(x, w1, sb1, w2, sb2, w3, sb3, ws, sbs, stride1, stride2, pad2, dil2, stride_s):
     ss, bs = sbs if sbs is not None else (None, None)
     pregate = PREGATE and ws is None and getattr(x, "_jtsm_block_relu_out", False)
-    del _FAN_CLAIMS[:]
-    _FAN_CLAIMS.append(grad_fan.claim(x) if ws is not None else None)
+    fan = grad_fan.claim(x) if ws is not None else None
     y = _BottleneckFn.apply(x, w1, sb1[0], sb1[1], w2, sb2[0], sb2[1], w3, sb3[0], sb3[1], ws, ss, bs,
-                            stride1, stride2, pad2, dil2, stride_s, pregate)
+                            stride1, stride2, pad2, dil2, stride_s, pregate, fan)
     y._jtsm_block_relu_out = True    # (a tag on this Python object: any op in between yields an untagged tensor)
     return y
 
@@ -237,8 +235,8 @@ class _MaskTowerFn(Function):
     apply(x, want_features, w_1, b_1, ..., w_k, b_k, w_deconv, b_deconv, w_pred, b_pred) -> (logits, features | None)."""
 
     @staticmethod
-    def forward(ctx, x, want_features, *params):
-        ctx.fan = _FAN_CLAIMS.pop() if _FAN_CLAIMS else None   # (mask_tower_fused claimed x's fan view, if it is one)
+    def forward(ctx, x, want_features, fan, *params):
+        ctx.fan = fan   # (layers/grad_fan.py: mask_tower_fused claimed x's fan view, if it is one)
         k = (len(params) - 4) // 2
         hs = [K.PlaneTensor.of(x)]
         for j in range(k):
@@ -263,10 +261,10 @@ class _MaskTowerFn(Function):
         k, hs, up = ctx.k, ctx.hs, ctx.up
         saved = ctx.saved_tensors
         ws, wd, wp = saved[:k], saved[k], saved[k + 1]
-        need = ctx.needs_input_grad[2:]                 # per parameter
+        need = ctx.needs_input_grad[3:]                 # per parameter
         grads = [None] * (2 * k + 4)
         if dlogits is None and du is None:
-            return (None, None) + tuple(grads)
+            return (None, None, None) + tuple(grads)
         sums, deconv_summed = K.ColsumBatch(), False
         # ---- predictor; its data gradient lands gated by the upsampler's ReLU, as planes
         if dlogits is not None:
@@ -342,7 +340,7 @@ class _MaskTowerFn(Function):
                 part = group[i0:i0 + 8]
                 for (slot, _), db in zip(part, K.planes_channel_sum_multi([gp for _, gp in part])):
                     grads[slot] = db
-        return (dx, None) + tuple(grads)
+        return (dx, None, None) + tuple(grads)
 
 
 def mask_tower_ok(x, convs, deconv, predictor):
@@ -366,10 +364,8 @@ def mask_tower_fused(x, convs, deconv, predictor, want_features=True):
     params = []
     for c in convs:
         params += [c.weight, c.bias]
-    del _FAN_CLAIMS[:]
-    _FAN_CLAIMS.append(grad_fan.claim(x))
-    return _MaskTowerFn.apply(x, bool(want_features), *params, deconv.weight, deconv.bias, predictor.weight,
-                              predictor.bias)
+    return _MaskTowerFn.apply(x, bool(want_features), grad_fan.claim(x), *params, deconv.weight, deconv.bias,
+                              predictor.weight, predictor.bias)
 
 
 class _FcStackFn(Function):

@@ -61,16 +61,12 @@ def _feat(x):
     return x.contiguous(memory_format=CL)
 
 
-# the fan records (layers/grad_fan.py) of the feature levels of the next _AlignLevels / _MOILevels call: claimed by
-# ROIPooler.forward on the tensors the caller handed in, picked up by the node's forward (same thread, next statement)
-_CLAIMS = []
-
-
 class _AlignLevels(Function):
     @staticmethod
-    def forward(ctx, rois, roi_level, res, sampling_ratio, aligned, scales, *feats):
-        """aligned: False / True = ROIAlign / ROIAlignV2 on (M,5) rois; "rotated" = ROIAlignRotated on (M,6) rois."""
-        ctx.fans = _CLAIMS.pop() if _CLAIMS else [None] * len(feats)
+    def forward(ctx, rois, roi_level, res, sampling_ratio, aligned, scales, fans, *feats):
+        """aligned: False / True = ROIAlign / ROIAlignV2 on (M,5) rois; "rotated" = ROIAlignRotated on (M,6) rois.
+        fans: the feature levels' fan records (layers/grad_fan.py), claimed by ROIPooler.forward on the caller's tensors."""
+        ctx.fans = list(fans) if fans is not None else [None] * len(feats)
         rotated = aligned == "rotated"
         if rois.shape[1] != (6 if rotated else 5):
             raise RuntimeError("pooler rois must be (M, %d), got %s" % (6 if rotated else 5, tuple(rois.shape)))
@@ -102,7 +98,7 @@ class _AlignLevels(Function):
         g = g.contiguous(memory_format=CL)
         nl = len(shapes)
         B, Cc = shapes[0][0], shapes[0][1]
-        wanted = [bool(ctx.needs_input_grad[6 + lvl]) for lvl in range(nl)]
+        wanted = [bool(ctx.needs_input_grad[7 + lvl]) for lvl in range(nl)]
         # maps another consumer of the same feature levels already wrote this backward pass (layers/grad_fan.py): add
         # into them — all levels or none, the call has one switch
         sinks = [grad_fan.target(ctx.fans[lvl], shapes[lvl], g.device) if wanted[lvl] else None for lvl in range(nl)]
@@ -121,30 +117,34 @@ class _AlignLevels(Function):
                     shapes[lvl][3], rois.shape[0], L.f32(scales[lvl]), res, res, sampling_ratio, int(accumulate),
                     L.stream()), "roi_align_rotated_backward_level")
             if accumulate:
-                return (None,) * (6 + nl)
+                return (None,) * (7 + nl)
             grads = [None if grad_fan.offer(ctx.fans[lvl], grads[lvl]) else grads[lvl] for lvl in range(nl)]
-            return (None, None, None, None, None, None, *grads)
+            return (None, None, None, None, None, None, None, *grads)
         Hs = (C.c_int * nl)(*[sh[2] for sh in shapes])
         Ws = (C.c_int * nl)(*[sh[3] for sh in shapes])
         sc = (C.c_float * nl)(*[float(x) for x in scales])
         ptrs = (C.c_void_p * nl)(*[(t.data_ptr() if t is not None else None) for t in grads])
         # read g, write every map
         L.note_bytes(4.0 * (g.numel() + sum(t.numel() for t in grads if t is not None) + rois.numel()))
-        L.check(L.lib().jtsm_roi_align_backward_levels_f32(
+        lib = L.lib()
+        ws = torch.empty(max(lib.jtsm_roi_align_backward_levels_workspace_bytes(Hs, Ws, nl, B, Cc, rois.shape[0]), 16),
+                         dtype=torch.uint8, device=g.device)
+        L.check(lib.jtsm_roi_align_backward_levels_f32(
             L.ptr(g), L.ptr(rois), L.ptr(roi_level), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
-            sampling_ratio, int(aligned), int(accumulate), L.stream()), "roi_align_backward_levels")
+            sampling_ratio, int(aligned), int(accumulate), L.ptr(ws), C.c_size_t(ws.numel()), L.stream()),
+            "roi_align_backward_levels")
         if accumulate:
-            return (None,) * (6 + nl)
+            return (None,) * (7 + nl)
         grads = [None if grad_fan.offer(ctx.fans[lvl], grads[lvl]) else grads[lvl] for lvl in range(nl)]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 class _MOILevels(Function):
     """MOIPool over all FPN levels in one launch each way (csrc/moi_pool.hip: moi_pool_fwd_levels / _bwd_levels)."""
 
     @staticmethod
-    def forward(ctx, rois, roi_level, res, scales, oh_labels, superpixels, *feats):
-        ctx.fans = _CLAIMS.pop() if _CLAIMS else [None] * len(feats)
+    def forward(ctx, rois, roi_level, res, scales, oh_labels, superpixels, fans, *feats):
+        ctx.fans = list(fans) if fans is not None else [None] * len(feats)
         feats = [_feat(f) for f in feats]
         M, Cc = rois.shape[0], feats[0].shape[1]
         Lw = oh_labels.shape[1]
@@ -177,13 +177,13 @@ class _MOILevels(Function):
     @once_differentiable
     def backward(ctx, g, _ga=None):
         if g is None:
-            return (None,) * (6 + len(ctx.cfg[1]))
+            return (None,) * (7 + len(ctx.cfg[1]))
         rois, roi_level, arg = ctx.saved_tensors
         res, shapes, scales = ctx.cfg
         g = g.contiguous(memory_format=CL)
         nl = len(shapes)
         B, Cc = shapes[0][0], shapes[0][1]
-        wanted = [bool(ctx.needs_input_grad[6 + lvl]) for lvl in range(nl)]
+        wanted = [bool(ctx.needs_input_grad[7 + lvl]) for lvl in range(nl)]
         sinks = [grad_fan.target(ctx.fans[lvl], shapes[lvl], g.device) for lvl in range(nl)]
         accumulate = all(wanted) and all(s is not None for s in sinks)     # (see _AlignLevels.backward)
         grads = sinks if accumulate else [torch.empty(shape, dtype=torch.float32, device=g.device, memory_format=CL)
@@ -200,10 +200,10 @@ class _MOILevels(Function):
             L.ptr(g), L.ptr(rois), L.ptr(roi_level), L.ptr(arg), ptrs, Hs, Ws, sc, nl, B, Cc, rois.shape[0], res, res,
             int(accumulate), L.ptr(ws), C.c_size_t(ws.numel()), L.stream()), "moi_pool_backward_levels")
         if accumulate:
-            return (None,) * (6 + nl)
+            return (None,) * (7 + nl)
         grads = [gi if wanted[lvl] else None for lvl, gi in enumerate(grads)]
         grads = [None if grad_fan.offer(ctx.fans[lvl], grads[lvl]) else grads[lvl] for lvl in range(nl)]
-        return (None, None, None, None, None, None, *grads)
+        return (None, None, None, None, None, None, None, *grads)
 
 
 def moi_label_inputs(oh_labels_list, superpixels):
@@ -295,9 +295,8 @@ class ROIPooler(nn.Module):
                                                            self.canonical_box_size, self.canonical_level)
             roi_level = level_assignments.to(torch.int32).contiguous()
         rois = pooler_fmt_boxes.to(torch.float32).contiguous()
-        del _CLAIMS[:]
-        _CLAIMS.append([grad_fan.claim(f) for f in x])
+        fans = [grad_fan.claim(f) for f in x]
         if moi:
-            return _MOILevels.apply(rois, roi_level, self.output_size[0], self.scales, labels, sp, *x)
+            return _MOILevels.apply(rois, roi_level, self.output_size[0], self.scales, labels, sp, fans, *x)
         mode = "rotated" if self.pooler_type == "ROIAlignRotated" else self.pooler_type == "ROIAlignV2"
-        return _AlignLevels.apply(rois, roi_level, self.output_size[0], self.sampling_ratio, mode, self.scales, *x)
+        return _AlignLevels.apply(rois, roi_level, self.output_size[0], self.sampling_ratio, mode, self.scales, fans, *x)

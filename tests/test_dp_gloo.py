@@ -204,3 +204,136 @@ def test_weight_used_twice_in_one_backward_gets_the_sum():
     import gc
     gc.collect()
     assert conv.grad_slot(w_alias) is None and key not in conv.GRAD_SLOTS
+
+
+# ---- deferred (grouped) weight gradients under the exchange (both medium items) ---------------------------
+class _Planes(object):
+    """Stand-in for layers/conv.py's PlaneTensor on the CPU: a 4-d shape and the tensor."""
+
+    def __init__(self, t):
+        self.t, self.shape = t, (t.shape[0], t.shape[1], 1, 1)
+
+
+class _QueuedWgrad(torch.autograd.Function):
+    """y = x @ w.T whose weight gradient goes through layers/conv.py's deferral queue exactly as the fused bottleneck
+    node's does: the node hands autograd None, the flush delivers the gradient and runs the parameter's hooks."""
+    fail = False
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        return x @ w.flatten(1).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        from jtsm_amd.layers import conv
+        x, w = ctx.saved_tensors
+        dw = conv.planes_backward_weight_deferred(_Planes(dy), _Planes(x), w)
+        if _QueuedWgrad.fail:
+            raise RuntimeError("backward aborted behind a queued weight gradient")
+        return dy @ w.flatten(1), dw
+
+
+class _TwoLayers(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w1 = torch.nn.Parameter(torch.randn(32, 32, 1, 1))
+        self.w2 = torch.nn.Parameter(torch.randn(32, 32, 1, 1))
+
+    def forward(self, x):
+        return (_QueuedWgrad.apply(x, self.w1) @ self.w2.flatten(1).t()).sum()
+
+
+def _deferral_on_cpu(monkeypatch):
+    from jtsm_amd.layers import conv
+
+    def wgrad(g, x, w, stride=1, pad=0, dil=1, row_scale=None):       # what the contraction kernel computes
+        return (g.t.t() @ x.t).view(w.shape)
+    monkeypatch.setattr(conv, "MATH", "bf16x3")
+    monkeypatch.setattr(conv, "DEFER_WGRAD", True)
+    monkeypatch.setattr(conv, "planes_backward_weight", wgrad)
+    return conv
+
+
+def test_deferred_weight_gradient_counts_once_with_grads_kept_and_two_backwards_per_step(monkeypatch):
+    """ADVICE r3 (medium, engine/dp.py): autograd runs a parameter's post-accumulate hook even when the node handed it
+    nothing; with zero_grad(set_to_none=False), or in a second backward before the optimizer step, `.grad` is then still
+    the OLD gradient — the exchange must not count it (the bucket would go out before the queued gradient exists, the
+    counter would go negative).  Every bucket is issued exactly once per backward, behind its real gradient."""
+    from jtsm_amd.engine import dp
+    conv = _deferral_on_cpu(monkeypatch)
+
+    torch.manual_seed(0)
+    model = _TwoLayers()
+    ex = dp.GradientExchange(model, torch.device("cpu"), cap_bytes=64, rebucket=False)
+    try:
+        assert len(ex.buckets) == 2
+        x = torch.randn(5, 32)
+        ref = _TwoLayers()
+        ref.load_state_dict(model.state_dict())
+        (ref.w2.flatten(1) @ ref.w1.flatten(1) @ x.t()).sum().backward()     # plain autograd, no deferral
+        want = {"w1": ref.w1.grad.clone(), "w2": ref.w2.grad.clone()}
+        issued = []
+        launch = ex._launch
+
+        def spy(i):       # the bucket's content at the moment its collective would be issued
+            issued.append((i, ex.buckets[i].flat.clone()))
+            launch(i)
+        ex._launch = spy
+        # (a) gradients kept across steps (set_to_none=False): .grad is non-None when autograd's empty hook call comes
+        for step in range(3):
+            model.zero_grad(set_to_none=False)
+            del issued[:]
+            model(x).backward()
+            assert sorted(i for i, _ in issued) == [0, 1] and [i for i, _ in issued] == sorted(i for i, _ in issued)
+            assert all(b.pending == len(b.params) for b in ex.buckets) and not conv._DEFERRED
+            for name in ("w1", "w2"):
+                p = getattr(model, name)
+                assert torch.allclose(p.grad, want[name], atol=1e-4), (step, name)
+                b, view = ex._slot[p]
+                snap = next(s for i, s in issued if ex.buckets[i] is b)
+                assert torch.allclose(snap[:p.numel()].view(p.shape), want[name], atol=1e-4), \
+                    "bucket of %s issued before its gradient" % name
+        # (b) two backward passes into the same gradients (no zero_grad between): the second adds, each pass issues once
+        model.zero_grad(set_to_none=False)
+        for k in (1, 2):
+            del issued[:]
+            model(x).backward()
+            assert sorted(i for i, _ in issued) == [0, 1]
+            assert all(b.pending == len(b.params) for b in ex.buckets)
+            assert torch.allclose(model.w1.grad, k * want["w1"], atol=1e-4 * k)
+            assert torch.allclose(model.w2.grad, k * want["w2"], atol=1e-4 * k)
+    finally:
+        ex.detach()
+
+
+def test_aborted_backward_does_not_leak_queued_weight_gradients_into_the_next_step(monkeypatch):
+    """ADVICE r3 (medium, layers/conv.py): a backward that raises never runs the engine's final callbacks; the queue
+    must not pin that step's operands, add them into the next step's gradients, or stay 'armed' for ever.  The next
+    forward (planes_clear) drops it; the next backward re-arms its own end-of-backward flush."""
+    conv = _deferral_on_cpu(monkeypatch)
+    torch.manual_seed(1)
+    model = _TwoLayers()
+    x = torch.randn(5, 32)
+    conv.planes_clear()
+    dropped = conv.STALE_DROPPED[0]
+    _QueuedWgrad.fail = True
+    try:
+        try:
+            model(x).backward()
+            raise AssertionError("the backward did not abort")
+        except RuntimeError as e:
+            assert "aborted" in str(e)
+    finally:
+        _QueuedWgrad.fail = False
+    assert len(conv._DEFERRED) == 1 and conv.deferred_pending(model.w1)
+    model.zero_grad(set_to_none=True)
+    conv.planes_clear()                                     # what every forward of the model starts with
+    assert not conv._DEFERRED and not conv.deferred_pending(model.w1) and conv.STALE_DROPPED[0] == dropped + 1
+    x2 = torch.randn(5, 32)
+    model(x2).backward()                                    # no stage flush here: only the re-armed callback delivers
+    ref = _TwoLayers()
+    ref.load_state_dict(model.state_dict())
+    (ref.w2.flatten(1) @ ref.w1.flatten(1) @ x2.t()).sum().backward()
+    assert model.w1.grad is not None and torch.allclose(model.w1.grad, ref.w1.grad, atol=1e-4)
+    assert not conv._DEFERRED
