@@ -325,22 +325,50 @@ def roofline_leg(step_fn):
     return compact, detail
 
 
-def cpu_baseline_leg(size, proposals):
-    """The CPU oracle (oracle/model.py, a torch-CPU port of the reference's arithmetic) on a bounded
-    sample: ONE image of the same workload, forward + backward, all host threads."""
+def _cpu_oracle_rate(size, proposals, threads, warmup, iters):
+    """images/sec of the torch-CPU oracle's training step (forward + backward, no optimizer) on ONE image."""
     from oracle import model as OM
 
-    p = OM.init_params(0, input_gain=1.0 / 64)
-    for n in OM.trainable_names(p):
-        p[n].requires_grad_(True)
-    b = OM.synthetic_batch(1234, B=1, size=size, R=proposals, sp_block=32)
-    t0 = time.perf_counter()
-    losses = OM.forward_losses(p, b)
-    sum(losses.values()).backward()
-    dt = time.perf_counter() - t0
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 training step (fwd+bwd, no optimizer) of the torch-CPU oracle on 1 image %dx%d with %d "
-                      "proposals; pooling ops single-threaded C like the reference (%.1f s)" % (size, size, proposals, dt)}
+    old = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        p = OM.init_params(0, input_gain=1.0 / 64)
+        for n in OM.trainable_names(p):
+            p[n].requires_grad_(True)
+        b = OM.synthetic_batch(1234, B=1, size=size, R=proposals, sp_block=32)
+        times = []
+        for it in range(warmup + iters):
+            for n in OM.trainable_names(p):
+                p[n].grad = None
+            t0 = time.perf_counter()
+            losses = OM.forward_losses(p, b)
+            sum(losses.values()).backward()
+            if it >= warmup:
+                times.append(time.perf_counter() - t0)
+        return len(times) / sum(times), times
+    finally:
+        torch.set_num_threads(old)
+
+
+def cpu_baseline_leg(size, proposals):
+    """The CPU oracle (oracle/model.py, a torch-CPU port of the reference's arithmetic) on a bounded sample of the
+    same workload, as SURVEY §8d asks: warmed up, several timed iterations, at all host threads AND at one.
+    `value` is the all-threads rate on one FULL-SIZE image (1 warm-up + 3 timed steps); the single-thread rate is
+    measured on a quarter-size sample (half the image side, a quarter of the proposals: a full-size step takes ~1
+    minute on one thread) and reported both as measured and scaled by the 4x work ratio."""
+    cores = torch.get_num_threads()
+    rate, times = _cpu_oracle_rate(size, proposals, cores, 1, 3)
+    small = (size // 2, proposals // 4)
+    rate1, times1 = _cpu_oracle_rate(small[0], small[1], 1, 1, 3)
+    return {"value": round(rate, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "torch-CPU oracle training step (fwd+bwd, no optimizer), 1 warm-up + 3 timed: all %d threads on 1 "
+                      "image %dx%d / %d proposals (%s s); pooling ops single-threaded C like the reference"
+                      % (cores, size, size, proposals, "/".join("%.1f" % t for t in times)),
+            "single_thread": {"value": round(rate1 / 4.0, 4), "cores": 1,
+                              "measured": round(rate1, 4),
+                              "sample": "same step, 1 thread, 1 image %dx%d / %d proposals (%s s); value = measured / 4 "
+                                        "(work ratio to the full-size image)"
+                                        % (small[0], small[0], small[1], "/".join("%.1f" % t for t in times1))}}
 
 
 def main():

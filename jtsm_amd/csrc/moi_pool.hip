@@ -269,6 +269,189 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_levels(
                      PH, PW, n, bin, threadIdx.x & 63);
 }
 
+// ---- forward, one wavefront per (roi, bin ROW) (round 4) --------------------------------------------------------------
+// The per-(roi, bin) form above is a chain of dependent round trips per wavefront (roi -> mask words -> ballot -> feature
+// rows, four cells at a time) at 196 000 wavefronts per call: load latency x occupancy bounds it (DESIGN §5 dead ends
+// 21-23), and every cell on a bin border is tested and fetched once per bin that contains it.  Here a wavefront owns the
+// PW bins of one bin row of one roi:
+//   1. hit test, lane = CELL: the rows of the bin row are cut into batches of 64 consecutive cells; a lane ANDs its
+//      cell's whole bit row against the roi's words (uniform loads) with all its 16-byte loads in flight, one ballot
+//      per 64 cells, and the hit cells are written — in (h, w) order, by prefix popcount — to a wave-private LDS list;
+//   2. pooling: the list is walked AHEAD cells at a time; every address is known before the first load, so a round trip
+//      serves AHEAD feature rows (16 B per lane, 1 KiB per row), and each row updates the accumulators of the bins whose
+//      column range holds its w (wave-uniform tests; a cell is fetched once per bin ROW, not once per bin).
+// Order inside a bin stays h outer / w inner with a strict '>', so values and arg-max are the reference's bit for bit
+// (MOIPool_cuda.cu:244-300).  A seventh of the wavefronts, each with ~2 + hits / AHEAD round trips instead of ~2 per
+// four cells of every bin.
+constexpr int kRowsList = 1024;        // LDS list entries per wavefront = 16 batches of 64 cells
+constexpr int kRowsBatches = kRowsList / 64;
+
+template <int VEC, int AHEAD, int PWT>
+__global__ __launch_bounds__(256) void moi_pool_fwd_rows(
+    const MoiLevels lv, const float* __restrict__ rois, const unsigned* __restrict__ roi_bits,
+    float* __restrict__ out, int* __restrict__ argmax, int C, int M, int words, int PH,
+    const int* __restrict__ roi_level, int nlevels, int only_level) {
+#pragma clang fp contract(off)
+  __shared__ unsigned hit_list[4][kRowsList];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // an XCD's workgroups take a CONTIGUOUS run of (roi, bin row) pairs (see moi_pool_fwd_levels)
+  const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const unsigned q8 = nblk >> 3, r8 = nblk & 7;
+  const unsigned blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  // wavefront -> (roi, bin row, channel block of 64 * VEC): the channel blocks of a bin row are neighbours in a workgroup
+  const int ncb = (C + 64 * VEC - 1) / (64 * VEC);
+  const long wave = (long)blk * 4 + wv;
+  if (wave >= (long)M * PH * ncb) return;
+  const int cbi = (int)(wave % ncb);
+  const long np = wave / ncb;
+  const int n = (int)(np / PH), ph = (int)(np - (long)n * PH);
+  int l = 0;
+  if (roi_level) {
+    l = roi_level[n];
+    if (only_level >= 0) {
+      if (l != only_level) return;     // FPN, per-level entry point: this roi lives on another level
+      l = 0;
+    } else if ((unsigned)l >= (unsigned)nlevels) {
+      return;
+    }
+  }
+  const int H = lv.H[l], W = lv.W[l];
+  const IBox r = round_box(rois + (size_t)n * 5, lv.scale[l]);
+  const int rw = max(r.x1 - r.x0 + 1, 1), rh = max(r.y1 - r.y0 + 1, 1);
+  const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PWT;
+  // rows of this bin row inside the rounded (inclusive) box and the map; column ranges of its PWT bins likewise
+  const int hs = max(clampi((int)floorf((float)ph * bh) + r.y0, 0, H), r.y0);
+  const int he = min(clampi((int)ceilf((float)(ph + 1) * bh) + r.y0, 0, H), r.y1 + 1);
+  int wsb[PWT], web[PWT];
+#pragma unroll
+  for (int pw = 0; pw < PWT; ++pw) {
+    wsb[pw] = max(clampi((int)floorf((float)pw * bw) + r.x0, 0, W), r.x0);
+    web[pw] = min(clampi((int)ceilf((float)(pw + 1) * bw) + r.x0, 0, W), r.x1 + 1);
+  }
+  const int cx0 = clampi(r.x0, 0, W), cx1 = clampi(r.x1 + 1, 0, W);
+  const int nbr = (cx1 - cx0 + 63) >> 6;                       // batches of 64 cells per row
+  const int nrows = he > hs ? he - hs : 0;
+  const unsigned* __restrict__ rrow = roi_bits + (size_t)n * words;
+  const float* __restrict__ plane = lv.in[l] + (size_t)r.b * H * W * C;
+  const unsigned* __restrict__ cplane = lv.cell[l] + (size_t)r.b * H * W * words;
+  unsigned* __restrict__ list = hit_list[wv];
+  const int nbins = PH * PWT;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int w4 = words >> 2;
+
+  {
+    const int c = cbi * 64 * VEC + lane * VEC;
+    const bool live = c < C;
+    float best[PWT][VEC];
+    int at[PWT][VEC];
+#pragma unroll
+    for (int pw = 0; pw < PWT; ++pw)
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { best[pw][v] = -FLT_MAX; at[pw][v] = -1; }
+
+    int hrow = hs, kb = 0;                       // next batch: row, 64-cell block of the row
+    const int nbatch = nrows * nbr;
+    for (int b0 = 0; b0 < nbatch; b0 += kRowsBatches) {
+      // ---- 1. hit test of up to kRowsBatches batches
+      const int nb = min(kRowsBatches, nbatch - b0);
+      int count = 0;
+      for (int bb = 0; bb < nb; ++bb) {
+        const int w = cx0 + (kb << 6) + lane;
+        unsigned acc = 0u;
+        if (w < cx1) {
+          const uint4* __restrict__ crow = reinterpret_cast<const uint4*>(cplane + ((size_t)hrow * W + w) * words);
+          const uint4* __restrict__ rr4 = reinterpret_cast<const uint4*>(rrow);
+#pragma unroll 8
+          for (int i = 0; i < w4; ++i) {
+            const uint4 cw = crow[i];
+            const uint4 rq = rr4[i];
+            acc |= (cw.x & rq.x) | (cw.y & rq.y) | (cw.z & rq.z) | (cw.w & rq.w);
+          }
+        }
+        const unsigned long long m = __ballot(acc != 0u);
+        if (acc != 0u) list[count + __popcll(m & below)] = ((unsigned)hrow << 16) | (unsigned)w;
+        count += __popcll(m);
+        if (++kb == nbr) { kb = 0; ++hrow; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- 2. the hit cells, AHEAD feature rows per round trip
+      for (int i0 = 0; i0 < count; i0 += AHEAD) {
+        int cell[AHEAD], cw_[AHEAD];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+          const unsigned e = __builtin_amdgcn_readfirstlane(list[min(i0 + u, count - 1)]);
+          cw_[u] = (int)(e & 0xffffu);
+          cell[u] = i0 + u < count ? (int)(e >> 16) * W + cw_[u] : -1;
+        }
+        float x[AHEAD][VEC];
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+          if (cell[u] < 0 || !live) continue;
+          const float* p = plane + (size_t)cell[u] * C + c;
+          if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(p);
+            x[u][0] = t.x; x[u][1 % VEC] = t.y; x[u][2 % VEC] = t.z; x[u][3 % VEC] = t.w;
+          } else if (VEC == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(p);
+            x[u][0] = t.x; x[u][1 % VEC] = t.y;
+          } else {
+            x[u][0] = p[0];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < AHEAD; ++u) {
+          if (cell[u] < 0 || !live) continue;
+#pragma unroll
+          for (int pw = 0; pw < PWT; ++pw) {
+            if (cw_[u] < wsb[pw] || cw_[u] >= web[pw]) continue;      // wave-uniform
+#pragma unroll
+            for (int v = 0; v < VEC; ++v)
+              if (x[u][v] > best[pw][v]) { best[pw][v] = x[u][v]; at[pw][v] = cell[u]; }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();          // the list is rewritten by the next chunk
+    }
+    if (live) {
+#pragma unroll
+      for (int pw = 0; pw < PWT; ++pw) {
+        const size_t o = ((size_t)n * nbins + ph * PWT + pw) * C + c;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          out[o + v] = at[pw][v] == -1 ? 0.f : best[pw][v];
+          argmax[o + v] = at[pw][v];
+        }
+      }
+    }
+  }
+}
+
+// JTSM_MOI_FWD_ROWS: 0 restores the per-(roi, bin) kernel; 1-4 pick (channels per lane, cells per round trip) for A/B
+static int moi_fwd_rows_mode() {
+  static const int v = [] { const char* e = getenv("JTSM_MOI_FWD_ROWS"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
+template <int VEC, int AHEAD>
+static void launch_fwd_rows_as(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax,
+                               int C, int M, int words, int PH, const int* roi_level, int nlevels, int only_level,
+                               hipStream_t st) {
+  const long waves = (long)M * PH * ceil_div(C, 64 * VEC);
+  hipLaunchKernelGGL((moi_pool_fwd_rows<VEC, AHEAD, 7>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, lv, rois, roi_bits, out,
+                     argmax, C, M, words, PH, roi_level, nlevels, only_level);
+}
+static void launch_fwd_rows(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax, int C,
+                            int M, int words, int PH, const int* roi_level, int nlevels, int only_level, hipStream_t st) {
+  switch (moi_fwd_rows_mode()) {
+    case 2: return launch_fwd_rows_as<4, 4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
+    case 3: return launch_fwd_rows_as<2, 8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
+    case 4: return launch_fwd_rows_as<2, 4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
+    default: return launch_fwd_rows_as<4, 8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
+  }
+}
+
 // grad_input[level(n)][b, argmax, c] += grad[n, bin, c]: a wavefront per (roi, bin).
 __global__ __launch_bounds__(256) void moi_pool_bwd_levels(
     const MoiLevels lv, const float* __restrict__ grad, const float* __restrict__ rois,
@@ -798,7 +981,12 @@ static int moi_forward_impl(const float* input, const float* rois, const int32_t
   const int words = bit_words(L);
   if (layout == JTSM_NHWC) {
     const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
-    if (C % 4 == 0 && ((uintptr_t)input & 15) == 0)
+    if (moi_fwd_rows_mode() != 0 && pooled_w == 7 && words % 4 == 0 && C % 4 == 0 && ((uintptr_t)input & 15) == 0 &&
+        ((uintptr_t)output & 15) == 0 && ((uintptr_t)argmax & 15) == 0 && H < 65536 && W < 65536) {
+      MoiLevels lv = {};
+      lv.in[0] = input; lv.cell[0] = k.cell; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
+      launch_fwd_rows(lv, rois, k.roi, output, argmax, C, M, words, pooled_h, roi_level, 1, roi_level ? level : -1, st);
+    } else if (C % 4 == 0 && ((uintptr_t)input & 15) == 0)
       hipLaunchKernelGGL(moi_pool_fwd_nhwc<4>, dim3(blocks), dim3(256), 0, st, input, rois, k.cell,
                          k.roi, output, argmax, C, H, W, M, words, spatial_scale, pooled_h,
                          pooled_w, roi_level, level);
@@ -932,9 +1120,16 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
   }
   hipLaunchKernelGGL(moi_roi_bits_kernel, dim3(ceil_div((long)M * words, 256)), dim3(256), 0, st, oh_labels, roi_bits,
                      (long)M * words, L, words);
-  const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
-  hipLaunchKernelGGL(moi_pool_fwd_levels<4>, dim3(blocks), dim3(256), 0, st, lv, rois, roi_bits, output, argmax, C, M,
-                     words, pooled_h, pooled_w, roi_level, nlevels);
+  bool rows_ok = moi_fwd_rows_mode() != 0 && pooled_w == 7 && words % 4 == 0 && ((uintptr_t)output & 15) == 0 &&
+                 ((uintptr_t)argmax & 15) == 0;
+  for (int l = 0; l < nlevels; ++l) rows_ok = rows_ok && H[l] < 65536 && W[l] < 65536;
+  if (rows_ok) {
+    launch_fwd_rows(lv, rois, roi_bits, output, argmax, C, M, words, pooled_h, roi_level, nlevels, -1, st);
+  } else {
+    const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
+    hipLaunchKernelGGL(moi_pool_fwd_levels<4>, dim3(blocks), dim3(256), 0, st, lv, rois, roi_bits, output, argmax, C, M,
+                       words, pooled_h, pooled_w, roi_level, nlevels);
+  }
   JTSM_CHECK_LAUNCH("moi_pool forward levels");
   return JTSM_OK;
 }

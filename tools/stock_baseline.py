@@ -24,11 +24,22 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 CL = torch.channels_last
+PAD_ROIS = 0     # --pad-rois: per-roi convolution batches padded with zero rows to a multiple of this (stock run only)
 
 
 def conv2d_stock(x, w, scale=None, bias=None, residual=None, stride=1, pad=0, dil=1, relu=False,
                  bias_needs_grad=False, emit_planes=True, emit_dx_planes=False):
+    n = x.shape[0]
+    padded = PAD_ROIS > 0 and n > 16 and n % PAD_ROIS     # (n > 16: a per-roi tensor, not the image batch)
+    if padded:
+        # MIOpen looks for (and, without a kernel database entry, COMPILES) kernels per exact shape, and the mask
+        # heads' batch is the step's foreground count, which changes from step to step on the clustered recipe — the
+        # 0.79 images/sec of rounds 2 / 3 was that, not a baseline.  Zero rows up to a multiple of PAD_ROIS keep the
+        # set of shapes small; the real rows' results and gradients are unchanged (a convolution is per sample).
+        x = F.pad(x, (0, 0, 0, 0, 0, 0, 0, PAD_ROIS - n % PAD_ROIS))
     y = F.conv2d(x, w, None, stride, pad, dil)
+    if padded:
+        y = y[:n]
     if scale is not None:
         y = y * scale.view(1, -1, 1, 1)
     if bias is not None:
@@ -117,7 +128,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cluster", type=float, default=1.0, help="as bench.py (0 = the uniform recipe of round 1)")
     ap.add_argument("--objects", type=int, default=40)
+    ap.add_argument("--pad-rois", type=int, default=64,
+                    help="pad per-roi convolution batches (the mask heads: one row per foreground roi) with zero rows to "
+                         "a multiple of this, so that MIOpen meets a handful of shapes instead of a new one per step; "
+                         "0 = off (rounds 2 / 3)")
     args = ap.parse_args()
+    global PAD_ROIS
+    PAD_ROIS = args.pad_rois
     patch_to_stock()
     import bench
     from jtsm_amd.utils.synthetic import synthetic_inputs
@@ -157,6 +174,7 @@ def main():
                       "value": round(2 * args.steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / args.steps, 3),
                       "steps": args.steps, "final_loss": round(float(last.detach()), 5), "cluster": args.cluster,
                       "foreground_rois_last_step": int(model.roi_heads.aux["fg_classes"].numel()),
+                      "pad_rois": args.pad_rois, "warmup": args.warmup,
                       "torch": torch.__version__}))
 
 
