@@ -48,16 +48,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v,
 // cell_bits[(b*H+h)*W+w][words]: a wavefront sweeps the image block under a cell (MOIPool_cuda.cu:175-186 bounds),
 // OR-ing id bits into an LDS row, then stores the row.  `cpw` cells share a wavefront (64 / cpw lanes each): at stride 4
 // a cell covers 16 pixels, and one wavefront per cell left 48 lanes idle in 131 000 wavefronts (46 us of the forward).
-__global__ __launch_bounds__(256) void moi_cell_bits_kernel(const int* __restrict__ superpixels,
-                                                            unsigned* __restrict__ cell_bits,
-                                                            int B, int H, int W, int Hs, int Ws,
-                                                            int L, int words, int cpw) {
+__device__ __forceinline__ void moi_cell_bits_block(const int* __restrict__ superpixels, unsigned* __restrict__ cell_bits,
+                                                    int B, int H, int W, int Hs, int Ws, int L, int words, int cpw,
+                                                    long block, unsigned* __restrict__ smem) {
 #pragma clang fp contract(off)
-  extern __shared__ __attribute__((aligned(16))) unsigned smem[];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lpc = 64 / cpw, sub = lane / lpc, pl = lane - sub * lpc;      // lanes per cell, this lane's cell and slot
   unsigned* rows = smem + wv * cpw * words;
-  const long cell0 = ((long)blockIdx.x * 4 + wv) * cpw, ncell = (long)B * H * W;
+  const long cell0 = (block * 4 + wv) * cpw, ncell = (long)B * H * W;
   const long cell = cell0 + sub;
   for (int i = lane; i < cpw * words; i += 64) rows[i] = 0u;
   __syncthreads();
@@ -82,6 +80,14 @@ __global__ __launch_bounds__(256) void moi_cell_bits_kernel(const int* __restric
   for (long i = lane; i < live; i += 64) cell_bits[cell0 * words + i] = rows[i];
 }
 
+__global__ __launch_bounds__(256) void moi_cell_bits_kernel(const int* __restrict__ superpixels,
+                                                            unsigned* __restrict__ cell_bits,
+                                                            int B, int H, int W, int Hs, int Ws,
+                                                            int L, int words, int cpw) {
+  extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+  moi_cell_bits_block(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, cpw, (long)blockIdx.x, smem);
+}
+
 // cells that share a wavefront in moi_cell_bits_kernel: 64 / (pixels under a cell, rounded up to a power of two)
 static int moi_cells_per_wave(int H, int W, int Hs, int Ws) {
   const long npix = (long)ceil_div(Hs, H > 0 ? H : 1) * ceil_div(Ws, W > 0 ? W : 1);
@@ -91,10 +97,9 @@ static int moi_cells_per_wave(int H, int W, int Hs, int Ws) {
 }
 
 // roi_bits[n][words]: bit id set iff oh_labels[n,id] == 1 (exactly 1, MOIPool_cuda.cu:198).
-__global__ __launch_bounds__(256) void moi_roi_bits_kernel(const int* __restrict__ oh_labels,
-                                                           unsigned* __restrict__ roi_bits,
-                                                           long total_words, int L, int words) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void moi_roi_bits_block(const int* __restrict__ oh_labels, unsigned* __restrict__ roi_bits,
+                                                   long total_words, int L, int words, long block) {
+  const long idx = block * 256 + threadIdx.x;
   if (idx >= total_words) return;
   const long n = idx / words;
   const int wd = (int)(idx - n * words);
@@ -105,6 +110,86 @@ __global__ __launch_bounds__(256) void moi_roi_bits_kernel(const int* __restrict
   for (int i = 0; i < 32; ++i)
     if (base + i < L && rowp[base + i] == 1) bits |= 1u << i;
   roi_bits[idx] = bits;
+}
+
+__global__ __launch_bounds__(256) void moi_roi_bits_kernel(const int* __restrict__ oh_labels,
+                                                           unsigned* __restrict__ roi_bits,
+                                                           long total_words, int L, int words) {
+  moi_roi_bits_block(oh_labels, roi_bits, total_words, L, words, (long)blockIdx.x);
+}
+
+// Both bit tables of a multi-level call in ONE launch (five launches of 10-15 us each before: four levels' cell bits
+// and the roi bits): the grid is the concatenation of the per-level cell-bit grids and the roi-bit grid.
+struct MoiBitsPlan {
+  unsigned* cell[8];
+  int H[8], W[8], cpw[8];
+  int first[9];            // first block of each level; first[n] = first roi-bits block
+  int n;
+  int sort_block;          // the block that orders the rois (-1: none)
+  int grid;                // the ordering's coarse grid (cells per side over the image)
+  float scale0;            // image -> level-0 cells
+};
+
+// rois in SPATIAL order for the pooling kernel: order[] = the rois sorted by (level, image, coarse centre row, coarse
+// centre column) — a counting sort by one workgroup.  The pooling kernel gives each XCD a contiguous run of that order,
+// so proposals piled on one object (and neighbours on the map) are pooled together and find each other's feature rows
+// in that XCD's L2: fabric-side reads of the bench's call 1.26 GB -> 0.06 GB (rocprofv3 FETCH_SIZE).  Order inside a
+// bucket is whatever the atomics give; nothing but the schedule depends on it.
+constexpr int kSortBuckets = 4096;
+__device__ __forceinline__ void moi_sort_block(const MoiBitsPlan& plan, const float* __restrict__ rois,
+                                               const int* __restrict__ roi_level, int M, int B, int* __restrict__ order,
+                                               unsigned* __restrict__ hist) {
+  const int t = threadIdx.x, G = plan.grid, nb = plan.n * B * G * G;
+  auto key_of = [&](int n) {
+    const float* r = rois + (size_t)n * 5;
+    const int l = min(max(roi_level[n], 0), plan.n - 1), b = min(max((int)r[0], 0), B - 1);
+    const float cx = (r[1] + r[3]) * 0.5f * plan.scale0, cy = (r[2] + r[4]) * 0.5f * plan.scale0;
+    const int gx = min(max((int)(cx * (float)G / (float)plan.W[0]), 0), G - 1);
+    const int gy = min(max((int)(cy * (float)G / (float)plan.H[0]), 0), G - 1);
+    return ((l * B + b) * G + gy) * G + gx;
+  };
+  for (int i = t; i < nb; i += 256) hist[i] = 0u;
+  __syncthreads();
+  for (int n = t; n < M; n += 256) atomicAdd(&hist[key_of(n)], 1u);
+  __syncthreads();
+  // exclusive scan of the buckets: a thread sums its run, the runs are scanned by thread 0's wavefront serially per wave
+  const int per = (nb + 255) / 256;
+  unsigned run = 0;
+  for (int i = t * per; i < min(nb, (t + 1) * per); ++i) run += hist[i];
+  __shared__ unsigned run_sum[256];
+  run_sum[t] = run;
+  __syncthreads();
+  if (t == 0) {
+    unsigned acc = 0;
+    for (int i = 0; i < 256; ++i) { const unsigned v = run_sum[i]; run_sum[i] = acc; acc += v; }
+  }
+  __syncthreads();
+  unsigned base = run_sum[t];
+  for (int i = t * per; i < min(nb, (t + 1) * per); ++i) { const unsigned v = hist[i]; hist[i] = base; base += v; }
+  __syncthreads();
+  for (int n = t; n < M; n += 256) order[atomicAdd(&hist[key_of(n)], 1u)] = n;
+}
+
+__global__ __launch_bounds__(256) void moi_bits_all_kernel(const MoiBitsPlan plan, const int* __restrict__ superpixels,
+                                                           const int* __restrict__ oh_labels, unsigned* __restrict__ roi_bits,
+                                                           int B, int Hs, int Ws, int L, int words, long roi_words,
+                                                           const float* __restrict__ rois, const int* __restrict__ roi_level,
+                                                           int M, int* __restrict__ order) {
+  extern __shared__ __attribute__((aligned(16))) unsigned smem[];
+  const int blk = blockIdx.x;
+  if (blk == plan.sort_block) {
+    __shared__ unsigned sort_hist[kSortBuckets];
+    moi_sort_block(plan, rois, roi_level, M, B, order, sort_hist);
+    return;
+  }
+  if (blk >= plan.first[plan.n]) {
+    moi_roi_bits_block(oh_labels, roi_bits, roi_words, L, words, (long)(blk - plan.first[plan.n]));
+    return;
+  }
+  int l = 0;
+  while (l + 1 < plan.n && blk >= plan.first[l + 1]) ++l;
+  moi_cell_bits_block(superpixels, plan.cell[l], B, plan.H[l], plan.W[l], Hs, Ws, L, words, plan.cpw[l],
+                      (long)(blk - plan.first[l]), smem);
 }
 
 struct BinRange { int hs, he, ws, we; };
@@ -285,27 +370,36 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_levels(
 // four cells of every bin.
 constexpr int kRowsList = 1024;        // LDS list entries per wavefront = 16 batches of 64 cells
 constexpr int kRowsBatches = kRowsList / 64;
+// workgroups (of 4 wavefronts = bin rows) per XCD chunk: 28 = 16 rois x 7 bin rows (JTSM_MOI_CHUNK overrides, for sweeps)
+static unsigned moi_rows_chunk() {
+  static const unsigned v = [] { const char* e = getenv("JTSM_MOI_CHUNK"); return e && atoi(e) > 0 ? (unsigned)atoi(e) : 28u; }();
+  return v;
+}
 
-template <int VEC, int AHEAD, int PWT>
-__global__ __launch_bounds__(256) void moi_pool_fwd_rows(
+template <int VEC, int AHEAD, int PWT, int W4, int NW, bool PIPE>
+__global__ __launch_bounds__(64 * NW) void moi_pool_fwd_rows(
     const MoiLevels lv, const float* __restrict__ rois, const unsigned* __restrict__ roi_bits,
     float* __restrict__ out, int* __restrict__ argmax, int C, int M, int words, int PH,
-    const int* __restrict__ roi_level, int nlevels, int only_level) {
+    const int* __restrict__ roi_level, int nlevels, int only_level, const int* __restrict__ order, unsigned chunk) {
 #pragma clang fp contract(off)
-  __shared__ unsigned hit_list[4][kRowsList];
+  __shared__ unsigned hit_list[NW][kRowsList];
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // an XCD's workgroups take a CONTIGUOUS run of (roi, bin row) pairs (see moi_pool_fwd_levels)
-  const unsigned nblk = gridDim.x, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const unsigned q8 = nblk >> 3, r8 = nblk & 7;
-  const unsigned blk = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+  // Workgroups are dealt round-robin over the 8 XCDs (private L2s).  The rois come in spatial order (moi_sort_block), so
+  // CHUNKS of `chunk` consecutive workgroups (16 rois: neighbours on the map, usually one pile of proposals) go to one
+  // XCD, and the chunks are dealt round-robin: every XCD sees an even mix of levels and roi sizes (whole eighths of the
+  // sorted list — all small rois on one XCD, all large ones on another — measured 393 us against 353 unsorted), while
+  // the rows a pile shares are fetched by one or two L2s instead of eight.  The grid is padded to whole rounds of chunks.
+  const unsigned xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const unsigned blk = ((j / chunk) * 8 + xcd) * chunk + j % chunk;
   // wavefront -> (roi, bin row, channel block of 64 * VEC): the channel blocks of a bin row are neighbours in a workgroup
   const int ncb = (C + 64 * VEC - 1) / (64 * VEC);
-  const long wave = (long)blk * 4 + wv;
+  const long wave = (long)blk * NW + wv;
   if (wave >= (long)M * PH * ncb) return;
   const int cbi = (int)(wave % ncb);
   const long np = wave / ncb;
-  const int n = (int)(np / PH), ph = (int)(np - (long)n * PH);
+  const int slot = (int)(np / PH), ph = (int)(np - (long)slot * PH);
+  const int n = order ? order[slot] : slot;        // (spatial order of the rois: moi_sort_block)
   int l = 0;
   if (roi_level) {
     l = roi_level[n];
@@ -338,11 +432,19 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_rows(
   unsigned* __restrict__ list = hit_list[wv];
   const int nbins = PH * PWT;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const int w4 = words >> 2;
+  // the roi's label words, once, in scalar registers (words == 4 * W4: the host picks the instantiation)
+  uint4 rq[W4];
+#pragma unroll
+  for (int i = 0; i < W4; ++i) {
+    const uint4 t = reinterpret_cast<const uint4*>(rrow)[i];
+    rq[i].x = __builtin_amdgcn_readfirstlane(t.x); rq[i].y = __builtin_amdgcn_readfirstlane(t.y);
+    rq[i].z = __builtin_amdgcn_readfirstlane(t.z); rq[i].w = __builtin_amdgcn_readfirstlane(t.w);
+  }
 
   {
     const int c = cbi * 64 * VEC + lane * VEC;
     const bool live = c < C;
+    const int c_safe = live ? c : 0;     // (loads are unconditional: a lane beyond C reads channel 0 and stores nothing)
     float best[PWT][VEC];
     int at[PWT][VEC];
 #pragma unroll
@@ -357,18 +459,18 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_rows(
       const int nb = min(kRowsBatches, nbatch - b0);
       int count = 0;
       for (int bb = 0; bb < nb; ++bb) {
+        // (no lane-dependent branch in front of the loads: behind one the compiler drains the memory counter before
+        // every load — a lane beyond the row's end reads the row's last cell and drops the result)
         const int w = cx0 + (kb << 6) + lane;
+        const uint4* __restrict__ crow =
+            reinterpret_cast<const uint4*>(cplane + ((size_t)hrow * W + min(w, cx1 - 1)) * words);
+        uint4 cw[W4];
+#pragma unroll
+        for (int i = 0; i < W4; ++i) cw[i] = crow[i];
         unsigned acc = 0u;
-        if (w < cx1) {
-          const uint4* __restrict__ crow = reinterpret_cast<const uint4*>(cplane + ((size_t)hrow * W + w) * words);
-          const uint4* __restrict__ rr4 = reinterpret_cast<const uint4*>(rrow);
-#pragma unroll 8
-          for (int i = 0; i < w4; ++i) {
-            const uint4 cw = crow[i];
-            const uint4 rq = rr4[i];
-            acc |= (cw.x & rq.x) | (cw.y & rq.y) | (cw.z & rq.z) | (cw.w & rq.w);
-          }
-        }
+#pragma unroll
+        for (int i = 0; i < W4; ++i) acc |= (cw[i].x & rq[i].x) | (cw[i].y & rq[i].y) | (cw[i].z & rq[i].z) | (cw[i].w & rq[i].w);
+        acc = w < cx1 ? acc : 0u;
         const unsigned long long m = __ballot(acc != 0u);
         if (acc != 0u) list[count + __popcll(m & below)] = ((unsigned)hrow << 16) | (unsigned)w;
         count += __popcll(m);
@@ -376,20 +478,19 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_rows(
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      // ---- 2. the hit cells, AHEAD feature rows per round trip
-      for (int i0 = 0; i0 < count; i0 += AHEAD) {
-        int cell[AHEAD], cw_[AHEAD];
+      // ---- 2. the hit cells, AHEAD feature rows per round trip; two groups alternate, one's loads in flight while the
+      // other is applied.  (Entries beyond the list's end repeat its last cell: a row applied twice changes nothing under
+      // a strict '>', and the loads stay free of branches.)
+      auto fetch = [&](int i0, int (&cell)[AHEAD], int (&cw_)[AHEAD], float (&x)[AHEAD][VEC]) {
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
           const unsigned e = __builtin_amdgcn_readfirstlane(list[min(i0 + u, count - 1)]);
           cw_[u] = (int)(e & 0xffffu);
-          cell[u] = i0 + u < count ? (int)(e >> 16) * W + cw_[u] : -1;
+          cell[u] = (int)(e >> 16) * W + cw_[u];
         }
-        float x[AHEAD][VEC];
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
-          if (cell[u] < 0 || !live) continue;
-          const float* p = plane + (size_t)cell[u] * C + c;
+          const float* p = plane + (size_t)cell[u] * C + c_safe;
           if (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(p);
             x[u][0] = t.x; x[u][1 % VEC] = t.y; x[u][2 % VEC] = t.z; x[u][3 % VEC] = t.w;
@@ -400,9 +501,10 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_rows(
             x[u][0] = p[0];
           }
         }
+      };
+      auto apply = [&](const int (&cell)[AHEAD], const int (&cw_)[AHEAD], const float (&x)[AHEAD][VEC]) {
 #pragma unroll
         for (int u = 0; u < AHEAD; ++u) {
-          if (cell[u] < 0 || !live) continue;
 #pragma unroll
           for (int pw = 0; pw < PWT; ++pw) {
             if (cw_[u] < wsb[pw] || cw_[u] >= web[pw]) continue;      // wave-uniform
@@ -410,6 +512,24 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_rows(
             for (int v = 0; v < VEC; ++v)
               if (x[u][v] > best[pw][v]) { best[pw][v] = x[u][v]; at[pw][v] = cell[u]; }
           }
+        }
+      };
+      if (PIPE) {
+        int ca[AHEAD], wa[AHEAD], cb_[AHEAD], wb[AHEAD];
+        float xa[AHEAD][VEC], xb[AHEAD][VEC];
+        if (count > 0) fetch(0, ca, wa, xa);
+        for (int i0 = 0; i0 < count; i0 += 2 * AHEAD) {
+          fetch(i0 + AHEAD, cb_, wb, xb);
+          apply(ca, wa, xa);
+          fetch(i0 + 2 * AHEAD, ca, wa, xa);
+          apply(cb_, wb, xb);
+        }
+      } else {
+        for (int i0 = 0; i0 < count; i0 += AHEAD) {
+          int ca[AHEAD], wa[AHEAD];
+          float xa[AHEAD][VEC];
+          fetch(i0, ca, wa, xa);
+          apply(ca, wa, xa);
         }
       }
       __builtin_amdgcn_wave_barrier();          // the list is rewritten by the next chunk
@@ -428,28 +548,50 @@ __global__ __launch_bounds__(256) void moi_pool_fwd_rows(
   }
 }
 
-// JTSM_MOI_FWD_ROWS: 0 restores the per-(roi, bin) kernel; 1-4 pick (channels per lane, cells per round trip) for A/B
+// JTSM_MOI_FWD_ROWS: 0 restores the per-(roi, bin) kernel; 2 = four cells per round trip instead of eight (A/B);
+// JTSM_MOI_SORT=0 switches the spatial ordering of the rois off.
+// Measured on the bench's call (4000 rois, 4 levels, 256 channels; whole forward entry point, hipEvents): per-(roi, bin)
+// 441-450 us; this kernel 370 (8 cells per round trip, 108 registers), 378 (4 cells), 480 (2 channels per lane: a
+// 512-byte wave-load costs the memory pipeline what a 1 KiB one does), 390 with seven-wavefront workgroups (one roi),
+// 352-390 with two groups of rows alternating (software pipelining buys nothing: the kernel runs at the ~40 GB/s per CU
+// the chip delivers to every CU at once) — and 352 with the bit tables in one launch.
 static int moi_fwd_rows_mode() {
   static const int v = [] { const char* e = getenv("JTSM_MOI_FWD_ROWS"); return e ? atoi(e) : 1; }();
   return v;
 }
+static bool moi_sort_on() {
+  static const bool v = [] { const char* e = getenv("JTSM_MOI_SORT"); return !e || atoi(e) != 0; }();
+  return v;
+}
 
-template <int VEC, int AHEAD>
+template <int AHEAD, int W4>
+static void launch_fwd_rows_w(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax,
+                              int C, int M, int words, int PH, const int* roi_level, int nlevels, int only_level,
+                              const int* order, hipStream_t st) {
+  const long waves = (long)M * PH * ceil_div(C, 256);
+  const unsigned chunk = moi_rows_chunk();
+  const long round = 8 * (long)chunk;                           // (workgroups beyond the last wavefront leave at once)
+  hipLaunchKernelGGL((moi_pool_fwd_rows<4, AHEAD, 7, W4, 4, false>), dim3(ceil_div(ceil_div(waves, 4), round) * round), dim3(256), 0, st, lv, rois,
+                     roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, chunk);
+}
+template <int AHEAD>
 static void launch_fwd_rows_as(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax,
                                int C, int M, int words, int PH, const int* roi_level, int nlevels, int only_level,
-                               hipStream_t st) {
-  const long waves = (long)M * PH * ceil_div(C, 64 * VEC);
-  hipLaunchKernelGGL((moi_pool_fwd_rows<VEC, AHEAD, 7>), dim3(ceil_div(waves, 4)), dim3(256), 0, st, lv, rois, roi_bits, out,
-                     argmax, C, M, words, PH, roi_level, nlevels, only_level);
-}
-static void launch_fwd_rows(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax, int C,
-                            int M, int words, int PH, const int* roi_level, int nlevels, int only_level, hipStream_t st) {
-  switch (moi_fwd_rows_mode()) {
-    case 2: return launch_fwd_rows_as<4, 4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
-    case 3: return launch_fwd_rows_as<2, 8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
-    case 4: return launch_fwd_rows_as<2, 4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
-    default: return launch_fwd_rows_as<4, 8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, st);
+                               const int* order, hipStream_t st) {
+  switch (words) {      // (moi_fwd_rows_words_ok: 4, 8, 16 or 32 words = up to 128 / 256 / 512 / 1024 superpixel ids)
+    case 4: return launch_fwd_rows_w<AHEAD, 1>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
+    case 8: return launch_fwd_rows_w<AHEAD, 2>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
+    case 16: return launch_fwd_rows_w<AHEAD, 4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
+    default: return launch_fwd_rows_w<AHEAD, 8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
   }
+}
+static bool moi_fwd_rows_words_ok(int words) { return words == 4 || words == 8 || words == 16 || words == 32; }
+static void launch_fwd_rows(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax, int C,
+                            int M, int words, int PH, const int* roi_level, int nlevels, int only_level, const int* order,
+                            hipStream_t st) {
+  if (moi_fwd_rows_mode() == 2)
+    return launch_fwd_rows_as<4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
+  return launch_fwd_rows_as<8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
 }
 
 // grad_input[level(n)][b, argmax, c] += grad[n, bin, c]: a wavefront per (roi, bin).
@@ -981,11 +1123,11 @@ static int moi_forward_impl(const float* input, const float* rois, const int32_t
   const int words = bit_words(L);
   if (layout == JTSM_NHWC) {
     const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
-    if (moi_fwd_rows_mode() != 0 && pooled_w == 7 && words % 4 == 0 && C % 4 == 0 && ((uintptr_t)input & 15) == 0 &&
+    if (moi_fwd_rows_mode() != 0 && pooled_w == 7 && moi_fwd_rows_words_ok(words) && C % 4 == 0 && ((uintptr_t)input & 15) == 0 &&
         ((uintptr_t)output & 15) == 0 && ((uintptr_t)argmax & 15) == 0 && H < 65536 && W < 65536) {
       MoiLevels lv = {};
       lv.in[0] = input; lv.cell[0] = k.cell; lv.H[0] = H; lv.W[0] = W; lv.scale[0] = spatial_scale;
-      launch_fwd_rows(lv, rois, k.roi, output, argmax, C, M, words, pooled_h, roi_level, 1, roi_level ? level : -1, st);
+      launch_fwd_rows(lv, rois, k.roi, output, argmax, C, M, words, pooled_h, roi_level, 1, roi_level ? level : -1, nullptr, st);
     } else if (C % 4 == 0 && ((uintptr_t)input & 15) == 0)
       hipLaunchKernelGGL(moi_pool_fwd_nhwc<4>, dim3(blocks), dim3(256), 0, st, input, rois, k.cell,
                          k.roi, output, argmax, C, H, W, M, words, spatial_scale, pooled_h,
@@ -1086,6 +1228,7 @@ size_t jtsm_moi_pool_levels_workspace_bytes(int B, const int* H, const int* W, i
   size_t total = 16 + (((size_t)M * bit_words(L) * sizeof(unsigned) + 15) & ~(size_t)15);
   for (int l = 0; l < nlevels; ++l)
     total += (((size_t)B * H[l] * W[l] * bit_words(L) * sizeof(unsigned)) + 15) & ~(size_t)15;
+  total += ((size_t)M * sizeof(int) + 15) & ~(size_t)15;      // the rois' spatial order
   return total;
 }
 
@@ -1107,6 +1250,8 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
   unsigned* roi_bits = reinterpret_cast<unsigned*>(w);
   w += (((size_t)M * words * sizeof(unsigned)) + 15) & ~(size_t)15;
   MoiLevels lv = {};
+  MoiBitsPlan bp = {};
+  int nblk = 0, max_cpw = 1;
   for (int l = 0; l < nlevels; ++l) {
     JTSM_REQUIRE(inputs[l] && H[l] > 0 && W[l] > 0 && ((uintptr_t)inputs[l] & 15) == 0, "moi_pool levels: bad level %d", l);
     lv.in[l] = inputs[l]; lv.H[l] = H[l]; lv.W[l] = W[l]; lv.scale[l] = scales[l];
@@ -1115,16 +1260,33 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
     w += (((size_t)B * H[l] * W[l] * words * sizeof(unsigned)) + 15) & ~(size_t)15;
     const long cells = (long)B * H[l] * W[l];
     const int cpw = moi_cells_per_wave(H[l], W[l], Hs, Ws);
-    hipLaunchKernelGGL(moi_cell_bits_kernel, dim3(ceil_div(cells, 4 * cpw)), dim3(256), 4 * cpw * words * sizeof(unsigned),
-                       st, superpixels, cell, B, H[l], W[l], Hs, Ws, L, words, cpw);
+    bp.cell[l] = cell; bp.H[l] = H[l]; bp.W[l] = W[l]; bp.cpw[l] = cpw; bp.first[l] = nblk;
+    nblk += (int)ceil_div(cells, 4 * cpw);
+    max_cpw = std::max(max_cpw, cpw);
   }
-  hipLaunchKernelGGL(moi_roi_bits_kernel, dim3(ceil_div((long)M * words, 256)), dim3(256), 0, st, oh_labels, roi_bits,
-                     (long)M * words, L, words);
-  bool rows_ok = moi_fwd_rows_mode() != 0 && pooled_w == 7 && words % 4 == 0 && ((uintptr_t)output & 15) == 0 &&
+  bp.n = nlevels;
+  bp.first[nlevels] = nblk;
+  nblk += (int)ceil_div((long)M * words, 256);
+  bool rows_ok = moi_fwd_rows_mode() != 0 && pooled_w == 7 && moi_fwd_rows_words_ok(words) && ((uintptr_t)output & 15) == 0 &&
                  ((uintptr_t)argmax & 15) == 0;
   for (int l = 0; l < nlevels; ++l) rows_ok = rows_ok && H[l] < 65536 && W[l] < 65536;
+  // the rois' spatial order (one more block of the same launch): the coarsest grid whose buckets fit the block's table
+  int* order = nullptr;
+  bp.sort_block = -1;
+  if (rows_ok && moi_sort_on()) {
+    int G = 16;
+    while (G > 1 && (long)nlevels * B * G * G > kSortBuckets) G >>= 1;
+    if ((long)nlevels * B * G * G <= kSortBuckets) {
+      order = reinterpret_cast<int*>(w);
+      bp.sort_block = nblk++;
+      bp.grid = G;
+      bp.scale0 = scales[0];
+    }
+  }
+  hipLaunchKernelGGL(moi_bits_all_kernel, dim3(nblk), dim3(256), 4 * max_cpw * words * sizeof(unsigned), st, bp, superpixels,
+                     oh_labels, roi_bits, B, Hs, Ws, L, words, (long)M * words, rois, roi_level, M, order);
   if (rows_ok) {
-    launch_fwd_rows(lv, rois, roi_bits, output, argmax, C, M, words, pooled_h, roi_level, nlevels, -1, st);
+    launch_fwd_rows(lv, rois, roi_bits, output, argmax, C, M, words, pooled_h, roi_level, nlevels, -1, order, st);
   } else {
     const int blocks = ceil_div((long)M * pooled_h * pooled_w, 4);
     hipLaunchKernelGGL(moi_pool_fwd_levels<4>, dim3(blocks), dim3(256), 0, st, lv, rois, roi_bits, output, argmax, C, M,

@@ -18,6 +18,17 @@ for cluster in (1.0, 0.0):
     boxes = [x["proposals"].proposal_boxes for x in inputs]
     oh = [x["proposals"].oh_labels for x in inputs]
     sp = torch.stack([x["superpixels"] for x in inputs]).to(dev)
+    if os.environ.get("SORT", "0") != "0":     # rois of an image in spatial order: level, then coarse centre (row-major)
+        from jtsm_amd.structures import Boxes
+        g = int(os.environ.get("SORT"))
+        for i in range(len(boxes)):
+            t = boxes[i].tensor
+            lvl = torch.floor(4 + torch.log2(torch.sqrt((t[:, 2] - t[:, 0]) * (t[:, 3] - t[:, 1])) / 224 + 1e-8)).clamp(2, 5)
+            cx, cy = ((t[:, 0] + t[:, 2]) / 2 / g).floor(), ((t[:, 1] + t[:, 3]) / 2 / g).floor()
+            key = (lvl * 64 + cy) * 64 + cx
+            order = torch.argsort(key, stable=True)
+            boxes[i] = Boxes(t[order].contiguous())
+            oh[i] = oh[i][order].contiguous()
     moi = ROIPooler(7, (1 / 4, 1 / 8, 1 / 16, 1 / 32), 0, "MOIPool")
     with torch.no_grad():
         for _ in range(3):
@@ -30,4 +41,4 @@ for cluster in (1.0, 0.0):
         b.record()
         torch.cuda.synchronize()
     chk = (int(out.view(torch.int32).to(torch.int64).sum()), int(arg.to(torch.int64).sum()), int((arg >= 0).sum()))
-    print("mode %s cluster %.0f: %.1f us per forward call, checksum %s" % (mode, cluster, a.elapsed_time(b) * 50, chk), flush=True)
+    print("sort %s mode %s cluster %.0f: %.1f us per forward call, checksum %s" % (os.environ.get("SORT", "0"), mode, cluster, a.elapsed_time(b) * 50, chk), flush=True)
