@@ -72,11 +72,35 @@ __device__ __forceinline__ int compact_wg(bool flag, int* __restrict__ wave_coun
 // number of work entries, plan[2 ...] = `fan` entries (tile * fan + k) for every tile whose census is at least
 // `heavy_min`, heaviest first (four load classes relative to the maximum, index order inside a class — the busy workgroups stride this list, so
 // the few tiles under a pile of proposals start first instead of ending the launch).
+// `order` (optional, `total` entries): ALL tiles by descending load — tiles at or above heavy_min first (another kernel's:
+// their workgroups leave at once), then the lighter ones in 64 load classes, heaviest class first, empty tiles last.  A
+// one-workgroup-per-tile launch that maps blockIdx through it starts its longest tiles first instead of wherever the
+// map's layout put them (the MOIPool backward's light-tile gather was one long tail: 230 us for ~70 us of work per slot).
 static __global__ __launch_bounds__(1024) void tile_plan_kernel(const int* __restrict__ census, int total,
-                                                                int* __restrict__ plan, int heavy_min, int fan) {
+                                                                int* __restrict__ plan, int heavy_min, int fan,
+                                                                int* __restrict__ order = nullptr) {
   __shared__ int wave_count[16];
   __shared__ int part[16];
+  __shared__ int cls_count[66];
   const int t = threadIdx.x;
+  if (order) {     // counting sort by load class (the order inside a class is the atomics'; only the schedule sees it)
+    auto cls_of = [&](int v) {
+      if (v >= heavy_min) return 0;
+      if (v <= 0) return 65;
+      return 64 - (int)min(63L, (long)v * 64 / max(heavy_min, 1));
+    };
+    if (t < 66) cls_count[t] = 0;
+    __syncthreads();
+    for (int i = t; i < total; i += 1024) atomicAdd(&cls_count[cls_of(census[i])], 1);
+    __syncthreads();
+    if (t == 0) {
+      int acc = 0;
+      for (int c = 0; c < 66; ++c) { const int v = cls_count[c]; cls_count[c] = acc; acc += v; }
+    }
+    __syncthreads();
+    for (int i = t; i < total; i += 1024) order[atomicAdd(&cls_count[cls_of(census[i])], 1)] = i;
+    __syncthreads();
+  }
   int m = 0;
   for (int i = t; i < total; i += 1024) m = max(m, census[i]);
   for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
     const MoiLevels lv, const MoiTiles tl, const float* __restrict__ grad, const float* __restrict__ rois,
     const int* __restrict__ argmax, int C, int M, int PH, int PW, int B, const int* __restrict__ lists,
     const int* __restrict__ counts, int nlevels, const int* __restrict__ plan, const int* __restrict__ census,
-    int heavy_min, int accumulate) {
+    int heavy_min, int accumulate, const int* __restrict__ tile_order) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float acc[];   // [64 cells][256 channels]
   __shared__ int roi_list[256];
@@ -718,10 +718,12 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   __shared__ int pair_list[kPairCap];   // (roi * nbins + bin) rows whose bin range touches the tile, in order
   __shared__ int wave_count[4];
   const int t = threadIdx.x;
+  // workgroups start in index order: through the plan's permutation the heaviest tiles start first (tile_plan_kernel)
+  const int tile = tile_order ? tile_order[blockIdx.x] : (int)blockIdx.x;
   int l = 0;
-  while (l + 1 < nlevels && (int)blockIdx.x >= tl.first[l + 1]) ++l;
+  while (l + 1 < nlevels && tile >= tl.first[l + 1]) ++l;
   const int H = lv.H[l], W = lv.W[l];
-  int rel = blockIdx.x - tl.first[l];
+  int rel = tile - tl.first[l];
   const int tx = rel % tl.tiles_x[l]; rel /= tl.tiles_x[l];
   const int ty = rel % tl.tiles_y[l];
   const int b = rel / tl.tiles_y[l];
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(256) void moi_pool_bwd_tiled(
   const float scale = lv.scale[l];
   const int nbins = PH * PW;
   float* __restrict__ out = lv.gin[l] + (size_t)b * H * W * C;
-  const int load = census[blockIdx.x];
+  const int load = census[tile];
   const bool fallback = plan[0] > kCensusLimit;   // too many rois on one tile somewhere: the scatter form adds into zeros
   if (load == 0 || fallback) {
     if (accumulate) return;   // the map holds another consumer's gradient: nothing to add here (the scatter form adds to it)
@@ -1296,6 +1298,28 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
   return JTSM_OK;
 }
 
+// The side stream and the fork / join events of the backward's two gathers, created once per device (JTSM_MOI_BWD_STREAMS=0:
+// one stream, the gathers one after the other).
+static hipStream_t moi_bwd_side_stream() {
+  static const bool on = [] { const char* e = getenv("JTSM_MOI_BWD_STREAMS"); return !e || atoi(e) != 0; }();
+  if (!on) return nullptr;
+  static hipStream_t streams[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!streams[dev] && hipStreamCreateWithFlags(&streams[dev], hipStreamNonBlocking) != hipSuccess) streams[dev] = nullptr;
+  return streams[dev];
+}
+static bool moi_bwd_events(hipEvent_t* fork, hipEvent_t* join) {
+  static hipEvent_t ev[16][2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+  for (int k = 0; k < 2; ++k)
+    if (!ev[dev][k] && hipEventCreateWithFlags(&ev[dev][k], hipEventDisableTiming) != hipSuccess) return false;
+  *fork = ev[dev][0];
+  *join = ev[dev][1];
+  return true;
+}
+
 static long census_tiles(const int* H, const int* W, int nlevels, int B) {
   long n = 0;
   for (int l = 0; l < nlevels; ++l) n += (long)B * ceil_div(W[l], kTile) * ceil_div(H[l], kTileY);
@@ -1305,7 +1329,8 @@ static long census_tiles(const int* H, const int* W, int nlevels, int B) {
 size_t jtsm_moi_pool_backward_levels_workspace_bytes(const int* H, const int* W, int nlevels, int B, int M) {
   if (nlevels <= 0 || nlevels > kMaxLevels || B <= 0 || M <= 0 || !H || !W) return 0;
   // per-(level, image) roi lists + counts, then the tile census and the launch plan (maximum, count, busy tiles)
-  return (((size_t)nlevels * B * ((size_t)M + 1) + 5 * (size_t)census_tiles(H, W, nlevels, B) + 8) * sizeof(int) + 15) &
+  // (... and the light-tile gather's workgroup order: one more int per tile)
+  return (((size_t)nlevels * B * ((size_t)M + 1) + 6 * (size_t)census_tiles(H, W, nlevels, B) + 8) * sizeof(int) + 15) &
          ~(size_t)15;
 }
 
@@ -1352,12 +1377,28 @@ int jtsm_moi_pool_backward_levels_f32(const float* grad, const float* rois, cons
     hipLaunchKernelGGL(moi_tile_census_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, lv, tl, rois, roi_level, M, nlevels,
                        pooled_h, pooled_w, census);
     // the plan: the census maximum and the heavy tiles (4 quadrant entries each), heaviest first
-    hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, st, census, ntile, plan, moi_heavy_min(), 4);
+    int* tile_order = plan + 2 + 4 * (size_t)ntile;   // (behind the busy list's at most 4 entries per tile)
+    hipLaunchKernelGGL(tile_plan_kernel, dim3(1), dim3(1024), 0, st, census, ntile, plan, moi_heavy_min(), 4, tile_order);
+    // The two gathers write disjoint cells and each ends in a tail of a few long workgroups (the light form's
+    // heaviest tiles; the piled quadrants): side by side on two streams the tails overlap.  Fork / join by events on a
+    // side stream the library keeps per device (no host synchronisation; the caller's stream waits for the join).
+    hipStream_t side = moi_bwd_side_stream();
+    hipEvent_t fork = nullptr, join = nullptr;
+    if (side && moi_bwd_events(&fork, &join)) {
+      JTSM_CHECK_HIP(hipEventRecord(fork, st));
+      JTSM_CHECK_HIP(hipStreamWaitEvent(side, fork, 0));
+    } else {
+      side = st;
+    }
+    hipLaunchKernelGGL(moi_pool_bwd_busy, dim3(256), dim3(1024), (size_t)kCopies * kQuad * kQuad * 256 * sizeof(float), side,
+                       lv, tl, grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, accumulate);
     hipLaunchKernelGGL(moi_pool_bwd_tiled, dim3(blocks, C / 256), dim3(256), kTile * kTile * 256 * sizeof(float), st, lv, tl,
                        grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, census, moi_heavy_min(),
-                       accumulate);
-    hipLaunchKernelGGL(moi_pool_bwd_busy, dim3(256), dim3(1024), (size_t)kCopies * kQuad * kQuad * 256 * sizeof(float), st,
-                       lv, tl, grad, rois, argmax, C, M, pooled_h, pooled_w, B, lists, counts, nlevels, plan, accumulate);
+                       accumulate, tile_order);
+    if (side != st) {
+      JTSM_CHECK_HIP(hipEventRecord(join, side));
+      JTSM_CHECK_HIP(hipStreamWaitEvent(st, join, 0));
+    }
     // (returns at once unless the census sent the gather home)
     hipLaunchKernelGGL(moi_pool_bwd_levels, dim3(std::min(ceil_div((long)M * pooled_h * pooled_w, 4), 8192)), dim3(256), 0,
                        st, lv, grad, rois, argmax, C, M, pooled_h * pooled_w, roi_level, nlevels, plan, kCensusLimit);

@@ -1,7 +1,7 @@
 import csv, collections, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 seq=collections.defaultdict(list)
-keys=('moi_pool_fwd','moi_pool_bwd_busy','align_bwd_gather','tile_plan','fillBuffer','moi_pool_bwd_tiled','align_bwd_tiled','moi_cell_bits','moi_roi_bits','moi_tile_census','moi_roi_lists','align_census_kernel','moi_fwd_rows')
+keys=('moi_pool_fwd','moi_pool_bwd_busy','align_bwd_gather','tile_plan','fillBuffer','moi_pool_bwd_tiled','align_bwd_tiled','moi_cell_bits','moi_roi_bits','moi_tile_census','moi_roi_lists','align_census_kernel','moi_fwd_rows','moi_bits_all','moi_pool_bwd_levels','align_bwd_nhwc')
 for r in rows:
     n=r['Kernel_Name']
     for key in keys:
