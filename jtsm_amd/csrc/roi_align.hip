@@ -124,6 +124,20 @@ __global__ __launch_bounds__(256) void align_fwd_nhwc(const T* __restrict__ in,
   }
 }
 
+// The maps of the call: one level (jtsm_roi_align_backward_level_f32 / the plain entry) or all FPN levels at once
+// (jtsm_roi_align_backward_levels_f32) — tiles of every level are workgroups of ONE launch, so the levels' critical
+// paths (the busiest tile of each) overlap instead of adding up.
+constexpr int kAlignLevels = 8;
+struct AlignLevels {
+  float* gin[kAlignLevels];
+  int H[kAlignLevels], W[kAlignLevels];
+  float scale[kAlignLevels];
+  int tiles_x[kAlignLevels], tiles_y[kAlignLevels];
+  int first_tile[kAlignLevels + 1];   // running sum of B * tiles_x * tiles_y
+  int level_id[kAlignLevels];         // the roi_level value this entry serves
+  int n;
+};
+
 // ---------------------------------------------------------------- NHWC backward
 template <typename T, int VEC, bool ROT>
 __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad,
@@ -189,6 +203,71 @@ __global__ __launch_bounds__(256) void align_bwd_nhwc(const T* __restrict__ grad
   }
 }
 
+// The scatter form over a level table in ONE launch (the census fallback of the gather form below: before, one launch
+// per level, four ~5 us launches that return at once in the usual case): every (roi, bin) wavefront adds into the map
+// of its own level.
+template <int VEC>
+__global__ __launch_bounds__(256) void align_bwd_nhwc_levels(const float* __restrict__ grad, const float* __restrict__ rois,
+                                                             const AlignLevels lv, int C, int M, int PH, int PW, int sr,
+                                                             int aligned, const int* __restrict__ roi_level,
+                                                             const int* __restrict__ census_max, int census_limit) {
+#pragma clang fp contract(off)
+  if (census_max && *census_max <= census_limit) return;   // the gather form took this call
+  const int lane = threadIdx.x & 63;
+  const int nbins = PH * PW;
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  if (wave >= (long)M * nbins) return;
+  const int n = (int)(wave / nbins);
+  int l = 0;
+  if (roi_level) {
+    const int id = roi_level[n];
+    for (l = 0; l < lv.n && lv.level_id[l] != id; ++l) {}
+    if (l == lv.n) return;
+  }
+  const int H = lv.H[l], W = lv.W[l];
+  const int bin = (int)(wave - (long)n * nbins);
+  const int ph = bin / PW, pw = bin - ph * PW;
+  const RoiGeom<float> g = roi_geometry<float, false>(rois, n, lv.scale[l], PH, PW, sr, aligned != 0);
+  const int S = (g.gh > 0 && g.gw > 0) ? g.gh * g.gw : 0;
+  const float count = (float)(g.gh * g.gw);
+  float* __restrict__ plane = lv.gin[l] + (size_t)g.b * H * W * C;
+  const float* __restrict__ grow = grad + ((size_t)n * nbins + bin) * C;
+  for (int cb = 0; cb < C; cb += 64 * VEC) {
+    const int c = cb + lane * VEC;
+    const bool live = c < C;
+    float go[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) go[v] = 0.f;
+    if (live) load_vec<float, VEC>(grow + c, go);
+    for (int s0 = 0; s0 < S; s0 += 64) {
+      const int s = s0 + lane;
+      Tap<float> mine;
+      if (s < S) {
+        const int iy = s / g.gw;
+        mine = sample_tap<float, false>(g, H, W, ph, pw, iy, s - iy * g.gw);
+      } else {
+        mine.pos[0] = mine.pos[1] = mine.pos[2] = mine.pos[3] = -1;
+        mine.w[0] = mine.w[1] = mine.w[2] = mine.w[3] = 0.f;
+      }
+      const int cnt = (S - s0) < 64 ? (S - s0) : 64;
+      for (int j = 0; j < cnt; ++j) {
+        const int p0 = __shfl(mine.pos[0], j);
+        if (p0 < 0) continue;
+        int p[4] = {p0, __shfl(mine.pos[1], j), __shfl(mine.pos[2], j), __shfl(mine.pos[3], j)};
+        float w[4] = {__shfl(mine.w[0], j), __shfl(mine.w[1], j), __shfl(mine.w[2], j), __shfl(mine.w[3], j)};
+        if (live) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            float* dst = plane + (size_t)p[q] * C + c;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) atomicAdd(dst + v, go[v] * w[q] / count);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- NHWC backward as a gather
 // A workgroup owns an 8 x 8-cell tile of the gradient map x 64 channels, lists — from the roi geometry alone, in
 // (roi, bin) order — the bins whose bilinear taps can reach the tile, and adds their contributions in LDS.  The bin's
@@ -206,20 +285,6 @@ static int census_limit() {
   return v;
 }
 
-
-// The maps of the call: one level (jtsm_roi_align_backward_level_f32 / the plain entry) or all FPN levels at once
-// (jtsm_roi_align_backward_levels_f32) — tiles of every level are workgroups of ONE launch, so the levels' critical
-// paths (the busiest tile of each) overlap instead of adding up.
-constexpr int kAlignLevels = 8;
-struct AlignLevels {
-  float* gin[kAlignLevels];
-  int H[kAlignLevels], W[kAlignLevels];
-  float scale[kAlignLevels];
-  int tiles_x[kAlignLevels], tiles_y[kAlignLevels];
-  int first_tile[kAlignLevels + 1];   // running sum of B * tiles_x * tiles_y
-  int level_id[kAlignLevels];         // the roi_level value this entry serves
-  int n;
-};
 
 __global__ __launch_bounds__(256) void align_census_kernel(const float* __restrict__ rois, int M, int PH, int PW, int sr,
                                                            int aligned, const int* __restrict__ roi_level,
@@ -681,16 +746,13 @@ static int align_backward_gather(const float* grad, const float* rois, AlignLeve
                      PW, sr, aligned, plan, census_limit(), fan, reach, meta, accumulate ? 1 : 0);
   constexpr int V = WideVec<float>::value;
   const int blocks = ceil_div((long)M * PH * PW, 4);
-  for (int l = 0; l < lv.n; ++l) {   // the scatter form, level by level (each returns at once unless the census says so)
-    if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
-      hipLaunchKernelGGL((align_bwd_nhwc<float, V, false>), dim3(blocks), dim3(256), 0, st, grad, rois, lv.gin[l], C,
-                         lv.H[l], lv.W[l], M, lv.scale[l], PH, PW, sr, aligned, roi_level, lv.level_id[l],
-                         plan, census_limit());
-    else
-      hipLaunchKernelGGL((align_bwd_nhwc<float, 1, false>), dim3(blocks), dim3(256), 0, st, grad, rois, lv.gin[l], C,
-                         lv.H[l], lv.W[l], M, lv.scale[l], PH, PW, sr, aligned, roi_level, lv.level_id[l],
-                         plan, census_limit());
-  }
+  // the scatter form, all levels in one launch (returns at once unless the census says so)
+  if (C % V == 0 && ((uintptr_t)grad % (V * sizeof(float))) == 0)
+    hipLaunchKernelGGL((align_bwd_nhwc_levels<V>), dim3(blocks), dim3(256), 0, st, grad, rois, lv, C, M, PH, PW, sr, aligned,
+                       roi_level, plan, census_limit());
+  else
+    hipLaunchKernelGGL((align_bwd_nhwc_levels<1>), dim3(blocks), dim3(256), 0, st, grad, rois, lv, C, M, PH, PW, sr, aligned,
+                       roi_level, plan, census_limit());
   JTSM_CHECK_LAUNCH("roi_align backward (gather + census)");
   return JTSM_OK;      // (own scratch: released by AsyncScratch, also on the error returns above)
 }

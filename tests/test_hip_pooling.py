@@ -486,6 +486,53 @@ def test_roi_align_backward_gather_reproducible_and_fallback(cuda):
     assert float(np.abs(gx[1]).max()) == 0.0            # nothing lands in the other image
 
 
+_SCATTER_WORKER = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from jtsm_amd.modeling.poolers import ROIPooler
+from jtsm_amd.structures import Boxes
+d = np.load(sys.argv[2])
+cuda = torch.device("cuda", 0)
+CL = torch.channels_last
+xs = [torch.from_numpy(d["f%d" % i]).to(cuda).contiguous(memory_format=CL).requires_grad_() for i in range(4)]
+boxes = [Boxes(torch.from_numpy(d["b%d" % i]).to(cuda)) for i in range(2)]
+y = ROIPooler(7, [1 / 4, 1 / 8, 1 / 16, 1 / 32], 0, "ROIAlignV2")(xs, boxes)
+y.backward(torch.from_numpy(d["g"]).to(cuda).contiguous(memory_format=CL))
+np.savez(sys.argv[3], **{"g%d" % i: x.grad.cpu().numpy() for i, x in enumerate(xs)})
+"""
+
+
+def test_multilevel_roi_align_backward_scatter_fallback_in_one_launch(cuda, tmp_path):
+    """The census fallback of the multi-level ROIAlign backward — the float-atomic scatter over the whole level table in
+    ONE launch (csrc/roi_align.hip: align_bwd_nhwc_levels) — forced by a census limit of 1 in a child process (the
+    library reads JTSM_ALIGN_CENSUS_LIMIT once): same gradients as the oracle's per-level scatter."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    from oracle import model as OM
+
+    rng = np.random.default_rng(41)
+    M = 400
+    r = _fpn_like_rois(rng, M, 2, 1024)
+    feats = [rng.standard_normal((2, 64, 256 >> i, 256 >> i)).astype(np.float32) for i in range(4)]
+    per_image = [r[r[:, 0] == b][:, 1:] for b in (0, 1)]
+    g = rng.standard_normal((M, 64, 7, 7)).astype(np.float32)
+    src, dst = str(tmp_path / "in.npz"), str(tmp_path / "out.npz")
+    np.savez(src, g=g, b0=per_image[0], b1=per_image[1], **{"f%d" % i: f for i, f in enumerate(feats)})
+    env = dict(os.environ, JTSM_ALIGN_CENSUS_LIMIT="1")
+    subprocess.run([sys.executable, "-c", _SCATTER_WORKER, ROOT, src, dst], env=env, check=True, timeout=600)
+    got = np.load(dst)
+    fr = [torch.from_numpy(f).requires_grad_() for f in feats]
+    rois = torch.cat([torch.cat([torch.full((len(b), 1), float(i)), torch.from_numpy(b)], 1) for i, b in enumerate(per_image)])
+    OM.roi_align_levels(fr, rois, 1024, 7).backward(torch.from_numpy(g))
+    for i, b in enumerate(fr):
+        ref = b.grad.numpy() if b.grad is not None else np.zeros_like(feats[i])     # (a level without rois)
+        assert np.allclose(got["g%d" % i], ref, rtol=1e-4, atol=1e-4 * max(1.0, float(np.abs(ref).max()))), i
+    assert float(np.abs(got["g0"]).sum()) > 0
+
+
 def test_fp16_boundary_moi_pool_exact_and_roi_align_rounded_once(cuda):
     """fp16 tensors at the pooling boundary (MOIPool_cuda.cu:400 dispatches on half; roi_align_rotated.py:79-85
     up-casts): MOIPool on fp16 features returns exactly the fp32 result on the same (fp16-representable) values, with
