@@ -405,6 +405,23 @@ int jtsm_conv2d_backward_data_ex_f16(const uint16_t* dy_h, const uint16_t* wt_h,
                                      const float* relu_mask, const uint16_t* gate_plane, int grad_shift, void* workspace,
                                      size_t workspace_bytes, void* stream);
 
+/* fp16-ONLY activations (BASELINE configs[4]; the reference's AMP step keeps activations and their gradients in fp16,
+ * detectron2/engine/train_loop.py:289-336): a chain of layers whose activations exist as their fp16 operand plane alone.
+ *   forward_res16:        jtsm_conv2d_forward_f16 with the RESIDUAL read from an fp16 plane (a block input that has no
+ *                         fp32 copy): y = relu?(conv * scale + bias + half(residual_h)); y may be NULL (plane only).
+ *   backward_data_acc16:  jtsm_conv2d_backward_data_ex_f16 with the ACCUMULATE term read from an fp16 gradient plane
+ *                         carrying 2^grad_shift (the shortcut path's gradient): dx = conv^T(dy) + accumulate_h * 2^-shift,
+ *                         then row scale / gate as in the _ex form; dx may be NULL (plane only).
+ * Both need out_c (in_c) % 4 == 0 and 16-byte aligned planes; not the strided 1x1 scatter. */
+int jtsm_conv2d_forward_res16_f16(const uint16_t* x_h, const uint16_t* w_h, float* y, uint16_t* y_h,
+                                  const jtsm_conv_shape* s, const float* scale, const float* bias,
+                                  const uint16_t* residual_h, int relu, void* workspace, size_t workspace_bytes,
+                                  void* stream);
+int jtsm_conv2d_backward_data_acc16_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                        const jtsm_conv_shape* s, const float* row_scale, const uint16_t* accumulate_h,
+                                        const uint16_t* gate_plane, int grad_shift, void* workspace,
+                                        size_t workspace_bytes, void* stream);
+
 /* The same data gradients (and the transposed convolution's), also leaving the COLUMN SUMS of the finished, gated
  * result: colsum (rows x in_c floats, rows = jtsm_conv_bf16x3_colsum_rows(s, role); role 0 for the transposed
  * convolution's conv shape, 1 for a data gradient; 0 rows: not available for this shape) holds one partial sum per row

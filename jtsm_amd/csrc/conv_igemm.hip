@@ -57,6 +57,11 @@ struct Epilogue {
   const float* residual;  // [M][ldc] or null (may alias the output)
   const float* mask;      // [M][ldc] or null: keep value where mask > 0
   int relu;
+  // fp16-only activations (BASELINE configs[4], the reference's AMP step: detectron2/engine/train_loop.py:289-336): the
+  // residual operand as ONE fp16 plane carrying 2^res_shift (a block input kept as its operand plane only; a gradient
+  // plane), used when `residual` is null.  Wide epilogue and the finishing passes only.
+  const unsigned short* residual_h;
+  int res_shift;
 };
 
 struct Params {
@@ -108,6 +113,17 @@ constexpr int PAD_D = 4;  // direct-store tiles:     stride BM+4
 
 // 2^k as a float (|k| < 127), exact
 __device__ __forceinline__ float pow2i(int k) { return __int_as_float((127 + k) << 23); }
+
+// Epilogue::residual_h: four / one element(s) of the fp16 residual plane as floats
+__device__ __forceinline__ float4 res_h4(const Epilogue& e, size_t o) {
+  typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+  const f16x4_t h = *reinterpret_cast<const f16x4_t*>(e.residual_h + o);
+  const float a = pow2i(-e.res_shift);
+  return make_float4((float)h[0] * a, (float)h[1] * a, (float)h[2] * a, (float)h[3] * a);
+}
+__device__ __forceinline__ float res_h1(const Epilogue& e, size_t o) {
+  return (float)reinterpret_cast<const _Float16*>(e.residual_h)[o] * pow2i(-e.res_shift);
+}
 
 __device__ __forceinline__ float4 ldg4(const float* p) {
   return *reinterpret_cast<const float4*>(p);
@@ -443,7 +459,8 @@ __device__ __forceinline__ void splitk_fold(const Params& p, int npiece, PIECE p
   else run(std::integral_constant<int, 8>{});
 }
 
-template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256, class MAP = LinearRows>
+template <int ROLE, int BM, int BN, int PASSES = 1, int TM = 2, int TN = 2, int NT = 256, class MAP = LinearRows,
+          bool RESH = false /* honour Epilogue::residual_h (the fp16 instantiations) */>
 __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[TM][TN], int m0, int n0, int wm, int wn,
                                                 int lane, int tid, float* tile /* [BM / PASSES][BN] in LDS */,
                                                 const MAP* map = nullptr, int split = -1, int tile_id = -1) {
@@ -481,6 +498,8 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
   // the arithmetic of the fused epilogue on one float4 piece, operands already in registers.  Every step is
   // individually rounded — no FMA contraction — so that the direct epilogue, the in-kernel split-K finishing and the
   // separate splitk_finish pass produce the same bits.
+  const bool res16 = RESH && !e.residual && e.residual_h;
+  const bool has_res = e.residual || res16;
   auto chain = [&](float4 v, bool has_scale, const float4& sc, const float4& bi, const float4& rr, const float4& mk,
                    const short4& mp) -> float4 {   // (mk: the fp32 gate; mp: the gate read from a 16-bit plane)
     if (p.in_shift) { const float a = pow2i(-p.in_shift); v.x *= a; v.y *= a; v.z *= a; v.w *= a; }
@@ -490,7 +509,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
     if (e.bias) {
       v.x = __fadd_rn(v.x, bi.x); v.y = __fadd_rn(v.y, bi.y); v.z = __fadd_rn(v.z, bi.z); v.w = __fadd_rn(v.w, bi.w);
     }
-    if (e.residual) {
+    if (has_res) {
       v.x = __fadd_rn(v.x, rr.x); v.y = __fadd_rn(v.y, rr.y); v.z = __fadd_rn(v.z, rr.z); v.w = __fadd_rn(v.w, rr.w);
     }
     if (e.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
@@ -513,6 +532,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
     else if (e.scale) sc = *reinterpret_cast<const float4*>(e.scale + nb);
     if (e.bias) bi = *reinterpret_cast<const float4*>(e.bias + nb);
     if (e.residual) rr = *reinterpret_cast<const float4*>(e.residual + o);
+    else if (res16) rr = res_h4(e, o);
     if (e.mask) mk = *reinterpret_cast<const float4*>(e.mask + o);
     if (p.mask_plane) mp = *reinterpret_cast<const short4*>(p.mask_plane + o);
     v = chain(v, e.scale != nullptr, sc, bi, rr, mk, mp);
@@ -545,7 +565,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
     if (e.scale && !row_scale) sc_col = *reinterpret_cast<const float4*>(e.scale + nb_col);
     if (e.bias) bi_col = *reinterpret_cast<const float4*>(e.bias + nb_col);
   }
-  const bool piped = !raw && (e.residual || e.mask || p.mask_plane);
+  const bool piped = !raw && (has_res || e.mask || p.mask_plane);
   float4 csum = make_float4(0.f, 0.f, 0.f, 0.f);    // (p.colsum) this thread's four columns over its rows, in row order
   int pm[U];
   float4 prr[U], pmk[U];
@@ -562,6 +582,7 @@ __device__ __forceinline__ void store_tile_wide(const Params& p, f32x16 (&acc)[T
       int nb;
       const size_t o = m >= 0 ? locate(m, n, nb) : 0;
       if (e.residual) prr[u] = *reinterpret_cast<const float4*>(e.residual + o);
+      else if (res16) prr[u] = res_h4(e, o);
       if (e.mask) pmk[u] = *reinterpret_cast<const float4*>(e.mask + o);
       if (p.mask_plane) pmp[u] = *reinterpret_cast<const float2*>(p.mask_plane + o);
     }
@@ -1205,6 +1226,7 @@ __global__ __launch_bounds__(256) void splitk_finish_shared(const Params p, int 
       if (e.scale) x = __fmul_rn(x, e.scale[scale_by_row ? m : n + j]);
       if (e.bias) x = __fadd_rn(x, e.bias[n + j]);
       if (e.residual) x = __fadd_rn(x, e.residual[o + j]);
+      else if (e.residual_h) x = __fadd_rn(x, res_h1(e, o + j));
       if (e.relu) x = fmaxf(x, 0.f);
       if (e.mask) x = e.mask[o + j] > 0.f ? x : 0.f;
       if (p.mask_plane) x = (short)p.mask_plane[o + j] > 0 ? x : 0.f;
@@ -1267,8 +1289,8 @@ __device__ __forceinline__ void splitk_finish_body(const Params& p, int splits, 
         if (e.bias) e_bi[j] = e.bias[n + j];
       }
       if (VEC == 4) {   // (16-byte alignment of residual / mask and 8-byte alignment of the gate plane: finish_split)
-        if (e.residual) {
-          const float4 t = *reinterpret_cast<const float4*>(e.residual + o);
+        if (e.residual || e.residual_h) {
+          const float4 t = e.residual ? *reinterpret_cast<const float4*>(e.residual + o) : res_h4(e, o);
           e_rr[0] = t.x; e_rr[1 % VEC] = t.y; e_rr[2 % VEC] = t.z; e_rr[3 % VEC] = t.w;
         }
         if (e.mask) {
@@ -1281,6 +1303,7 @@ __device__ __forceinline__ void splitk_finish_body(const Params& p, int splits, 
         }
       } else {
         if (e.residual) e_rr[0] = e.residual[o];
+        else if (e.residual_h) e_rr[0] = res_h1(e, o);
         if (e.mask) e_mk[0] = e.mask[o];
         if (p.mask_plane) e_mp[0] = (short)p.mask_plane[o];
       }
@@ -1340,6 +1363,7 @@ __device__ __forceinline__ void splitk_finish_body(const Params& p, int splits, 
         if (e.scale) e_sc[j] = e.scale[scale_by_row ? m : n + j];
         if (e.bias) e_bi[j] = e.bias[n + j];
         if (e.residual) e_rr[j] = e.residual[o + j];
+        else if (e.residual_h) e_rr[j] = res_h1(e, o + j);
         if (e.mask) e_mk[j] = e.mask[o + j];
         if (p.mask_plane) e_mp[j] = (short)p.mask_plane[o + j];
       }
@@ -1349,7 +1373,7 @@ __device__ __forceinline__ void splitk_finish_body(const Params& p, int splits, 
       float x = v[j] * alpha;                                   // (a power of two: exact)
       if (e.scale) x = __fmul_rn(x, e_sc[j]);
       if (e.bias) x = __fadd_rn(x, e_bi[j]);
-      if (e.residual) x = __fadd_rn(x, e_rr[j]);
+      if (e.residual || e.residual_h) x = __fadd_rn(x, e_rr[j]);
       if (e.relu) x = fmaxf(x, 0.f);
       if (e.mask) x = e_mk[j] > 0.f ? x : 0.f;
       if (p.mask_plane) x = e_mp[j] > 0 ? x : 0.f;
@@ -1749,6 +1773,8 @@ struct FwdExtras {
   int in_shift = 0, out_shift = 0;
   int shuffle_c = 0, shuffle_h = 0, shuffle_w = 0;   // Params::shuffle_*
   float* colsum = nullptr;                            // Params::colsum
+  const uint16_t* residual_h = nullptr;               // Epilogue::residual_h (fp16 instantiations only)
+  int res_shift = 0;
 };
 
 template <int NP>
@@ -1779,6 +1805,9 @@ static int x3_forward(const uint16_t* x_hi, const uint16_t* x_lo, const uint16_t
   JTSM_REQUIRE(!ex.mask_plane || aligned16(ex.mask_plane), "conv forward bf16x3: the gate plane must be 16-byte aligned");
   p.shuffle_c = ex.shuffle_c; p.shuffle_h = ex.shuffle_h; p.shuffle_w = ex.shuffle_w;
   p.colsum = ex.colsum;
+  JTSM_REQUIRE(!ex.residual_h || (NP == 1 && !residual && aligned16(ex.residual_h) && p.N % 4 == 0 && !ex.shuffle_c),
+               "conv forward f16: the fp16 residual plane needs the fp16 arithmetic, out_c %% 4 == 0 and 16-byte alignment");
+  p.e.residual_h = ex.residual_h; p.e.res_shift = ex.res_shift;
   JTSM_REQUIRE(!ex.colsum || (aligned16(ex.colsum) && !ex.shuffle_c), "conv forward bf16x3: column sums need a 16-byte aligned buffer (and no pixel shuffle)");
   JTSM_REQUIRE(!ex.mask || aligned16(ex.mask), "conv forward bf16x3: the gate must be 16-byte aligned");
   if (ex.shuffle_c) {   // only the wide epilogue knows the pixel-shuffle map, and a K split's finishing pass does not
@@ -1804,7 +1833,7 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
                             const jtsm_conv_shape* s, const float* accumulate, const float* relu_mask, int grad_shift,
                             void* workspace, size_t workspace_bytes, void* stream,
                             const uint16_t* gate_plane = nullptr, const float* row_scale = nullptr,
-                            float* colsum = nullptr) {
+                            float* colsum = nullptr, const uint16_t* accumulate_h = nullptr) {
   int rc = check_shape(s);
   if (rc) return rc;
   Params p = {};
@@ -1829,6 +1858,11 @@ static int x3_backward_data(const uint16_t* dy_hi, const uint16_t* dy_lo, const 
                 reinterpret_cast<const __bf16*>(wt_hi), reinterpret_cast<const __bf16*>(wt_lo)};
   p.C = dx; p.ldc = p.N;
   p.e.residual = accumulate; p.e.mask = relu_mask;
+  // (accumulate_h: another gradient term as an fp16 plane carrying 2^grad_shift, added in the epilogue)
+  JTSM_REQUIRE(!accumulate_h || (NP == 1 && !accumulate && aligned16(accumulate_h) && p.N % 4 == 0 &&
+                                 !(p.s.KH == 1 && p.s.KW == 1 && p.s.stride > 1)),
+               "conv backward-data f16: an fp16 accumulate plane needs the fp16 arithmetic, in_c %% 4 == 0, no strided 1x1");
+  p.e.residual_h = accumulate_h; p.e.res_shift = grad_shift;
   JTSM_REQUIRE(NP == 1 || (dx_hi == nullptr) == (dx_lo == nullptr), "conv backward-data bf16x3: give both output planes or neither");
   hipStream_t st = as_stream(stream);
   if (!workspace) workspace_bytes = 0;
@@ -2181,6 +2215,24 @@ int jtsm_conv2d_forward_f16(const uint16_t* x_h, const uint16_t* w_h, float* y, 
                             void* stream) {
   return x3_forward<1>(x_h, nullptr, w_h, nullptr, y, y_h, nullptr, s, scale, bias, residual, relu, workspace,
                        workspace_bytes, stream);
+}
+
+/* ---- fp16-only activations: the residual / accumulate operand as an fp16 plane (include/jtsm_hip.h) ---- */
+int jtsm_conv2d_forward_res16_f16(const uint16_t* x_h, const uint16_t* w_h, float* y, uint16_t* y_h,
+                                  const jtsm_conv_shape* s, const float* scale, const float* bias,
+                                  const uint16_t* residual_h, int relu, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+  FwdExtras ex;
+  ex.residual_h = residual_h;
+  return x3_forward<1>(x_h, nullptr, w_h, nullptr, y, y_h, nullptr, s, scale, bias, nullptr, relu, workspace,
+                       workspace_bytes, stream, ex);
+}
+int jtsm_conv2d_backward_data_acc16_f16(const uint16_t* dy_h, const uint16_t* wt_h, float* dx, uint16_t* dx_h,
+                                        const jtsm_conv_shape* s, const float* row_scale, const uint16_t* accumulate_h,
+                                        const uint16_t* gate_plane, int grad_shift, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+  return x3_backward_data<1>(dy_h, nullptr, wt_h, nullptr, dx, dx_h, nullptr, s, nullptr, nullptr, grad_shift,
+                             workspace, workspace_bytes, stream, gate_plane, row_scale, nullptr, accumulate_h);
 }
 
 // ---- ConvTranspose2d(kernel 2, stride 2, padding 0): the mask heads' upsampler -----------------------------------

@@ -377,7 +377,8 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
   }
   static_assert(LDSB >= BM * BN * 4 / PASSES && (BM / PASSES) % (32 * TM) == 0, "epilogue band does not fit / split a wave tile");
   if (p.wide)
-    store_tile_wide<ROLE, BM, BN, PASSES, TM, TN, NT>(p, acc, m0, n0, wm, wn, lane, tid, reinterpret_cast<float*>(lds));
+    store_tile_wide<ROLE, BM, BN, PASSES, TM, TN, NT, LinearRows, NP == 1>(p, acc, m0, n0, wm, wn, lane, tid,
+                                                                            reinterpret_cast<float*>(lds));
   else
     store_tile<ROLE, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
@@ -1268,8 +1269,8 @@ int launch_x3_cfg(Params& p, const X3Planes& q, void* workspace, size_t workspac
            (!p.e.residual || aligned16(p.e.residual)) && (!p.e.mask || aligned16(p.e.mask)) &&
            (!p.e.scale || aligned16(p.e.scale)) && (!p.e.bias || aligned16(p.e.bias));
   JTSM_REQUIRE(!p.out_hi || p.wide, "conv bf16x3: output planes requested but the tensors are not 16-byte aligned");
-  JTSM_REQUIRE((!p.mask_plane && !p.scale_rows && p.C && !p.colsum) || p.wide,
-               "conv bf16x3: a gate plane, a row scale, column sums or a planes-only result need N %% 4 == 0 and 16-byte aligned tensors");
+  JTSM_REQUIRE((!p.mask_plane && !p.scale_rows && p.C && !p.colsum && !p.e.residual_h) || p.wide,
+               "conv bf16x3: a gate plane, a row scale, column sums, an fp16 residual plane or a planes-only result need N %% 4 == 0 and 16-byte aligned tensors");
   const dim3 grid(ntiles, splits > 1 ? splits : 1);
   const bool fused = use_fused_finish(p, ntiles, splits, st);
   if (NT == 256 && ceil_div(ktiles, splits > 1 ? splits : 1) <= x3_nbuf1_stages(ROLE))
@@ -1390,7 +1391,7 @@ int launch_x3_halo(Params& p, const X3Planes& q, void* workspace, size_t workspa
 
 template <int ROLE, int NP = 2>
 int launch_split_x3(Params& p, const X3Planes& q, void* workspace, size_t workspace_bytes, hipStream_t st) {
-  if (!p.colsum && x3_halo_ok(ROLE, p)) {   // (column sums: the generic kernel's row tiles)
+  if (!p.colsum && !p.e.residual_h && x3_halo_ok(ROLE, p)) {   // (column sums: the generic kernel's row tiles; so is the fp16 residual plane)
     if (x3_tile_choice(p) == 2) return launch_x3_halo<ROLE, true, NP>(p, q, workspace, workspace_bytes, st);
     return launch_x3_halo<ROLE, false, NP>(p, q, workspace, workspace_bytes, st);
   }

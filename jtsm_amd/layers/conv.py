@@ -768,9 +768,11 @@ class PlaneTensor(object):
         return PlaneTensor(_planes_buf(n, device), shape)
 
 
-def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=False, scale=None, residual=None):
+def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=False, scale=None, residual=None,
+                   residual_plane=None):
     """x: PlaneTensor -> PlaneTensor of relu?(conv(x, w) + bias) (fp32=False: planes only, no fp32 copy is written), or
-    the fp32 result alone (fp32=True: a chain's last layer, read by a loss)."""
+    the fp32 result alone (fp32=True: a chain's last layer, read by a loss).  residual_plane (fp16 arithmetic only): the
+    residual as a PlaneTensor — a block input that exists as its operand plane alone."""
     pl = _plan(x.shape, w.shape, stride, pad, dil)
     s = pl.s
     if not pl.x3[0]:
@@ -788,7 +790,14 @@ def planes_forward(x, w, stride=1, pad=0, dil=1, bias=None, relu=False, fp32=Fal
     n_out = s.batch * s.out_c * pl.oh * pl.ow
     if residual is not None:
         residual = _cl(residual)
-    if MATH == "f16":
+    if residual_plane is not None:
+        assert MATH == "f16" and residual is None and tuple(residual_plane.shape) == oshape
+        rh = _hl(residual_plane.buf)[0]
+        L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_res16_f16(
+            xh, wh, L.ptr(y), yh, pl.ref, L.ptr(scale), L.ptr(bias), rh, int(bool(relu)), L.ptr(ws),
+            C.c_size_t(nbytes), L.stream()), pl.desc, 0.5 * n_out, n_out, yp is not None, bool(fp32)),
+                "conv2d_forward_res16_f16")
+    elif MATH == "f16":
         L.check(_timed(_x3_variant(s, 0), pl.flops, lambda: lib.jtsm_conv2d_forward_f16(
             xh, wh, L.ptr(y), yh, pl.ref, L.ptr(scale), L.ptr(bias), L.ptr(residual), int(bool(relu)), L.ptr(ws),
             C.c_size_t(nbytes), L.stream()), pl.desc, _numel(residual), n_out, yp is not None, bool(fp32)),
@@ -849,14 +858,15 @@ class _ColsumSlot(object):
 
 
 def planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
-                         row_scale=None, kscale=None, both=False, into=None, bias_out=None):
+                         row_scale=None, kscale=None, both=False, into=None, bias_out=None, accumulate_plane=None):
     """bias_out (a ColsumBatch slot): ALSO the column sums of the finished (gated) result — the bias gradient of the
     layer whose output gradient this call produces — taken in the epilogue that writes it.  Returns (result, True)
     then, or (result, False) when this shape cannot (the caller sums the planes afterwards)."""
     if bias_out is not None:
         assert not fp32 and not both and accumulate is None and into is None
         return _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out, row_scale)
-    return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, fp32, accumulate, row_scale, kscale, both, into)
+    return _planes_backward_data(g, w, x_shape, stride, pad, dil, gate, fp32, accumulate, row_scale, kscale, both, into,
+                                 accumulate_plane)
 
 
 def _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, bias_out, row_scale=None):
@@ -887,7 +897,7 @@ def _planes_backward_data_colsum(g, w, x_shape, stride, pad, dil, gate, kscale, 
 
 
 def _planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32=False, accumulate=None,
-                          row_scale=None, kscale=None, both=False, into=None):
+                          row_scale=None, kscale=None, both=False, into=None, accumulate_plane=None):
     """... kscale: per-output-channel factor folded into the weight rows (FrozenBN).  both: fp32 AND planes."""
     """g: PlaneTensor of the output gradient (gradient planes: times 2^GRAD_SHIFT in fp16 mode); gate: PlaneTensor of
     the ReLU output the result is gated by (or None) -> the input gradient as fp32 tensor (fp32=True) or PlaneTensor."""
@@ -917,7 +927,15 @@ def _planes_backward_data(g, w, x_shape, stride=1, pad=0, dil=1, gate=None, fp32
     extra = (0.5 * n_in if gate is not None else 0) + _numel(accumulate)     # (the gate plane: 2 bytes per element)
     if accumulate is not None:
         accumulate = _cl(accumulate)
-    if MATH == "f16":
+    if accumulate_plane is not None:
+        # another gradient term as an fp16 plane (times 2^GRAD_SHIFT): the shortcut path of a chain whose gradient
+        # stream has no fp32 copy
+        assert MATH == "f16" and accumulate is None and into is None and tuple(accumulate_plane.shape) == tuple(x_shape)
+        ah = _hl(accumulate_plane.buf)[0]
+        L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_acc16_f16(
+            gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(row_scale), ah, gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes),
+            L.stream()), pl.desc, extra + 0.5 * n_in, n_in, dp is not None, fp32), "conv2d_backward_data_acc16_f16")
+    elif MATH == "f16":
         L.check(_timed(_x3_variant(s, 1), pl.flops, lambda: lib.jtsm_conv2d_backward_data_ex_f16(
             gh, wh, L.ptr(dx), dh, pl.ref, L.ptr(row_scale), L.ptr(accumulate), None, gate_h, GRAD_SHIFT, L.ptr(ws), C.c_size_t(nbytes), L.stream()),
             pl.desc, extra, n_in, dp is not None, fp32), "conv2d_backward_data_ex_f16")

@@ -45,6 +45,8 @@ def _dgrad(g, w, scale, x_shape, stride, pad, dil, accumulate=None, relu_mask=No
 # consumer's term into it in place (it adds into a fresh tensor instead, which then fails the identity check below
 # and is gated the ordinary way).
 _PREGATED = [None]
+# fp16 arithmetic: the identity-shortcut blocks of a stage as one node on fp16 planes only (JTSM_CHAIN16=0: per-block nodes)
+CHAIN16 = os.environ.get("JTSM_CHAIN16", "1") != "0"
 
 
 def _drop_pregated():
@@ -197,6 +199,108 @@ class _BottleneckFn(Function):
         return (dx, _same_strides(dw1, w1), None, None, _same_strides(dw2, w2), None, None, _same_strides(dw3, w3),
                 None, None, _same_strides(dws, ws) if ws is not None else None, None, None, None, None, None, None, None,
                 None, None)
+
+
+class _IdentityChain16Fn(Function):
+    """fp16-ONLY activations (BASELINE configs[4]; the reference's AMP step keeps activations and their gradients in
+    fp16, detectron2/engine/train_loop.py:289-336): the identity-shortcut blocks of a stage — every block after its
+    first — as ONE autograd node in the fp16 arithmetic.  Inside it an activation exists as its fp16 operand plane and
+    nothing else: conv3's epilogue reads the residual from the block input's plane (jtsm_conv2d_forward_res16_f16) and
+    writes the block output's plane only; backward, the gradient stream between the blocks is an fp16 plane carrying
+    2^GRAD_SHIFT — conv1's data-gradient epilogue adds the shortcut term from the previous plane
+    (jtsm_conv2d_backward_data_acc16_f16), gates by the block input's plane and emits the next one.  fp32 exists for the
+    chain's input (the first block's output, whose plane is reused), its output (read by the FPN lateral and the next
+    stage) and the two gradients at those ends.  Per inner block output that is 2 B written + 2 B read instead of
+    4 + 2 B written + 4 B read.
+
+    apply(x, pad2, dil2, n, w1, s1, b1, w2, s2, b2, w3, s3, b3, ... per block) -> y."""
+
+    @staticmethod
+    def forward(ctx, x, pad2, dil2, n, *params):
+        inp = K.PlaneTensor.of(x)
+        saved, y = [], None
+        for k in range(n):
+            w1, s1, b1, w2, s2, b2, w3, s3, b3 = params[9 * k:9 * k + 9]
+            y1 = K.planes_forward(inp, w1, 1, 0, 1, b1, True, scale=s1)
+            y2 = K.planes_forward(y1, w2, 1, pad2, dil2, b2, True, scale=s2)
+            if k == n - 1:
+                y, yp = K.planes_forward(y2, w3, 1, 0, 1, b3, True, fp32="both", scale=s3, residual_plane=inp)
+                K.planes_put(y, yp.buf)
+            else:
+                yp = K.planes_forward(y2, w3, 1, 0, 1, b3, True, scale=s3, residual_plane=inp)
+            saved.append((inp, y1, y2))
+            inp = yp
+        ctx.cfg, ctx.inner, ctx.xshape = (pad2, dil2, n), saved, tuple(x.shape)
+        ctx.save_for_backward(y, *params)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        pad2, dil2, n = ctx.cfg
+        y, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        need = ctx.needs_input_grad
+        grads = [None] * (9 * n)
+        # the chain's own output gate (the next stage's first block never pre-gates: it has a projection shortcut)
+        g = dy if _take_pregated(dy) else relu_backward(dy, y, emit_planes=True)
+        gp = K.PlaneTensor.of(g, grad=True)
+        dx = None
+        for k in range(n - 1, -1, -1):
+            w1, s1, b1, w2, s2, b2, w3, s3, b3 = params[9 * k:9 * k + 9]
+            inp, y1, y2 = ctx.inner[k]
+            base = 4 + 9 * k
+            if need[base + 6]:
+                grads[9 * k + 6] = _same_strides(K.planes_backward_weight_deferred(gp, y2, w3, 1, 0, 1, row_scale=s3), w3)
+            d2 = K.planes_backward_data(gp, w3, y2.shape, 1, 0, 1, gate=y2, kscale=s3)
+            if need[base + 3]:
+                grads[9 * k + 3] = _same_strides(K.planes_backward_weight_deferred(d2, y1, w2, 1, pad2, dil2, row_scale=s2), w2)
+            d1 = K.planes_backward_data(d2, w2, y1.shape, 1, pad2, dil2, gate=y1, kscale=s2)
+            if need[base]:
+                grads[9 * k] = _same_strides(K.planes_backward_weight_deferred(d1, inp, w1, 1, 0, 1, row_scale=s1), w1)
+            if k > 0:
+                # gradient at this block's input = the previous block's output: conv1's term + the shortcut's (gp), gated
+                # by that output's ReLU (its plane) — a plane only
+                gp = K.planes_backward_data(d1, w1, inp.shape, 1, 0, 1, kscale=s1, accumulate_plane=gp, gate=inp)
+            elif need[0]:
+                # the chain's input is the first block's ReLU output: its gate rides here too, and the first block's
+                # node takes the gradient as already gated (fp32 + planes)
+                dx, dxp = K.planes_backward_data(d1, w1, ctx.xshape, 1, 0, 1, kscale=s1, accumulate_plane=gp, gate=inp,
+                                                 both=True)
+                K.planes_put(dx, dxp.buf)
+                _hand_pregated(dx)
+        ctx.inner = None
+        return (dx, None, None, None) + tuple(grads)
+
+
+def identity_chain_ok(x, blocks):
+    """The blocks after a stage's first one as an fp16-only chain: fp16 arithmetic, fused nodes on, frozen norms,
+    identity shortcuts, stride 1, one 3x3 geometry, plane-eligible widths."""
+    if not (ENABLED and CHAIN16 and K.MATH == "f16" and blocks and x.is_cuda and x.dtype == torch.float32 and
+            x.shape[0] > 0):
+        return False
+    pad2, dil2 = blocks[0].conv2.padding[0], blocks[0].conv2.dilation[0]
+    for b in blocks:
+        if getattr(b, "shortcut", True) is not None:
+            return False
+        cs = (b.conv1, b.conv2, b.conv3)
+        if any(c.stride[0] != 1 for c in cs) or b.conv2.padding[0] != pad2 or b.conv2.dilation[0] != dil2:
+            return False
+        if any(not hasattr(c.norm, "scale_bias") for c in cs):
+            return False
+        if not _plane_block_ok(x, b.conv1.weight, b.conv2.weight, b.conv3.weight, None):
+            return False
+    return True
+
+
+def identity_chain_fused(x, blocks):
+    params = []
+    for b in blocks:
+        for c in (b.conv1, b.conv2, b.conv3):
+            s, bi = c.norm.scale_bias()
+            params += [c.weight, s, bi]
+    y = _IdentityChain16Fn.apply(x, blocks[0].conv2.padding[0], blocks[0].conv2.dilation[0], len(blocks), *params)
+    y._jtsm_block_relu_out = True
+    return y
 
 
 def _plane_block_ok(x, w1, w2, w3, ws):

@@ -155,7 +155,7 @@ class ResNet(Backbone):
         if "stem" in keep:
             out["stem"] = x
         for name in self.stage_names:
-            x = getattr(self, name)(x)
+            x = self._run_stage(getattr(self, name), x)
             if name in keep:
                 if name != self.stage_names[-1]:
                     # read twice — by whoever takes the feature (an FPN lateral) and by the next stage: one view each, so
@@ -164,6 +164,22 @@ class ResNet(Backbone):
                 else:
                     out[name] = x
         return out
+
+    @staticmethod
+    def _run_stage(stage, x):
+        """The stage's blocks in order.  In the fp16 arithmetic the identity-shortcut blocks behind the first one run
+        as ONE node whose activations are fp16 planes only (layers/fused_blocks.py: _IdentityChain16Fn)."""
+        blocks = list(stage.children())
+        rest = blocks[1:]
+        if rest and all(isinstance(b, BottleneckBlock) and _all_frozen(b._members()) for b in blocks) and \
+                fused_blocks.identity_chain_ok(x, rest):
+            y = blocks[0](x)
+            if fused_blocks.identity_chain_ok(y, rest):
+                return fused_blocks.identity_chain_fused(y, rest)
+            for b in rest:
+                y = b(y)
+            return y
+        return stage(x)
 
     def freeze(self, freeze_at=0):
         """freeze_at = 1 freezes the stem, 2 also res2, ... (resnet.py:457-479)."""

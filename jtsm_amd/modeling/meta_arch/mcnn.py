@@ -7,6 +7,8 @@ Input contract (mcnn.py:163-171,185-207): a list of dicts with `image` (3,H,W), 
 (gt_classes[, gt_boxes]), `sem_seg` (H,W) long, `proposals` Instances(proposal_boxes, objectness_logits,
 oh_labels), `superpixels` (H,W) int.  Images are kept channels_last from the first pad onward.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -20,6 +22,10 @@ from ...layers.grad_fan import fan_out
 from ...layers.postprocess import argmax_channels, preprocess_images_u8
 from ..postprocessing import detector_postprocess, sem_seg_postprocess
 from .panoptic_fpn import combine_semantic_and_instance_outputs
+
+# The semantic head's forward enqueued inside the mask branch's synchronisation window (roi_heads_jtsm.py: sync_window):
+# JTSM_SEM_IN_SYNC_WINDOW=0 restores the order of the reference's forward (heads one after the other).
+SEM_IN_SYNC_WINDOW = os.environ.get("JTSM_SEM_IN_SYNC_WINDOW", "1") != "0"
 
 
 @META_ARCH_REGISTRY.register()
@@ -83,12 +89,21 @@ class GeneralizedMCNNWSL(nn.Module):
         # (layers/grad_fan.py); without it, or for a head that does not take part, the views behave like `features`
         fans = {k: fan_out(v, 3) for k, v in features.items()}
         f_box, f_mask, f_sem = ({k: v[i] for k, v in fans.items()} for i in range(3))
+        in_window = SEM_IN_SYNC_WINDOW and getattr(self.roi_heads, "mask_on", False) and \
+            getattr(self.roi_heads, "takes_mask_features", False)
+        if in_window:   # the semantic head's forward fills the wait for the mask branch's foreground count
+            self.roi_heads.sync_window = lambda: self.sem_seg_head(f_sem, self.roi_heads.pgt_sem_seg)
         if getattr(self.roi_heads, "takes_mask_features", False):
             _, detector_losses = self.roi_heads(images, f_box, proposals, gt_instances, gt_sem_seg, superpixels,
                                                 mask_features=f_mask)
         else:
             _, detector_losses = self.roi_heads(images, f_box, proposals, gt_instances, gt_sem_seg, superpixels)
-        _, sem_seg_losses = self.sem_seg_head(f_sem, self.roi_heads.pgt_sem_seg)
+        if in_window:
+            self.roi_heads.sync_window = None
+            _, sem_seg_losses = self.roi_heads.sync_window_result
+            self.roi_heads.sync_window_result = None
+        else:
+            _, sem_seg_losses = self.sem_seg_head(f_sem, self.roi_heads.pgt_sem_seg)
         losses = {}
         losses.update(sem_seg_losses)
         losses.update(detector_losses)

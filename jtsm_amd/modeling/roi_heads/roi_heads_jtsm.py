@@ -256,6 +256,11 @@ class JTSMROIHeads(ROIHeads):
         losses = self._forward_box(features, proposals)
         if self.mask_on:
             self._mask_prepare()
+            # work that does not depend on the foreground count, enqueued while the count is on its way to the host (the
+            # meta-architecture hands the semantic head's forward here): the device keeps busy behind the step's one
+            # synchronisation instead of draining while the host waits
+            window = getattr(self, "sync_window", None)
+            self.sync_window_result = window() if window is not None else None
             losses.update(self._forward_mask(mask_features if mask_features is not None else features, proposals))
         return proposals, losses
 

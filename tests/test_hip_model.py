@@ -509,6 +509,72 @@ def test_r101_rectangular_fp16_losses_within_stated_tolerance(cuda):
     assert not bad, bad
 
 
+def test_fp16_only_identity_chain_matches_the_per_block_nodes(cuda):
+    """fp16-only activations.  A stage's identity blocks as ONE node whose activations and gradient
+    stream are fp16 planes alone (layers/fused_blocks.py: _IdentityChain16Fn; residual / shortcut gradient read from
+    planes: jtsm_conv2d_forward_res16_f16 / jtsm_conv2d_backward_data_acc16_f16) against (1) the per-block nodes of the
+    same fp16 arithmetic, which keep an fp32 residual stream, and (2) the same stage in exact fp32: output, input
+    gradient and every weight gradient within the fp16 leg's stated bars (operands round at 2^-11 per layer either
+    way; the chain also rounds the residual stream once per block, as the reference's AMP step does)."""
+    from jtsm_amd.layers import fused_blocks
+    from jtsm_amd.modeling.backbone.resnet import BottleneckBlock, ResNet
+
+    torch.manual_seed(5)
+    blocks = ResNet.make_stage(BottleneckBlock, 5, 2, in_channels=128, out_channels=256, norm="FrozenBN",
+                               bottleneck_channels=64, stride_in_1x1=True)
+    stage = torch.nn.Sequential(*blocks).to(cuda)
+    with torch.no_grad():
+        for n, b in stage.named_buffers():
+            if n.endswith("norm.weight"):
+                b.copy_(torch.rand_like(b) * 0.5 + (0.2 if "conv3" in n else 0.8))
+            if n.endswith("norm.bias"):
+                b.copy_(torch.randn_like(b) * 0.1)
+    x0 = torch.relu(torch.randn(2, 128, 40, 48, device=cuda)).contiguous(memory_format=torch.channels_last)
+    g0 = torch.randn(2, 256, 20, 24, device=cuda).contiguous(memory_format=torch.channels_last)
+    weights = [p for p in stage.parameters()]
+
+    def run(math, chain):
+        old_math, old_chain = K.MATH, fused_blocks.CHAIN16
+        K.set_math(math)
+        fused_blocks.CHAIN16 = chain
+        K.planes_clear()
+        try:
+            x = x0.clone().requires_grad_(True)
+            for p in weights:
+                p.grad = None
+            y = ResNet._run_stage(stage, x)
+            y.backward(g0)
+            K.flush_deferred_weight_gradients()
+            torch.cuda.synchronize()
+            return y.detach().clone(), x.grad.clone(), [p.grad.clone() for p in weights]
+        finally:
+            K.set_math(old_math)
+            fused_blocks.CHAIN16 = old_chain
+
+    fused_blocks_nodes = run("f16", False)
+    chain = run("f16", True)
+    exact = run("f32", False)
+    assert fused_blocks.identity_chain_ok(x0, list(stage.children())[1:]) is False     # (outside the fp16 arithmetic: off)
+
+    def l2(a, b):
+        a, b = a.double(), b.double()
+        return float((a - b).norm() / (b.norm() + 1e-30))
+
+    def errors(a, b, fn):
+        return [fn(a[1], b[1])] + [fn(p, q) for p, q in zip(a[2], b[2])]
+    # A ReLU gate within fp16 rounding of zero falls on different sides in two arithmetics and changes gradient entries
+    # outright (tests above: the free-running gradient test), so the max-norm is compared between the two fp16 forms
+    # and the arithmetic bar is applied to the L2 error
+    max_chain, max_nodes = max(errors(chain, exact, _rel)), max(errors(fused_blocks_nodes, exact, _rel))
+    l2_chain, l2_nodes = max(errors(chain, exact, l2)), max(errors(fused_blocks_nodes, exact, l2))
+    print("fp16-only chain vs exact fp32: output %.2e, gradients max-norm %.2e / L2 %.2e (per-block fp16 nodes: %.2e / %.2e)"
+          % (_rel(chain[0], exact[0]), max_chain, l2_chain, max_nodes, l2_nodes))
+    assert _rel(chain[0], exact[0]) <= FP16_LOSS_TOL, _rel(chain[0], exact[0])          # activations: the loss bar
+    assert l2_chain <= 2 * FP16_GRAD_TOL, errors(chain, exact, l2)                      # (gate flips included: see above)
+    assert max_chain <= 1.5 * max_nodes + 1e-2 and l2_chain <= 1.5 * l2_nodes + 1e-3    # no worse than the fp32-stream form
+    assert all(float(g.abs().max()) > 0 for g in chain[2])
+
+
 def test_config4_full_size_fp16_step(cuda):
     """BASELINE configs[4] at FULL size on one GPU: R101-FPN JTSM panoptic, 2 x 3 x 1024 x 2048 (Cityscapes-shaped),
     2000 proposals per image (the configs[2] recipe scaled x2 in x), fp16 MFMA path.  Too big for the CPU oracle, so
