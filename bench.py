@@ -75,6 +75,9 @@ def parse():
                          "uniform recipe of round 1")
     ap.add_argument("--objects", type=int, default=40, help="proposal groups per image (see --cluster)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] extra leg (R101, fp16)")
+    ap.add_argument("--launch-sequence", default=None,
+                    help="write the contraction launches of one extra step (kernel, model segment, shape) to this JSON "
+                         "file: tools/pmc_mfma.py splits a counter pass of the same command by backbone / FPN / heads")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank code-path rehearsal on a single GPU: every rank uses device 0 and the gloo backend "
                          "(not a measurement)")
@@ -452,6 +455,16 @@ def main():
                          "real proposal sets crowd around regions, the rest uniform" % (round(100 * args.cluster), args.objects),
             "torch_device_ops": ["autograd gradient-accumulation adds", "sort glue of the label path",
                                  "RCCL collectives (N > 1)"]}
+    if args.launch_sequence and world == 1:
+        # the contraction launches of ONE step, in order, with the part of the model they belong to: what
+        # tools/pmc_mfma.py aligns a counter pass of this command with (every step launches the same sequence)
+        conv_layers.LAUNCH_LOG = []
+        step()
+        torch.cuda.synchronize()
+        seq, conv_layers.LAUNCH_LOG = conv_layers.LAUNCH_LOG, None
+        with open(args.launch_sequence, "w") as f:
+            json.dump([{"kernel": str(v), "segment": getattr(v, "segment", None), "shape": list(shape[:-1])}
+                       for v, _, _, shape, _ in seq], f)
     if not args.no_roofline:
         # every rank runs the extra (untimed) step — it contains the gradient all-reduce — rank 0 reports it
         roof, roof_detail = roofline_leg(step)

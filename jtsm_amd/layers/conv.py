@@ -21,6 +21,15 @@ CL = torch.channels_last
 # Optional per-launch timing (bench.py's roofline leg): when a list, every contraction launch appends
 # (kernel variant, algorithmic FLOPs, LaunchSpan, shape); events are recorded on the launch stream.
 LAUNCH_LOG = None
+# Which part of the model the next contraction launches belong to ("backbone" | "fpn" | "heads"): set by the modules on
+# their way forward, remembered by every autograd node of this package and restored at the start of its backward.  Only
+# the measurement tools read it (LAUNCH_LOG entries carry it: bench.py --launch-sequence, tools/pmc_mfma.py).
+SEGMENT = "heads"
+
+
+def set_segment(name):
+    global SEGMENT
+    SEGMENT = name
 
 
 # Contraction arithmetic: "f32" = exact fp32 MFMA; "bf16x3" = split-bf16 (three bf16 MFMA products per fp32
@@ -443,6 +452,8 @@ def _timed(variant, flops, call, shape=None, extra_elems=0, out_elems=0, planes=
     rc = call()
     lib.jtsm_conv_set_mid_event(None)
     lib.jtsm_event_record(C.c_void_p(span.b), st)
+    if variant is not None:
+        variant.segment = SEGMENT
     LAUNCH_LOG.append((variant, flops, span, shape, finish_bytes))
     return rc
 
@@ -997,6 +1008,7 @@ def planes_backward_weight(g, x, w, stride=1, pad=0, dil=1, w_shape=None, row_sc
 DEFER_WGRAD = os.environ.get("JTSM_DEFER_WGRAD", "1") != "0"
 GROUP_MAX = 8
 _DEFERRED = []
+_DEFERRED_SEGMENT = {}     # id(weight) -> SEGMENT at queueing time (measurement only)
 _DEFERRED_PENDING = {}     # id(weight) -> queued launches not delivered yet (engine/dp.py ignores autograd's hook for them)
 STALE_DROPPED = [0]        # (tests) queued launches of an aborted backward dropped at the next forward
 
@@ -1040,6 +1052,7 @@ def planes_backward_weight_deferred(g, x, w, stride=1, pad=0, dil=1, row_scale=N
         except RuntimeError:     # not inside a backward pass: nothing would flush the queue
             return planes_backward_weight(g, x, w, stride, pad, dil, row_scale=row_scale)
     _DEFERRED.append((g, x, w, stride, pad, dil, row_scale))
+    _DEFERRED_SEGMENT[id(w)] = SEGMENT
     _DEFERRED_PENDING[id(w)] = _DEFERRED_PENDING.get(id(w), 0) + 1
     return None
 
@@ -1076,6 +1089,7 @@ def flush_deferred_weight_gradients():
     lib = L.lib()
     for (x_shape, w_shape, stride, pad, dil), members in groups.items():
         pl = _plan(x_shape, w_shape, stride, pad, dil)
+        set_segment(_DEFERRED_SEGMENT.get(id(members[0][2]), SEGMENT))
         for i0 in range(0, len(members), GROUP_MAX):
             part = members[i0:i0 + GROUP_MAX]
             if len(part) == 1 or not pl.x3[2]:
@@ -1312,6 +1326,7 @@ class _ConvFused(Function):
     @staticmethod
     def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True,
                 emit_dx_planes=False, fan=None):
+        ctx.segment = SEGMENT
         y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
         ctx.fan = fan   # (layers/grad_fan.py: conv2d_fused claimed the input's fan view, if it is one)
         ctx.emit_dx_planes = emit_dx_planes   # the input's gradient is the dy of another contraction (FPN laterals)
@@ -1325,6 +1340,7 @@ class _ConvFused(Function):
     def backward(ctx, dy):
         from .elementwise import channel_sum, relu_backward
 
+        set_segment(ctx.segment)
         x, w, scale, y = ctx.saved_tensors
         stride, pad, dil, relu, bias_needs_grad, xs, ws = ctx.cfg
         x3 = MATH != "f32" and dy.shape[0] > 0 and dy.shape[1] % 8 == 0 and \

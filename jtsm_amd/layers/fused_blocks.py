@@ -85,6 +85,7 @@ class _BottleneckFn(Function):
     def forward(ctx, x, w1, s1, b1, w2, s2, b2, w3, s3, b3, ws, ss, bs, stride1, stride2, pad2, dil2, stride_s,
                 pregate=False, fan=None):
         ctx.cfg = (stride1, stride2, pad2, dil2, stride_s)
+        ctx.segment = K.SEGMENT
         ctx.fan = fan   # (layers/grad_fan.py: bottleneck_fused claimed x's fan view, if it is one)
         # x is the ReLU output of the previous block's node (bottleneck_fused tags it): its gate goes into this
         # block's conv1 data-gradient epilogue
@@ -110,6 +111,7 @@ class _BottleneckFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        K.set_segment(ctx.segment)
         if ctx.planes:
             return _BottleneckFn._backward_planes(ctx, dy)
         x, y1, y2, y3, w1, s1, w2, s2, w3, s3, ws, ss = ctx.saved_tensors
@@ -217,6 +219,7 @@ class _IdentityChain16Fn(Function):
 
     @staticmethod
     def forward(ctx, x, pad2, dil2, n, *params):
+        ctx.segment = K.SEGMENT
         inp = K.PlaneTensor.of(x)
         saved, y = [], None
         for k in range(n):
@@ -237,6 +240,7 @@ class _IdentityChain16Fn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        K.set_segment(ctx.segment)
         pad2, dil2, n = ctx.cfg
         y, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         need = ctx.needs_input_grad
@@ -340,6 +344,7 @@ class _MaskTowerFn(Function):
 
     @staticmethod
     def forward(ctx, x, want_features, fan, *params):
+        ctx.segment = K.SEGMENT
         ctx.fan = fan   # (layers/grad_fan.py: mask_tower_fused claimed x's fan view, if it is one)
         k = (len(params) - 4) // 2
         hs = [K.PlaneTensor.of(x)]
@@ -361,6 +366,8 @@ class _MaskTowerFn(Function):
     @once_differentiable
     def backward(ctx, dlogits, du):
         from .elementwise import channel_sum
+
+        K.set_segment(ctx.segment)
 
         k, hs, up = ctx.k, ctx.hs, ctx.up
         saved = ctx.saved_tensors
@@ -528,6 +535,8 @@ class _FcStackFn(Function):
     @once_differentiable
     def backward(ctx, dout, dtail=None):
         from .elementwise import channel_sum, relu_backward_scaled
+
+        K.set_segment("heads")
 
         k, hs = ctx.k, ctx.hs
         ys, ws = ctx.saved_tensors[:k], ctx.saved_tensors[k:2 * k]

@@ -13,6 +13,7 @@ from torch import nn
 
 from ...layers.batch_norm import get_norm
 from ...layers.elementwise import subsample2, upsample2_add
+from ...layers.conv import set_segment
 from ...layers.grad_fan import fan_out
 from ...layers.shape_spec import ShapeSpec
 from ...layers.wrappers import Conv2d
@@ -73,7 +74,9 @@ class FPN(Backbone):
         return self._size_divisibility
 
     def forward(self, x):
+        set_segment("backbone")        # (measurement tag of the contraction launches, layers/conv.py)
         feats = self.bottom_up(x)
+        set_segment("fpn")
         out, merged = {}, None
         for level, name in reversed(self.levels):            # coarsest level first
             lateral = getattr(self, "fpn_lateral%d" % level)(feats[name])

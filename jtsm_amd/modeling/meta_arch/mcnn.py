@@ -17,7 +17,7 @@ from ..backbone import build_backbone
 from ..roi_heads import build_roi_heads
 from .build import META_ARCH_REGISTRY
 from .semantic_seg import build_sem_seg_head
-from ...layers.conv import planes_clear
+from ...layers.conv import planes_clear, set_segment
 from ...layers.grad_fan import fan_out
 from ...layers.postprocess import argmax_channels, preprocess_images_u8
 from ..postprocessing import detector_postprocess, sem_seg_postprocess
@@ -80,7 +80,9 @@ class GeneralizedMCNNWSL(nn.Module):
         gt_instances = [x["instances"].to(self.device) for x in batched_inputs]
         gt_sem_seg = ImageList.from_tensors([x["sem_seg"].to(self.device) for x in batched_inputs],
                                             self.backbone.size_divisibility, self.sem_seg_head.ignore_value).tensor
+        set_segment("backbone")
         features = self.backbone(images.tensor)
+        set_segment("heads")
         superpixels = ImageList.from_tensors([x["superpixels"].to(self.device) for x in batched_inputs],
                                              self.backbone.size_divisibility)
         proposals = [x["proposals"].to(self.device) for x in batched_inputs]

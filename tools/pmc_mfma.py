@@ -20,8 +20,46 @@ from pmc_traffic import label
 SIMDS, XCDS = 1024, 8
 
 
+def by_segment(disp, dur, seq_path):
+    """Split the contraction dispatches by model segment.  `seq_path` (bench.py --launch-sequence): the contraction
+    launches of ONE step in order, each with its segment.  Every step of the profiled command launches the same
+    sequence, so for each kernel name the i-th dispatch of the pass is the (i mod n)-th launch of that name in the list."""
+    seq = json.load(open(seq_path))
+    per_name = collections.defaultdict(list)
+    for e in seq:
+        per_name[e["kernel"]].append(e["segment"] or "heads")
+    seen = collections.defaultdict(int)
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
+    unmatched = 0
+    for i in sorted(disp, key=lambda d: int(d)):
+        v = disp[i]
+        k = label(v["name"])
+        if not (k and k.startswith("igemm")):
+            continue
+        segs = per_name.get(k)
+        if not segs:
+            unmatched += 1
+            continue
+        seg = segs[seen[k] % len(segs)]
+        seen[k] += 1
+        a = agg[seg]
+        a[0] += 1
+        a[1] += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        a[2] += v.get("GRBM_GUI_ACTIVE", 0.0)
+        a[3] += dur.get(i, 0)
+    tn = sum(a[3] for a in agg.values()) or 1
+    out = {seg: {"launches_profiled": n, "mfma_util": round(busy / (SIMDS * gui / XCDS), 4) if gui else None,
+                 "clock_ghz": round(gui / XCDS / ns, 3) if ns else None, "share_of_contraction_time": round(ns / tn, 4)}
+           for seg, (n, busy, gui, ns) in sorted(agg.items())}
+    out["_unmatched_dispatches"] = unmatched
+    # a sanity check of the alignment: every kernel name's dispatch count must be a multiple of its per-step count
+    out["_aligned"] = all(seen[k] % len(per_name[k]) == 0 for k in seen)
+    return out
+
+
 def main():
     root, out = sys.argv[1], sys.argv[2]
+    seq_path = sys.argv[3] if len(sys.argv) > 3 else None
     cc = glob.glob(root + "/**/*counter_collection.csv", recursive=True)[0]
     kt = glob.glob(root + "/**/*kernel_trace.csv", recursive=True)[0]
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(kt))}
@@ -48,7 +86,10 @@ def main():
     tb, tg, tn = (sum(a[i] for a in agg.values()) for i in (1, 2, 3))
     for k, a in agg.items():
         kernels[k]["share_of_contraction_time"] = round(a[3] / tn, 4)
-    json.dump({"command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- "
+    segments = by_segment(disp, dur, seq_path) if seq_path else None
+    json.dump({"by_segment": segments, "by_segment_note": "backbone = ResNet stages (the north star's 'backbone convs'), fpn = lateral / "
+               "output convolutions, heads = box head, predictors, mask towers, semantic head; split through bench.py "
+               "--launch-sequence (tools/pmc_mfma.py: by_segment)", "command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- "
                           "python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-exact",
                "formula": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs); "
                           "clock = GRBM_GUI_ACTIVE / 8 / duration",
