@@ -54,9 +54,44 @@ __device__ __forceinline__ void moi_cell_bits_block(const int* __restrict__ supe
 #pragma clang fp contract(off)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int lpc = 64 / cpw, sub = lane / lpc, pl = lane - sub * lpc;      // lanes per cell, this lane's cell and slot
-  unsigned* rows = smem + wv * cpw * words;
   const long cell0 = (block * 4 + wv) * cpw, ncell = (long)B * H * W;
   const long cell = cell0 + sub;
+  if (cpw == 1 && words <= 64) {
+    // Coarse levels (a wavefront per cell, hundreds of pixels under it, a handful of distinct ids): the row lives in
+    // REGISTERS, lane = word.  64 pixels at a time; every distinct id among them is picked once (first live lane's id,
+    // the lanes that hold the same id drop out by a ballot) and the lane that owns its word sets the bit — no LDS row,
+    // no atomics (64 lanes OR-ing the same word serialise in the LDS atomic unit), no barrier.
+    if (cell >= ncell) return;          // (wave-uniform)
+    const int w = (int)(cell % W), h = (int)((cell / W) % H), b = (int)(cell / W / H);
+    const float s = (float)(1.0 * H / Hs);
+    const int hs = clampi((int)floorf((float)h / s), 0, Hs), he = clampi((int)ceilf((float)(h + 1) / s), 0, Hs);
+    const int ws = clampi((int)floorf((float)w / s), 0, Ws), we = clampi((int)ceilf((float)(w + 1) / s), 0, Ws);
+    const int bw = we - ws, npix = (he - hs) * bw;
+    const int* __restrict__ spp = superpixels + (size_t)b * Hs * Ws;
+    unsigned mine = 0u;
+    for (int p0 = 0; p0 < npix; p0 += 256) {
+      int id[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {       // four batches' loads in flight
+        const int p = p0 + u * 64 + lane;
+        const int q = min(p, npix - 1);
+        const int v = spp[(size_t)(hs + q / bw) * Ws + ws + q % bw];
+        id[u] = (p < npix && v >= 0 && v < L) ? v : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        unsigned long long todo = __ballot(id[u] >= 0);
+        while (todo) {
+          const int v = __builtin_amdgcn_readlane(id[u], (int)__builtin_ctzll(todo));
+          todo &= ~__ballot(id[u] == v);
+          if (lane == (v >> 5)) mine |= 1u << (v & 31);
+        }
+      }
+    }
+    if (lane < words) cell_bits[(size_t)cell * words + lane] = mine;
+    return;
+  }
+  unsigned* rows = smem + wv * cpw * words;
   for (int i = lane; i < cpw * words; i += 64) rows[i] = 0u;
   __syncthreads();
   if (cell < ncell) {
@@ -69,10 +104,18 @@ __device__ __forceinline__ void moi_cell_bits_block(const int* __restrict__ supe
     ws = clampi(ws, 0, Ws); we = clampi(we, 0, Ws);
     const int bw = we - ws, npix = (he - hs) * bw;
     const int* __restrict__ spp = superpixels + (size_t)b * Hs * Ws;
-    for (int p = pl; p < npix; p += lpc) {
-      const int hh = hs + p / bw, ww = ws + p % bw;
-      const int id = spp[(size_t)hh * Ws + ww];
-      if (id >= 0 && id < L) atomicOr(&row[id >> 5], 1u << (id & 31));
+    // (eight ids requested together, then their bits: left as one load per trip the coarse levels — 256 and 1024 pixels per
+    // cell — walked 4 and 16 dependent round trips per wavefront and were the launch's long pole)
+    for (int p0 = pl; p0 < npix; p0 += 8 * lpc) {
+      int id[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int p = min(p0 + u * lpc, npix - 1);          // (a repeated pixel sets the same bit again)
+        id[u] = spp[(size_t)(hs + p / bw) * Ws + ws + p % bw];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (id[u] >= 0 && id[u] < L) atomicOr(&row[id[u] >> 5], 1u << (id[u] & 31));
     }
   }
   __syncthreads();
@@ -80,12 +123,76 @@ __device__ __forceinline__ void moi_cell_bits_block(const int* __restrict__ supe
   for (long i = lane; i < live; i += 64) cell_bits[cell0 * words + i] = rows[i];
 }
 
+// Fine levels whose cells cover a few pixels (the superpixel map an exact multiple of the level: every BASELINE shape; at
+// most 8 x 8 pixels per cell): ONE THREAD PER CELL.  The thread reads its ph x pw ids (neighbouring lanes read neighbouring
+// 16-byte pieces of the same rows) and builds the row word by word in registers — no LDS row, no atomics, no barrier.
+// (The wavefront form above spent its time in two barriers and a dependent load per 16-cell workgroup: 8192 workgroups
+// for the stride-4 level.  A first attempt with the ids traded by shuffles inside a cell's lanes measured SLOWER than it:
+// 68 against 59 us for the bench's four levels — 32 bpermutes per word pair.)
+template <int KP>     // KP = pixels per cell side (a power of two: 1, 2, 4 or 8)
+__device__ __forceinline__ void moi_cell_bits_small(const int* __restrict__ superpixels, unsigned* __restrict__ cell_bits,
+                                                    int B, int H, int W, int Hs, int Ws, int L, int words, long block) {
+  const long cell = block * 256 + threadIdx.x, ncell = (long)B * H * W;
+  if (cell >= ncell) return;
+  const int w = (int)(cell % W), h = (int)((cell / W) % H), b = (int)(cell / W / H);
+  const int* __restrict__ src = superpixels + ((size_t)b * Hs + (size_t)h * KP) * Ws + (size_t)w * KP;
+  int id[KP * KP];
+  if (KP % 4 == 0 && (Ws & 3) == 0) {          // 16-byte pieces of the rows
+#pragma unroll
+    for (int r = 0; r < KP; ++r)
+#pragma unroll
+      for (int q = 0; q < KP / 4; ++q) {
+        const int4 t = *reinterpret_cast<const int4*>(src + (size_t)r * Ws + 4 * q);
+        id[KP * r + 4 * q] = t.x; id[KP * r + 4 * q + 1] = t.y; id[KP * r + 4 * q + 2] = t.z; id[KP * r + 4 * q + 3] = t.w;
+      }
+  } else {
+#pragma unroll
+    for (int p = 0; p < KP * KP; ++p) id[p] = src[(size_t)(p / KP) * Ws + p % KP];
+  }
+#pragma unroll
+  for (int p = 0; p < KP * KP; ++p) if (id[p] >= L) id[p] = -1;
+  unsigned* __restrict__ dst = cell_bits + (size_t)cell * words;
+  for (int w0 = 0; w0 < words; w0 += 4) {
+    unsigned v[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < KP * KP; ++p) {
+      const int wd = id[p] >> 5;                      // (-1 >> 5 == -1: never a word index)
+      const unsigned bit = 1u << (id[p] & 31);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] |= wd == w0 + k ? bit : 0u;
+    }
+    if (w0 + 4 <= words && (words & 3) == 0) {
+      *reinterpret_cast<uint4*>(dst + w0) = make_uint4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (w0 + k < words) dst[w0 + k] = v[k];
+    }
+  }
+}
+__device__ __forceinline__ void moi_cell_bits_small_any(const int* __restrict__ superpixels, unsigned* __restrict__ cell_bits,
+                                                        int B, int H, int W, int Hs, int Ws, int L, int words, long block) {
+  switch (Hs / H) {
+    case 1: return moi_cell_bits_small<1>(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, block);
+    case 2: return moi_cell_bits_small<2>(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, block);
+    case 4: return moi_cell_bits_small<4>(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, block);
+    default: return moi_cell_bits_small<8>(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, block);
+  }
+}
+// (the reference derives BOTH axes' pixel ranges from s = (float)H / Hs, floor(h / s) .. ceil((h + 1) / s),
+// MOIPool_cuda.cu:175-186: those are exactly [k h, k h + k) only for a power-of-two ratio k shared by both axes)
+static bool moi_bits_small_ok(int H, int W, int Hs, int Ws) {
+  if (H <= 0 || W <= 0 || Hs % H || Ws % W) return false;
+  const int k = Hs / H;
+  return k == Ws / W && (k & (k - 1)) == 0 && k <= 8;
+}
+
 __global__ __launch_bounds__(256) void moi_cell_bits_kernel(const int* __restrict__ superpixels,
                                                             unsigned* __restrict__ cell_bits,
                                                             int B, int H, int W, int Hs, int Ws,
                                                             int L, int words, int cpw) {
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
-  moi_cell_bits_block(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, cpw, (long)blockIdx.x, smem);
+  if (cpw == 0) moi_cell_bits_small_any(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, (long)blockIdx.x);
+  else moi_cell_bits_block(superpixels, cell_bits, B, H, W, Hs, Ws, L, words, cpw, (long)blockIdx.x, smem);
 }
 
 // cells that share a wavefront in moi_cell_bits_kernel: 64 / (pixels under a cell, rounded up to a power of two)
@@ -96,26 +203,31 @@ static int moi_cells_per_wave(int H, int W, int Hs, int Ws) {
   return cpw;
 }
 
-// roi_bits[n][words]: bit id set iff oh_labels[n,id] == 1 (exactly 1, MOIPool_cuda.cu:198).
+// roi_bits[n][words]: bit id set iff oh_labels[n,id] == 1 (exactly 1, MOIPool_cuda.cu:198).  A wavefront takes whole
+// rows: 64 consecutive labels per load (coalesced), one ballot = two words.  (A thread per word read its 32 labels one
+// after the other, the lanes of a load 128 bytes apart: 64 lines touched per wave-instruction.)
+constexpr int kRoiBitsRows = 8;      // rows per workgroup (two per wavefront)
 __device__ __forceinline__ void moi_roi_bits_block(const int* __restrict__ oh_labels, unsigned* __restrict__ roi_bits,
-                                                   long total_words, int L, int words, long block) {
-  const long idx = block * 256 + threadIdx.x;
-  if (idx >= total_words) return;
-  const long n = idx / words;
-  const int wd = (int)(idx - n * words);
-  const int* __restrict__ rowp = oh_labels + n * L;
-  unsigned bits = 0u;
-  const int base = wd * 32;
-#pragma unroll 4
-  for (int i = 0; i < 32; ++i)
-    if (base + i < L && rowp[base + i] == 1) bits |= 1u << i;
-  roi_bits[idx] = bits;
+                                                   long M, int L, int words, long block) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int r = wv; r < kRoiBitsRows; r += 4) {
+    const long n = block * kRoiBitsRows + r;
+    if (n >= M) return;
+    const int* __restrict__ rowp = oh_labels + n * L;
+    unsigned* __restrict__ dst = roi_bits + n * words;
+    for (int c0 = 0; c0 < L; c0 += 64) {
+      const int c = c0 + lane;
+      const unsigned long long m = __ballot(c < L && rowp[c] == 1);
+      const int wd = (c0 >> 5) + lane;                  // lanes 0 and 1 store the two words
+      if (lane < 2 && wd < words) dst[wd] = lane ? (unsigned)(m >> 32) : (unsigned)m;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void moi_roi_bits_kernel(const int* __restrict__ oh_labels,
                                                            unsigned* __restrict__ roi_bits,
-                                                           long total_words, int L, int words) {
-  moi_roi_bits_block(oh_labels, roi_bits, total_words, L, words, (long)blockIdx.x);
+                                                           long M, int L, int words) {
+  moi_roi_bits_block(oh_labels, roi_bits, M, L, words, (long)blockIdx.x);
 }
 
 // Both bit tables of a multi-level call in ONE launch (five launches of 10-15 us each before: four levels' cell bits
@@ -150,7 +262,14 @@ __device__ __forceinline__ void moi_sort_block(const MoiBitsPlan& plan, const fl
   };
   for (int i = t; i < nb; i += 256) hist[i] = 0u;
   __syncthreads();
-  for (int n = t; n < M; n += 256) atomicAdd(&hist[key_of(n)], 1u);
+  // (four rois' loads in flight per trip: one workgroup walks all M rois twice, a round trip per trip otherwise)
+  for (int n0 = t; n0 < M; n0 += 1024) {
+    int key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) key[u] = key_of(min(n0 + u * 256, M - 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (n0 + u * 256 < M) atomicAdd(&hist[key[u]], 1u);
+  }
   __syncthreads();
   // exclusive scan of the buckets: a thread sums its run, the runs are scanned by thread 0's wavefront serially per wave
   const int per = (nb + 255) / 256;
@@ -167,29 +286,43 @@ __device__ __forceinline__ void moi_sort_block(const MoiBitsPlan& plan, const fl
   unsigned base = run_sum[t];
   for (int i = t * per; i < min(nb, (t + 1) * per); ++i) { const unsigned v = hist[i]; hist[i] = base; base += v; }
   __syncthreads();
-  for (int n = t; n < M; n += 256) order[atomicAdd(&hist[key_of(n)], 1u)] = n;
+  for (int n0 = t; n0 < M; n0 += 1024) {
+    int key[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) key[u] = key_of(min(n0 + u * 256, M - 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (n0 + u * 256 < M) order[atomicAdd(&hist[key[u]], 1u)] = n0 + u * 256;
+  }
 }
 
 __global__ __launch_bounds__(256) void moi_bits_all_kernel(const MoiBitsPlan plan, const int* __restrict__ superpixels,
                                                            const int* __restrict__ oh_labels, unsigned* __restrict__ roi_bits,
-                                                           int B, int Hs, int Ws, int L, int words, long roi_words,
+                                                           int B, int Hs, int Ws, int L, int words, long roi_rows,
                                                            const float* __restrict__ rois, const int* __restrict__ roi_level,
-                                                           int M, int* __restrict__ order) {
+                                                           int M, int* __restrict__ order, int skip) {
   extern __shared__ __attribute__((aligned(16))) unsigned smem[];
   const int blk = blockIdx.x;
+  if (skip) {   // (timing aid, tools/sweeps: leave parts of the launch out — results are then wrong)
+    if (blk >= plan.first[plan.n] && blk != plan.sort_block && (skip & 16)) return;
+    for (int l = 0; l < plan.n; ++l)
+      if ((skip >> l & 1) && blk >= plan.first[l] && blk < plan.first[l + 1]) return;
+  }
   if (blk == plan.sort_block) {
     __shared__ unsigned sort_hist[kSortBuckets];
     moi_sort_block(plan, rois, roi_level, M, B, order, sort_hist);
     return;
   }
   if (blk >= plan.first[plan.n]) {
-    moi_roi_bits_block(oh_labels, roi_bits, roi_words, L, words, (long)(blk - plan.first[plan.n]));
+    moi_roi_bits_block(oh_labels, roi_bits, roi_rows, L, words, (long)(blk - plan.first[plan.n]));
     return;
   }
   int l = 0;
   while (l + 1 < plan.n && blk >= plan.first[l + 1]) ++l;
-  moi_cell_bits_block(superpixels, plan.cell[l], B, plan.H[l], plan.W[l], Hs, Ws, L, words, plan.cpw[l],
-                      (long)(blk - plan.first[l]), smem);
+  if (plan.cpw[l] == 0)     // (one thread per cell: moi_cell_bits_small)
+    moi_cell_bits_small_any(superpixels, plan.cell[l], B, plan.H[l], plan.W[l], Hs, Ws, L, words, (long)(blk - plan.first[l]));
+  else
+    moi_cell_bits_block(superpixels, plan.cell[l], B, plan.H[l], plan.W[l], Hs, Ws, L, words, plan.cpw[l],
+                        (long)(blk - plan.first[l]), smem);
 }
 
 struct BinRange { int hs, he, ws, we; };
@@ -557,6 +690,10 @@ __global__ __launch_bounds__(64 * NW) void moi_pool_fwd_rows(
 // the chip delivers to every CU at once) — and 352 with the bit tables in one launch.
 static int moi_fwd_rows_mode() {
   static const int v = [] { const char* e = getenv("JTSM_MOI_FWD_ROWS"); return e ? atoi(e) : 1; }();
+  return v;
+}
+static int moi_bits_skip() {
+  static const int v = [] { const char* e = getenv("JTSM_MOI_BITS_SKIP"); return e ? atoi(e) : 0; }();
   return v;
 }
 static bool moi_sort_on() {
@@ -1078,14 +1215,14 @@ int build_bits(const int* oh_labels, const int* superpixels, const Workspace& k,
                int W, int M, int L, int Hs, int Ws, hipStream_t st) {
   const int words = bit_words(L);
   const long cells = (long)B * H * W;
-  const int cpw = moi_cells_per_wave(H, W, Hs, Ws);
-  hipLaunchKernelGGL(moi_cell_bits_kernel, dim3(ceil_div(cells, 4 * cpw)), dim3(256),
+  const bool small = moi_bits_small_ok(H, W, Hs, Ws);
+  const int cpw = small ? 0 : moi_cells_per_wave(H, W, Hs, Ws);
+  hipLaunchKernelGGL(moi_cell_bits_kernel, dim3(small ? ceil_div(cells, 256) : ceil_div(cells, 4 * cpw)), dim3(256),
                      4 * cpw * words * sizeof(unsigned), st, superpixels, k.cell, B, H, W, Hs, Ws, L,
                      words, cpw);
   JTSM_CHECK_LAUNCH("moi_cell_bits");
-  const long tw = (long)M * words;
-  hipLaunchKernelGGL(moi_roi_bits_kernel, dim3(ceil_div(tw, 256)), dim3(256), 0, st, oh_labels,
-                     k.roi, tw, L, words);
+  hipLaunchKernelGGL(moi_roi_bits_kernel, dim3(ceil_div((long)M, kRoiBitsRows)), dim3(256), 0, st, oh_labels,
+                     k.roi, (long)M, L, words);
   JTSM_CHECK_LAUNCH("moi_roi_bits");
   return JTSM_OK;
 }
@@ -1261,14 +1398,15 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
     lv.cell[l] = cell;
     w += (((size_t)B * H[l] * W[l] * words * sizeof(unsigned)) + 15) & ~(size_t)15;
     const long cells = (long)B * H[l] * W[l];
-    const int cpw = moi_cells_per_wave(H[l], W[l], Hs, Ws);
+    const bool small = moi_bits_small_ok(H[l], W[l], Hs, Ws);
+    const int cpw = small ? 0 : moi_cells_per_wave(H[l], W[l], Hs, Ws);
     bp.cell[l] = cell; bp.H[l] = H[l]; bp.W[l] = W[l]; bp.cpw[l] = cpw; bp.first[l] = nblk;
-    nblk += (int)ceil_div(cells, 4 * cpw);
+    nblk += (int)(small ? ceil_div(cells, 256) : ceil_div(cells, 4 * cpw));
     max_cpw = std::max(max_cpw, cpw);
   }
   bp.n = nlevels;
   bp.first[nlevels] = nblk;
-  nblk += (int)ceil_div((long)M * words, 256);
+  nblk += (int)ceil_div((long)M, kRoiBitsRows);
   bool rows_ok = moi_fwd_rows_mode() != 0 && pooled_w == 7 && moi_fwd_rows_words_ok(words) && ((uintptr_t)output & 15) == 0 &&
                  ((uintptr_t)argmax & 15) == 0;
   for (int l = 0; l < nlevels; ++l) rows_ok = rows_ok && H[l] < 65536 && W[l] < 65536;
@@ -1286,7 +1424,7 @@ int jtsm_moi_pool_forward_levels_f32(const float* const* inputs, const int* H, c
     }
   }
   hipLaunchKernelGGL(moi_bits_all_kernel, dim3(nblk), dim3(256), 4 * max_cpw * words * sizeof(unsigned), st, bp, superpixels,
-                     oh_labels, roi_bits, B, Hs, Ws, L, words, (long)M * words, rois, roi_level, M, order);
+                     oh_labels, roi_bits, B, Hs, Ws, L, words, (long)M, rois, roi_level, M, order, moi_bits_skip());
   if (rows_ok) {
     launch_fwd_rows(lv, rois, roi_bits, output, argmax, C, M, words, pooled_h, roi_level, nlevels, -1, order, st);
   } else {

@@ -31,7 +31,10 @@ def by_segment(disp, dur, seq_path):
     seen = collections.defaultdict(int)
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])
     unmatched = 0
-    for i in sorted(disp, key=lambda d: int(d)):
+    # aligned from the END of the pass: the listed step is the process's last one, so the last n dispatches of a name ARE
+    # its n launches of the list; earlier steps repeat them (a first step that launches something once only — plan
+    # building, a different foreground count — cannot shift the later ones)
+    for i in sorted(disp, key=lambda d: -int(d)):
         v = disp[i]
         k = label(v["name"])
         if not (k and k.startswith("igemm")):
@@ -40,7 +43,7 @@ def by_segment(disp, dur, seq_path):
         if not segs:
             unmatched += 1
             continue
-        seg = segs[seen[k] % len(segs)]
+        seg = segs[len(segs) - 1 - seen[k] % len(segs)]
         seen[k] += 1
         a = agg[seg]
         a[0] += 1
