@@ -369,10 +369,14 @@ _SCRATCH = {}
 def _scratch(nbytes, device):
     if nbytes == 0:
         return None
-    buf = _SCRATCH.get(device)
+    key = (device, "side") if _ON_SIDE_STREAM[0] else device     # (the weight-gradient side stream has its own slabs)
+    buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = _SCRATCH[device] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        buf = _SCRATCH[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
     return buf
+
+
+_ON_SIDE_STREAM = [False]
 
 
 def _x3_variant(s, role):
@@ -1048,7 +1052,7 @@ def planes_backward_weight_deferred(g, x, w, stride=1, pad=0, dil=1, row_scale=N
         # sticky flag — a flag left set by an aborted backward would never queue a callback again; a second callback in
         # one backward (after a stage's own flush emptied the queue) finds nothing to do
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(flush_deferred_weight_gradients)
+            torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
         except RuntimeError:     # not inside a backward pass: nothing would flush the queue
             return planes_backward_weight(g, x, w, stride, pad, dil, row_scale=row_scale)
     _DEFERRED.append((g, x, w, stride, pad, dil, row_scale))
@@ -1076,10 +1080,54 @@ def _deliver_grad(w, dw):
             hook(w)
 
 
+# The queued weight gradients on a SIDE stream (JTSM_WGRAD_STREAM=0: off): nothing in the backward waits for them, so a
+# stage's grouped launches can run beside the next stage's (short, latency-bound) data gradients instead of in front of
+# them.  Only without post-accumulate hooks on the parameters (the data-parallel exchange orders its collectives on the
+# compute stream); the end of the backward pass makes the compute stream wait for the side stream.  Same-process A/B
+# (tools/sweeps/wgrad_stream_ab.py, 4 x 25 steps each way): 21.74-22.10 -> 21.54-21.64 ms per step.  (Round 1 measured a
+# weight gradient beside ITS OWN layer's data gradient as no gain — two large kernels competing for operand delivery;
+# here a stage's grouped gradients run beside the next stage's short layers, which leave the matrix pipes idle.)
+WGRAD_STREAM = os.environ.get("JTSM_WGRAD_STREAM", "1") != "0"
+_WGRAD_SIDE = {}
+
+
+def _wgrad_side_stream(device):
+    st = _WGRAD_SIDE.get(device)
+    if st is None:
+        st = _WGRAD_SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_wgrad_stream():
+    """The compute stream waits for the weight gradients launched on the side stream (end of the backward pass)."""
+    for device, st in _WGRAD_SIDE.items():
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
+def _final_flush():
+    flush_deferred_weight_gradients()
+    join_wgrad_stream()
+
+
 @torch.no_grad()
 def flush_deferred_weight_gradients():
     global _DEFERRED
     if not _DEFERRED:
+        return
+    if WGRAD_STREAM and not _ON_SIDE_STREAM[0] and _DEFERRED[0][1].buf.is_cuda and \
+            not any(getattr(it[2], "_post_accumulate_grad_hooks", None) for it in _DEFERRED):
+        device = _DEFERRED[0][1].buf.device
+        side = _wgrad_side_stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        for g, x, *_ in _DEFERRED:        # operand planes were allocated on the compute stream: keep them until the side stream is done
+            g.buf.record_stream(side)
+            x.buf.record_stream(side)
+        _ON_SIDE_STREAM[0] = True
+        try:
+            with torch.cuda.stream(side):
+                flush_deferred_weight_gradients()
+        finally:
+            _ON_SIDE_STREAM[0] = False
         return
     items, _DEFERRED = _DEFERRED, []
     groups = {}

@@ -861,6 +861,19 @@ def test_deferred_weight_gradients_are_grouped_and_match_the_single_launches(cud
         for a, b, c in zip(g0, g1, g2):
             assert torch.equal(b, c)                                            # reproducible
             assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), float((a - b).abs().max())
+        # the queued launches on the side stream (layers/conv.py: WGRAD_STREAM): the same kernels on the same operands
+        # beside the backward instead of inside it — the same bits, and the compute stream has waited for them when
+        # backward() returns (the gradients are read here without any synchronisation of ours)
+        old_side = K.WGRAD_STREAM
+        K.WGRAD_STREAM = True
+        try:
+            dx3, g3, _ = run(True)
+            dx4, g4, _ = run(True)
+        finally:
+            K.WGRAD_STREAM = old_side
+        assert torch.equal(dx3, dx1) and torch.equal(dx4, dx1)
+        for b, c, d in zip(g1, g3, g4):
+            assert torch.equal(b, c) and torch.equal(b, d)
         # accumulation into an existing .grad (no zero_grad between two backward passes): the sum of both
         K.defer_weight_gradients(True)
         x = x0.clone().requires_grad_()
