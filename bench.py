@@ -303,6 +303,15 @@ def roofline_leg(step_fn):
         r = describe(name, d)
         r["traffic"] = traffic_of(name)
         rooflines.append(r)
+    # the region-pooling entry points, whatever their share (VERDICT r3 item 1 watches them; each is a few launches —
+    # bit tables / census / plan + the pooling kernel(s) — timed as one call, traffic: the entry's dominant kernel)
+    detail["pooling_entry_points"] = []
+    for name in ("jtsm_moi_pool_forward_levels_f32", "jtsm_moi_pool_backward_levels_f32",
+                 "jtsm_roi_align_backward_levels_f32", "jtsm_roi_align_forward_level_f32"):
+        if name in per and per[name]["ms"] > 0:
+            r = describe(name, per[name])
+            r["traffic"] = traffic_of(name)
+            detail["pooling_entry_points"].append(r)
     contr = {k: v for k, v in per.items() if v["bound"] == "mfma"}
     c_ms = sum(v["ms"] for v in contr.values())
     c_fl = sum(v["flops"] for v in contr.values())

@@ -21,7 +21,7 @@ ROLE = {"0": "FWD", "1": "DGRAD", "2": "WGRAD"}
 
 # non-contraction kernels that bench.py reports under their C-ABI entry point (the entry's dominant kernel)
 ENTRY = (("splitk_finish<4", "splitk_finish<4>"),   # <4, 1> and <4, 16> (threads per piece) book as one
-         ("moi_pool_fwd_levels", "jtsm_moi_pool_forward_levels_f32"),
+         ("moi_pool_fwd_levels", "jtsm_moi_pool_forward_levels_f32"), ("moi_pool_fwd_rows", "jtsm_moi_pool_forward_levels_f32"),
          ("moi_pool_bwd_tiled", "jtsm_moi_pool_backward_levels_f32"), ("align_bwd_gather", "jtsm_roi_align_backward_levels_f32"),
          ("relu_bwd_split_kernel", "jtsm_relu_backward_split_f32"), ("channel_sum4_kernel", "jtsm_channel_sum_ws_f32"),
          ("split_bf16_kernel", "jtsm_split_bf16_f32"), ("sgd_multi_kernel", "jtsm_sgd_momentum_multi_f32"),
