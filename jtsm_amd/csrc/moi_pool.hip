@@ -597,12 +597,17 @@ __global__ __launch_bounds__(64 * NW) void moi_pool_fwd_rows(
         const int w = cx0 + (kb << 6) + lane;
         const uint4* __restrict__ crow =
             reinterpret_cast<const uint4*>(cplane + ((size_t)hrow * W + min(w, cx1 - 1)) * words);
-        uint4 cw[W4];
-#pragma unroll
-        for (int i = 0; i < W4; ++i) cw[i] = crow[i];
+        constexpr int CH = W4 < 8 ? W4 : 8;      // 16-byte loads in flight per lane (wider label sets: several rounds)
         unsigned acc = 0u;
 #pragma unroll
-        for (int i = 0; i < W4; ++i) acc |= (cw[i].x & rq[i].x) | (cw[i].y & rq[i].y) | (cw[i].z & rq[i].z) | (cw[i].w & rq[i].w);
+        for (int c0 = 0; c0 < W4; c0 += CH) {
+          uint4 cw[CH];
+#pragma unroll
+          for (int i = 0; i < CH; ++i) cw[i] = crow[c0 + i];
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            acc |= (cw[i].x & rq[c0 + i].x) | (cw[i].y & rq[c0 + i].y) | (cw[i].z & rq[c0 + i].z) | (cw[i].w & rq[c0 + i].w);
+        }
         acc = w < cx1 ? acc : 0u;
         const unsigned long long m = __ballot(acc != 0u);
         if (acc != 0u) list[count + __popcll(m & below)] = ((unsigned)hrow << 16) | (unsigned)w;
@@ -715,14 +720,15 @@ template <int AHEAD>
 static void launch_fwd_rows_as(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax,
                                int C, int M, int words, int PH, const int* roi_level, int nlevels, int only_level,
                                const int* order, hipStream_t st) {
-  switch (words) {      // (moi_fwd_rows_words_ok: 4, 8, 16 or 32 words = up to 128 / 256 / 512 / 1024 superpixel ids)
+  switch (words) {      // (moi_fwd_rows_words_ok: 4, 8, 16, 32 or 64 words = up to 128 ... 2048 superpixel ids)
     case 4: return launch_fwd_rows_w<AHEAD, 1>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
     case 8: return launch_fwd_rows_w<AHEAD, 2>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
     case 16: return launch_fwd_rows_w<AHEAD, 4>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
+    case 64: return launch_fwd_rows_w<AHEAD, 16>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
     default: return launch_fwd_rows_w<AHEAD, 8>(lv, rois, roi_bits, out, argmax, C, M, words, PH, roi_level, nlevels, only_level, order, st);
   }
 }
-static bool moi_fwd_rows_words_ok(int words) { return words == 4 || words == 8 || words == 16 || words == 32; }
+static bool moi_fwd_rows_words_ok(int words) { return words == 4 || words == 8 || words == 16 || words == 32 || words == 64; }
 static void launch_fwd_rows(const MoiLevels& lv, const float* rois, const unsigned* roi_bits, float* out, int* argmax, int C,
                             int M, int words, int PH, const int* roi_level, int nlevels, int only_level, const int* order,
                             hipStream_t st) {

@@ -369,7 +369,9 @@ _SCRATCH = {}
 def _scratch(nbytes, device):
     if nbytes == 0:
         return None
-    key = (device, "side") if _ON_SIDE_STREAM[0] else device     # (the weight-gradient side stream has its own slabs)
+    # (one buffer per STREAM: launches of one stream run in order, and a side stream — the queued weight gradients, the
+    # semantic head — must not fold its slabs through the buffer the compute stream's contractions are using)
+    key = (device, L.stream().value)
     buf = _SCRATCH.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = _SCRATCH[key] = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)

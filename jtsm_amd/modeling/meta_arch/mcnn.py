@@ -26,6 +26,20 @@ from .panoptic_fpn import combine_semantic_and_instance_outputs
 # The semantic head's forward enqueued inside the mask branch's synchronisation window (roi_heads_jtsm.py: sync_window):
 # JTSM_SEM_IN_SYNC_WINDOW=0 restores the order of the reference's forward (heads one after the other).
 SEM_IN_SYNC_WINDOW = os.environ.get("JTSM_SEM_IN_SYNC_WINDOW", "1") != "0"
+# The semantic head on a side stream (JTSM_SEM_SIDE_STREAM=1) — EXPERIMENTAL, OFF: its layers start as soon as the pyramid
+# exists and run beside the box / mask branches; autograd runs a node's backward on the stream its forward ran on, so the
+# head's backward runs beside theirs too.  Its GroupNorm / up-sampling / cross-entropy kernels are bound by HBM and vector
+# issue, the branches' large contractions by the matrix pipes: same-process A/B 22.8 -> 21.7 ms per step
+# (tools/sweeps/sem_side_ab.py).  NOT shipped: with the head on its own stream the step is no longer reproducible — in about
+# one forward in four a kernel of the side stream (the bilinear up-sampling behind a GroupNorm, found with
+# tools/sweeps/sem_side_check2.py) read its input before the kernel in front of it ON THE SAME STREAM had finished writing
+# it (11 500 of 16.7 M elements wrong; input and output unchanged afterwards).  The effect disappears with a host
+# synchronisation in front of the fork, with the compute stream waiting right behind the head, and with
+# GPU_MAX_HW_QUEUES=1 (tools/sweeps/stream_soak.py: 19 of 19 runs differ / 0 of 19); no unordered access of this
+# package's own was found (per-stream split-K scratch, no shared workspaces, no fan records across streams).  The two
+# side streams that ARE shipped — the queued weight gradients (layers/conv.py) and the MOIPool backward's second gather —
+# pass the same soak bit for bit (0 of 24).
+SEM_SIDE_STREAM = os.environ.get("JTSM_SEM_SIDE_STREAM", "0") != "0"
 
 
 @META_ARCH_REGISTRY.register()
@@ -89,9 +103,25 @@ class GeneralizedMCNNWSL(nn.Module):
         # every FPN level has three readers (box pooler, mask pooler, semantic head): each gets its own view, through
         # which their backward kernels add into ONE gradient map per level instead of autograd adding three
         # (layers/grad_fan.py); without it, or for a head that does not take part, the views behave like `features`
-        fans = {k: fan_out(v, 3) for k, v in features.items()}
-        f_box, f_mask, f_sem = ({k: v[i] for k, v in fans.items()} for i in range(3))
-        in_window = SEM_IN_SYNC_WINDOW and getattr(self.roi_heads, "mask_on", False) and \
+        use_side = SEM_SIDE_STREAM and images.tensor.is_cuda and hasattr(self.sem_seg_head, "layers") and \
+            not (torch.distributed.is_available() and torch.distributed.is_initialized() and
+                 torch.distributed.get_world_size() > 1)      # (the gradient exchange orders its collectives on ONE stream)
+        fans = {k: fan_out(v, 2 if use_side else 3) for k, v in features.items()}
+        f_box, f_mask = ({k: v[i] for k, v in fans.items()} for i in range(2))
+        f_sem = None if use_side else {k: v[2] for k, v in fans.items()}
+        side = None
+        if use_side:
+            side = getattr(self, "_sem_stream", None)
+            if side is None:
+                side = self._sem_stream = torch.cuda.Stream(device=images.tensor.device)
+            main = torch.cuda.current_stream(images.tensor.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                # (the pyramid itself, not the fan views: the shared gradient maps of layers/grad_fan.py are added into in
+                # place by the compute stream's nodes, which a node on another stream must not join — autograd's own
+                # accumulation orders the two streams)
+                sem_pred = self.sem_seg_head.layers(features)
+        in_window = side is None and SEM_IN_SYNC_WINDOW and getattr(self.roi_heads, "mask_on", False) and \
             getattr(self.roi_heads, "takes_mask_features", False)
         if in_window:   # the semantic head's forward fills the wait for the mask branch's foreground count
             self.roi_heads.sync_window = lambda: self.sem_seg_head(f_sem, self.roi_heads.pgt_sem_seg)
@@ -100,7 +130,13 @@ class GeneralizedMCNNWSL(nn.Module):
                                                 mask_features=f_mask)
         else:
             _, detector_losses = self.roi_heads(images, f_box, proposals, gt_instances, gt_sem_seg, superpixels)
-        if in_window:
+        if side is not None:
+            main = torch.cuda.current_stream(images.tensor.device)
+            side.wait_stream(main)                    # the pseudo semantic target is painted on the compute stream
+            with torch.cuda.stream(side):
+                sem_seg_losses = self.sem_seg_head.losses(sem_pred, self.roi_heads.pgt_sem_seg)
+            main.wait_stream(side)                    # the caller sums the losses on the compute stream
+        elif in_window:
             self.roi_heads.sync_window = None
             _, sem_seg_losses = self.roi_heads.sync_window_result
             self.roi_heads.sync_window_result = None

@@ -352,6 +352,42 @@ def test_multilevel_roi_align_rotated_pooler_matches_oracle_and_v2_at_zero_degre
         assert np.allclose(a, b, atol=1e-4 * max(1.0, np.abs(a).max()))
 
 
+@pytest.mark.parametrize("sp,size", [(8, 256), (16, 256), (4, 128), (32, 256), (12, 240), (8, 360), (32, 352)])
+def test_multilevel_moi_pool_forward_label_widths_and_bit_table_forms(cuda, sp, size):
+    """The multi-level MOIPool forward over the label-set widths the per-(roi, bin row) kernel is instantiated for
+    (ceil(L / 32) = 4, 8, 16, 32, 64 words; other widths take the per-(roi, bin) kernel) and over the three ways the cell
+    bit tables are built (thread per cell at power-of-two superpixel ratios <= 8, register rows per wavefront on coarse
+    levels, the LDS form when the map is not a power-of-two multiple of the level — size 240 with 12-px blocks): values
+    and arg-max bit-exact against the oracle, level by level."""
+    from jtsm_amd.modeling.poolers import ROIPooler
+    from jtsm_amd.structures import Boxes
+    from oracle import model as OM
+
+    rng = np.random.default_rng(sp * 1000 + size)
+    B, Cc, M = 2, 64, 160
+    r = _fpn_like_rois(rng, M, B, size)
+    r[:, 1:] *= 1.0                                   # boxes in the size x size image
+    boxes = [torch.from_numpy(r[r[:, 0] == b][:, 1:]) for b in range(B)]
+    grid = size // sp
+    ids = (torch.arange(size)[:, None] // sp) * grid + (torch.arange(size)[None, :] // sp)
+    superpixels = ids.to(torch.int32)[None].repeat(B, 1, 1)
+    cy = torch.arange(grid) * sp + sp / 2.0
+    oh = []
+    for bx in boxes:
+        iny = (cy[None, :] >= bx[:, 1:2]) & (cy[None, :] <= bx[:, 3:4])
+        inx = (cy[None, :] >= bx[:, 0:1]) & (cy[None, :] <= bx[:, 2:3])
+        oh.append((iny[:, :, None] & inx[:, None, :]).reshape(len(bx), -1).to(torch.int32))
+    feats = [rng.standard_normal((B, Cc, (size // 4) >> i, (size // 4) >> i)).astype(np.float32) for i in range(4)]
+    scales = [1 / 4, 1 / 8, 1 / 16, 1 / 32]
+    pooler = ROIPooler(7, scales, 0, "MOIPool")
+    y, arg = pooler([dev(f, cuda, True) for f in feats], [Boxes(b.to(cuda)) for b in boxes],
+                    oh_labels_list=[o.to(cuda) for o in oh], superpixels=superpixels.to(cuda))
+    y0, a0 = OM.moi_pool_levels([torch.from_numpy(f) for f in feats], boxes, oh, superpixels)
+    assert np.array_equal(arg.cpu().numpy(), a0.numpy())
+    assert np.array_equal(y.cpu().numpy(), y0.numpy())
+    assert float((a0 >= 0).float().mean()) > 0.05
+
+
 def test_multilevel_moi_pool_backward_gather_matches_oracle_and_scatter(cuda):
     """The gather form of the multi-level MOIPool backward (one workgroup per 8x8-cell tile, LDS accumulation in
     roi / bin order; 256-channel maps) against (1) the oracle's per-level scatter, (2) the library's own atomic

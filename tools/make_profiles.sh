@@ -15,12 +15,14 @@ FAST="--no-cpu-baseline --no-roofline --no-exact --no-config4"
 PMCF="--no-cpu-baseline --no-roofline --no-exact"   # (with the configs[4] fp16 leg: its kernels' traffic rows)
 case "$1" in
 pmc)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $PMCF > $A/pmc_fetch.log 2>&1 &&
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $PMCF > $A/pmc_write.log 2>&1 &&
-python tools/pmc_traffic.py $A/pmc profiles/pmc_traffic.json && cp profiles/pmc_traffic.json $A/pmc_traffic.json &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST > $A/pmc_write.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $A/pmc4/fetch -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $PMCF > $A/pmc4_fetch.log 2>&1 &&
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $A/pmc4/write -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $PMCF > $A/pmc4_write.log 2>&1 &&
+python tools/pmc_traffic.py $A/pmc profiles/pmc_traffic.json $A/pmc4 && cp profiles/pmc_traffic.json $A/pmc_traffic.json &&
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $A/pmc/mfma -o p --output-format csv -- python bench.py --steps 2 --warmup 1 $FAST --launch-sequence $A/launch_sequence.json > $A/pmc_mfma.log 2>&1 &&
 (cd tools && python pmc_mfma.py ../$A/pmc/mfma ../profiles/pmc_mfma.json ../$A/launch_sequence.json) && cp profiles/pmc_mfma.json $A/pmc_mfma.json
-rm -rf $A/pmc/fetch $A/pmc/write $A/pmc/mfma   # (the raw per-dispatch tables are tens of MB; the two JSON files are what is kept)
+rm -rf $A/pmc/fetch $A/pmc/write $A/pmc/mfma $A/pmc4   # (the raw per-dispatch tables are tens of MB; the two JSON files are what is kept)
 ;;
 prof)
 rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 > $A/prof_bench.json 2> $A/prof.log &&

@@ -87,9 +87,22 @@ def per_kernel(directory, counter):
     return agg
 
 
+def is_fp16(k):
+    """Labels of the fp16 instantiations (the configs[4] leg): NP = 1 as the last template argument."""
+    return k.endswith(",1>") or k.endswith("<1>")
+
+
 def main():
+    """pmc_traffic.py ROOT OUT [ROOT4]: ROOT = passes of the headline step alone; ROOT4 (optional) = passes of a run
+    that includes the configs[4] leg, from which ONLY the fp16 kernels' rows are taken — entry points without a
+    template argument to tell the legs apart (the pooling calls: other maps, other label widths) would otherwise be
+    averaged over both."""
     root, out = sys.argv[1], sys.argv[2]
     fetch, write = per_kernel(root + "/fetch", "FETCH_SIZE"), per_kernel(root + "/write", "WRITE_SIZE")
+    if len(sys.argv) > 3:
+        f4, w4 = per_kernel(sys.argv[3] + "/fetch", "FETCH_SIZE"), per_kernel(sys.argv[3] + "/write", "WRITE_SIZE")
+        fetch.update({k: v for k, v in f4.items() if is_fp16(k)})
+        write.update({k: v for k, v in w4.items() if is_fp16(k)})
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
         nf, f = fetch.get(k, [0, 0.0])
@@ -106,7 +119,7 @@ def main():
                     "is fabric-side traffic, an upper bound on HBM bytes",
         }
     json.dump({"command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python bench.py --steps 2 --warmup 1 "
-                          "--no-cpu-baseline --no-roofline --no-exact (the configs[4] fp16 leg included: its kernels carry the \",1\" labels)", "kernels": kernels}, open(out, "w"), indent=1)
+                          "--no-cpu-baseline --no-roofline --no-exact --no-config4 (the fp16 kernels' rows — \",1\" labels — from a second pair of passes that includes the configs[4] leg)", "kernels": kernels}, open(out, "w"), indent=1)
     print("wrote", out, len(kernels), "kernels")
 
 
