@@ -35,13 +35,13 @@ bench)
 python bench.py --steps 20 --warmup 5 > $A/bench.json 2> $A/bench.err && cp gpurun_out/bench_detail.json $A/bench_detail.json
 ;;
 side)
-python tools/stock_baseline.py --cluster 0 > $A/stock_uniform.json 2> $A/stock_uniform.err &&
+python tools/stock_baseline.py --cluster 0 --warmup 25 > $A/stock_uniform.json 2> $A/stock_uniform.err &&
 rocprofv3 --kernel-trace --stats -d $A/infprof -o r --output-format csv -- python tools/bench_inference.py --steps 10 --warmup 3 > $A/infprof_bench.json 2> $A/infprof.log &&
 cp $A/infprof/r_kernel_stats.csv $A/inference_kernel_stats.csv && rm -rf $A/infprof &&
 python tools/bench_inference.py --steps 20 --warmup 5 --cpu-baseline > $A/inference.json 2> $A/inference.err &&
 python tools/bench_input_pipeline.py > $A/input_pipeline.json 2> $A/input_pipeline.err &&
 python tools/bench_config1.py > $A/config1.json 2> $A/config1.err &&
-python tools/stock_baseline.py > $A/stock.json 2> $A/stock.err
+python tools/stock_baseline.py --warmup 25 > $A/stock.json 2> $A/stock.err
 ;;
 *) echo "usage: make_profiles.sh pmc|prof|bench|side"; exit 2;;
 esac
