@@ -1107,8 +1107,51 @@ def join_wgrad_stream():
 
 
 def _final_flush():
+    _JOIN_QUEUED[0] = False
     flush_deferred_weight_gradients()
     join_wgrad_stream()
+
+
+_JOIN_QUEUED = [False]     # an end-of-backward join is queued for this backward pass (reset with the plane cache too)
+CLEAR_HOOKS.append(lambda: _JOIN_QUEUED.__setitem__(0, False))
+
+
+def side_weight_gradients(params, compute, operands=()):
+    """Weight (and bias) gradients that nothing in the backward waits for, computed NOW but on the weight-gradient side
+    stream: `compute()` launches the contraction(s) and returns one gradient per entry of `params` (leaf parameters; a
+    None entry is skipped); the gradients are delivered here as AccumulateGrad would (the caller returns None to autograd
+    for them).  `operands`: buffers the launches read that may be freed before the side stream is done.  False: not
+    applicable (switched off, a parameter that is a view / carries hooks / needs no gradient, no backward in progress) —
+    the caller computes the gradients the ordinary way."""
+    live = [p for p in params if p is not None]
+    if not (WGRAD_STREAM and DEFER_WGRAD and MATH != "f32" and live and live[0].is_cuda):
+        return False
+    for p in live:
+        if not (p.is_leaf and p.requires_grad and p._base is None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    if not _JOIN_QUEUED[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
+        except RuntimeError:
+            return False
+        _JOIN_QUEUED[0] = True
+    device = live[0].device
+    side = _wgrad_side_stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    for b in operands:
+        if b is not None:
+            b.record_stream(side)
+    with torch.no_grad(), torch.cuda.stream(side):
+        grads = compute()
+        for p, g in zip(params, grads):
+            if p is None or g is None:
+                continue
+            g = g.view(p.shape) if g.shape != p.shape else g
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad.add_(g)
+    return True
 
 
 @torch.no_grad()
@@ -1377,6 +1420,7 @@ class _ConvFused(Function):
     def forward(ctx, x, w, scale, bias, residual, stride, pad, dil, relu, bias_needs_grad, emit_planes=True,
                 emit_dx_planes=False, fan=None):
         ctx.segment = SEGMENT
+        ctx.bias_param = bias if bias_needs_grad else None
         y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
         ctx.fan = fan   # (layers/grad_fan.py: conv2d_fused claimed the input's fan view, if it is one)
         ctx.emit_dx_planes = emit_dx_planes   # the input's gradient is the dy of another contraction (FPN laterals)
@@ -1418,9 +1462,19 @@ class _ConvFused(Function):
                 dx = None      # (in the fan's record: autograd gets it from the fan node)
         want_db = bias_needs_grad and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[1]:
-            if want_db:   # the bias gradient rides in the weight-gradient contraction
-                db = torch.empty(ws[0], dtype=g.dtype, device=g.device)
-            dw = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale, w=w, bias_out=db)
+            def run():
+                db_ = torch.empty(ws[0], dtype=g.dtype, device=g.device) if want_db else None   # (rides in the contraction)
+                dw_ = conv2d_backward_weight(g, x, ws, stride, pad, dil, row_scale=scale, w=w, bias_out=db_)
+                if dw_.stride() != w.stride() and w.shape[2] == 1 and w.shape[3] == 1:
+                    dw_ = dw_.as_strided(w.shape, w.stride())
+                return dw_, db_
+            # beside the rest of the backward on the weight-gradient side stream when the parameters are plain leaves
+            # (the operands' planes live in the step's plane cache; g and x themselves may be freed behind this node)
+            if x3 and _plan(x.shape, ws, stride, pad, dil).x3[2] and \
+                    side_weight_gradients([w, ctx.bias_param if want_db else None], run, (g, x)):
+                dw = db = None
+            else:
+                dw, db = run()
         elif want_db:
             db = channel_sum(g)
         if dw is not None and dw.stride() != w.stride() and w.shape[2] == 1 and w.shape[3] == 1:

@@ -577,7 +577,14 @@ class _FcStackFn(Function):
                 gp, summed = K.PlaneTensor(gbuf, ys[j].shape), False
             if need[4 + 2 * j]:
                 db = torch.empty(w.shape[0], dtype=torch.float32, device=dev) if (need[5 + 2 * j] and not summed) else None
-                grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1, bias_out=db).view(w.shape)
+                # (fc1's 12544 x 2048 weight gradient is 0.33 ms nothing waits for: beside the rest of the backward on the
+                # weight-gradient side stream when its bias gradient comes from a data-gradient epilogue anyway)
+                if db is None and K.side_weight_gradients(
+                        [w], lambda gp=gp, hj=hs[j], w4=w4: [K.planes_backward_weight(gp, hj, w4, 1, 0, 1)],
+                        (gp.buf, hs[j].buf)):
+                    grads[2 * j] = None
+                else:
+                    grads[2 * j] = K.planes_backward_weight(gp, hs[j], w4, 1, 0, 1, bias_out=db).view(w.shape)
                 if not summed:
                     grads[2 * j + 1] = db
             elif need[5 + 2 * j] and not summed:

@@ -25,8 +25,11 @@ def hook(name):
 for n, m in model.sem_seg_head.named_modules():
     if n and "." not in n or n.count(".") == 1:
         m.register_forward_hook(hook(n))
+def pre(mod, inp):
+    keep["inp_before"] = inp[0].detach().clone()
+# (a clone in front of the op hides the effect)
 ref = None
-for mode in (0, 1, 1, 1, 1):
+for mode in (0, 1, 1, 1, 1, 1, 1):
     mcnn.SEM_SIDE_STREAM = bool(mode)
     del sums[:]
     losses = model(inputs)
@@ -41,3 +44,29 @@ for mode in (0, 1, 1, 1, 1):
           "| out changed after the op:", bool((keep["out"] != keep["out_copy"]).any()), "inp changed:", bool((keep["inp"] != keep["inp_copy"]).any()),
           "| out_copy vs torch upsample of inp_copy: max err %.3e, wrong elements %d" % (float((keep["out_copy"] - want).abs().max()), int(((keep["out_copy"] - want).abs() > 1e-4).sum())),
           "ptr %x size %d" % (keep["out"].data_ptr(), keep["out"].numel() * 4), flush=True)
+    wrong = ((keep["out_copy"] - want).abs() > 1e-4)
+    if bool(wrong.any()):
+        idx = wrong.nonzero()
+        o = keep["out_copy"]
+        print("   wrong elements: n", idx[:, 0].unique().tolist(), "c range", int(idx[:, 1].min()), int(idx[:, 1].max()),
+              "h range", int(idx[:, 2].min()), int(idx[:, 2].max()), "w range", int(idx[:, 3].min()), int(idx[:, 3].max()),
+              "| distinct (h) rows:", idx[:, 2].unique().numel(), "| values there: min %.3f max %.3f, zeros %d, nan %d" % (
+                  float(o[wrong].min()), float(o[wrong].max()), int((o[wrong] == 0).sum()), int(torch.isnan(o[wrong]).sum())),
+              "| expected there: min %.3f max %.3f" % (float(want[wrong].min()), float(want[wrong].max())), flush=True)
+        n_, c_, h_, w_ = idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]
+        got = o[wrong]
+        for name, cc, hh, ww in (("c-64", c_ - 64, h_, w_), ("c-1", c_ - 1, h_, w_), ("c+1", c_ + 1, h_, w_), ("c-2", c_ - 2, h_, w_),
+                                 ("c+2", c_ + 2, h_, w_), ("h-1", c_, h_ - 1, w_), ("h+1", c_, h_ + 1, w_), ("w-1", c_, h_, w_ - 1), ("w+1", c_, h_, w_ + 1)):
+            ok = (cc >= 0) & (cc < o.shape[1]) & (hh >= 0) & (hh < o.shape[2]) & (ww >= 0) & (ww < o.shape[3])
+            v = want[n_[ok], cc[ok], hh[ok], ww[ok]]
+            print("   wrong value == correct value at %s: %d of %d" % (name, int(((got[ok] - v).abs() < 1e-6).sum()), int(ok.sum())), flush=True)
+        inp = keep["inp_copy"]
+        near = inp[n_, c_, (h_ // 2).clamp(max=inp.shape[2] - 1), (w_ // 2).clamp(max=inp.shape[3] - 1)]
+        print("   wrong value == input at (h/2, w/2): %d; == 0: %d; ratio got/want median %.3f" % (
+            int(((got - near).abs() < 1e-6).sum()), int((got == 0).sum()), float((got / want[wrong].clamp(min=1e-6)).median())), flush=True)
+        # flat (memory) positions of the wrong float4 pieces, NHWC
+        flat = ((idx[:, 0] * o.shape[2] + idx[:, 2]) * o.shape[3] + idx[:, 3]) * o.shape[1] + idx[:, 1]
+        f = flat.sort().values
+        runs = (f[1:] - f[:-1] > 1).sum().item() + 1
+        print("   flat positions: first %d last %d, %d contiguous runs; first runs start at %s" % (
+            int(f[0]), int(f[-1]), runs, [int(x) for x in f[torch.cat([torch.tensor([True], device=f.device), f[1:] - f[:-1] > 1])][:12]]), flush=True)

@@ -1,5 +1,6 @@
-"""Same-process A/B: the queued (grouped) weight gradients on a side stream beside the backward (layers/conv.py:
-WGRAD_STREAM) against the compute stream; alternating blocks of steps, ms per step per setting; losses must agree."""
+"""Same-process A/B of the weight-gradient side stream (layers/conv.py: WGRAD_STREAM: the queued / grouped gradients of the
+ResNet stages and the mask towers, and — side_weight_gradients — the FPN / semantic-head convolutions' and the box head's
+fully connected layers') against one stream; alternating blocks of steps, ms per step per setting."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -13,7 +14,8 @@ torch.cuda.set_device(0)
 model = bench.build(dev)
 inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=dev, cluster=1.0, objects=40)
 opt = bench.make_optimizer(model)
-last = [None]
+only_queue = os.environ.get("ONLY_QUEUE") == "1"     # mode 1 = the queued gradients only (round 4's first form)
+orig = K.side_weight_gradients
 
 def step():
     losses = model(inputs)
@@ -21,14 +23,14 @@ def step():
     total.backward()
     opt.step()
     opt.zero_grad(set_to_none=True)
-    last[0] = total
 
 for _ in range(8):
     step()
-res = {0: [], 1: []}
+res = {0: [], 1: [], 2: []}
 for rnd in range(4):
-    for mode in (0, 1):
-        K.WGRAD_STREAM = bool(mode)
+    for mode in (0, 1, 2):
+        K.WGRAD_STREAM = mode > 0
+        K.side_weight_gradients = (lambda *a, **k: False) if mode == 1 else orig
         for _ in range(3):
             step()
         torch.cuda.synchronize()
@@ -37,6 +39,5 @@ for rnd in range(4):
             step()
         torch.cuda.synchronize()
         res[mode].append((time.perf_counter() - t0) / 25 * 1e3)
-for mode in (0, 1):
-    print("weight gradients on the side stream = %d: %s ms/step" % (mode, " ".join("%.3f" % x for x in res[mode])))
-print("final loss", float(last[0]))
+for mode, what in ((0, "one stream"), (1, "queued gradients on the side stream"), (2, "+ FPN / semantic / fc gradients")):
+    print("%-40s %s ms/step" % (what, " ".join("%.3f" % x for x in res[mode])))
