@@ -357,6 +357,7 @@ class _MaskTowerFn(Function):
             u, up = None, K.planes_conv_transpose2x2_forward(hs[-1], wd, bd, True)
         logits = K.planes_forward(up, wp, 1, 0, 1, bp, False, fp32=True)
         ctx.k, ctx.hs, ctx.up, ctx.xshape = k, hs, up, tuple(x.shape)
+        ctx.bp = bp                  # (the predictor's bias parameter: its gradient may be delivered from the side stream)
         ctx.u = u                    # (fp32 features, when asked for: the gate of a gradient that arrives through them alone)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*params[0:2 * k:2], wd, wp)
@@ -383,8 +384,14 @@ class _MaskTowerFn(Function):
             gl = K.PlaneTensor.of(dl, grad=True)
             dbp = torch.empty(wp.shape[0], dtype=torch.float32, device=dl.device) if need[2 * k + 3] else None
             if need[2 * k + 2]:     # (the predictor's bias gradient rides in its weight-gradient contraction)
-                grads[2 * k + 2] = _same_strides(K.planes_backward_weight(gl, up, wp, bias_out=dbp), wp)
-                grads[2 * k + 3] = dbp
+                def predictor_gradients(gl=gl):
+                    db_ = torch.empty(wp.shape[0], dtype=torch.float32, device=dl.device) if dbp is not None else None
+                    return [_same_strides(K.planes_backward_weight(gl, up, wp, bias_out=db_), wp), db_]
+                # (beside the rest of the backward on the weight-gradient side stream: nothing waits for them)
+                if not K.side_weight_gradients([wp, ctx.bp if dbp is not None else None], predictor_gradients,
+                                               (gl.buf, up.buf)):
+                    grads[2 * k + 2] = _same_strides(K.planes_backward_weight(gl, up, wp, bias_out=dbp), wp)
+                    grads[2 * k + 3] = dbp
             elif dbp is not None:
                 grads[2 * k + 3] = channel_sum(dl)
             # (a bias gradient is the column sum of its layer's output gradient: taken in the epilogue of the launch that
@@ -400,7 +407,8 @@ class _MaskTowerFn(Function):
         # ---- transposed convolution
         bias_of = []                                   # (slot in grads, gradient planes) still to be summed
         x_device = gu.buf.device
-        if need[2 * k]:
+        if need[2 * k] and not K.side_weight_gradients(
+                [wd], lambda gu=gu: [K.planes_conv_transpose2x2_backward_weight(gu, hs[k], wd)], (gu.buf, hs[k].buf)):
             grads[2 * k] = K.planes_conv_transpose2x2_backward_weight(gu, hs[k], wd)
         if need[2 * k + 1] and not deconv_summed:
             bias_of.append((2 * k + 1, gu))
