@@ -20,6 +20,13 @@ LIB = os.path.join(HERE, "lib", "libjtsm_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc"] + os.environ.get("JTSM_EXTRA_HIPCC_FLAGS", "").split()
+# Per-file flags.  semseg_ops.hip without the SLP vectoriser, i.e. without packed fp32 arithmetic (v_pk_fma_f32 ...):
+# with the semantic head on its own stream (modeling/meta_arch/mcnn.py) the bilinear up-sampling kernel built WITH it
+# stored sums that lacked one of their four terms in lanes 48-63 of about 1 % of its wavefronts whenever a second
+# hardware queue was busy ("the side-stream anomaly": 10-11 of 12 forward passes wrong; 0 of 35 without
+# packed arithmetic; idle cycles after the loads / before the store change nothing).  These kernels are bound by
+# their bytes: the scalar form costs nothing measurable.
+FILE_FLAGS = {"semseg_ops.hip": ["-fno-slp-vectorize"]}
 
 
 def _stale(target, deps):
@@ -38,12 +45,12 @@ def build(force=False, verbose=False, jobs=4):
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        if force or _stale(o, [s, os.path.abspath(__file__)] + hdrs):
             todo.append((s, o))
 
     def cc(job):
         s, o = job
-        cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+        cmd = [HIPCC] + FLAGS + FILE_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -11,7 +11,17 @@ namespace {
 
 constexpr int GN_SLAB_ROWS = 256;   // pixels per workgroup in the statistics passes (>= 2 workgroups per CU on the 256x256 map)
 
+#ifdef JTSM_DIAG_LD4   // diagnostic builds (tools/sweeps/build_alt_src.sh ... -DJTSM_DIAG_LD4='"sc0 sc1"'): every 16-byte
+                       // read of this file as an asm load with the given cache bits, waited for at once
+typedef float diag_fx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p) {
+  diag_fx4 t;
+  asm volatile("global_load_dwordx4 %0, %1, off " JTSM_DIAG_LD4 "\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(p) : "memory");
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+#else
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#endif
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
 // ---- forward statistics: part[n][slab][chunk] = (sum, sumsq) over the slab's pixels of the chunk's 4
@@ -236,6 +246,32 @@ __device__ __forceinline__ Lerp lerp_of(int o, int n_src) {
   return r;
 }
 
+#ifdef JTSM_DIAG_UP2   // diagnostic build: the kernel checks itself (second look at its operands past the caches,
+                       // second evaluation one product at a time) and books what it finds
+__device__ unsigned int g_up2_diag[8 + 64 * 40];
+typedef float diag2_fx4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_system(const float* p) {
+  diag2_fx4 t;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(p) : "memory");
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ float one_at_a_time(float w00, float a, float w01, float b, float w10, float c, float w11, float d) {
+  float r = __fmul_rn(w00, a);
+  asm volatile("" : "+v"(r));
+  float t = __fmul_rn(w01, b);
+  asm volatile("" : "+v"(t));
+  r = __fadd_rn(r, t);
+  asm volatile("" : "+v"(r));
+  t = __fmul_rn(w10, c);
+  asm volatile("" : "+v"(t));
+  r = __fadd_rn(r, t);
+  asm volatile("" : "+v"(r));
+  t = __fmul_rn(w11, d);
+  asm volatile("" : "+v"(t));
+  return __fadd_rn(r, t);
+}
+#endif
+
 __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       unsigned short* __restrict__ y_hi,
                                                       unsigned short* __restrict__ y_lo, int N,
@@ -249,18 +285,80 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ 
     const int n = (int)(t / Ho);
     const Lerp a = lerp_of(oh, H), b = lerp_of(ow, W);
     const float* base = x + (size_t)n * H * W * C4 * 4;
-    const float4 v00 = ld4(base + ((size_t)(a.i0 * W + b.i0) * C4 + c) * 4);
-    const float4 v01 = ld4(base + ((size_t)(a.i0 * W + b.i1) * C4 + c) * 4);
-    const float4 v10 = ld4(base + ((size_t)(a.i1 * W + b.i0) * C4 + c) * 4);
-    const float4 v11 = ld4(base + ((size_t)(a.i1 * W + b.i1) * C4 + c) * 4);
+    float4 v00 = ld4(base + ((size_t)(a.i0 * W + b.i0) * C4 + c) * 4);
+    float4 v01 = ld4(base + ((size_t)(a.i0 * W + b.i1) * C4 + c) * 4);
+    float4 v10 = ld4(base + ((size_t)(a.i1 * W + b.i0) * C4 + c) * 4);
+    float4 v11 = ld4(base + ((size_t)(a.i1 * W + b.i1) * C4 + c) * 4);
+#ifdef JTSM_DIAG_UP2_LOADWAIT   // diagnostic build: all four loads complete, then idle cycles, before the first packed multiply reads them
+    {
+      typedef float lw_fx4 __attribute__((ext_vector_type(4)));
+      lw_fx4 t0 = {v00.x, v00.y, v00.z, v00.w}, t1 = {v01.x, v01.y, v01.z, v01.w}, t2 = {v10.x, v10.y, v10.z, v10.w}, t3 = {v11.x, v11.y, v11.z, v11.w};
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 7\n\ts_nop 7" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+      v00 = make_float4(t0[0], t0[1], t0[2], t0[3]);
+      v01 = make_float4(t1[0], t1[1], t1[2], t1[3]);
+      v10 = make_float4(t2[0], t2[1], t2[2], t2[3]);
+      v11 = make_float4(t3[0], t3[1], t3[2], t3[3]);
+    }
+#endif
     const float w00 = (1.f - a.l) * (1.f - b.l), w01 = (1.f - a.l) * b.l, w10 = a.l * (1.f - b.l), w11 = a.l * b.l;
     float4 o;
     o.x = w00 * v00.x + w01 * v01.x + w10 * v10.x + w11 * v11.x;
     o.y = w00 * v00.y + w01 * v01.y + w10 * v10.y + w11 * v11.y;
     o.z = w00 * v00.z + w01 * v01.z + w10 * v10.z + w11 * v11.z;
     o.w = w00 * v00.w + w01 * v01.w + w10 * v10.w + w11 * v11.w;
+#ifdef JTSM_DIAG_UP2_NOPS   // diagnostic build: idle cycles between the last packed multiply-add and the store that reads it
+    {
+      typedef float nops_fx4 __attribute__((ext_vector_type(4)));
+      nops_fx4 t = {o.x, o.y, o.z, o.w};
+      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(t));
+      o = make_float4(t[0], t[1], t[2], t[3]);
+    }
+#endif
     st4(y + i * 4, o);
     if (y_hi) put_planes4(y_hi, y_lo, i, o);
+#ifdef JTSM_DIAG_UP2
+    {
+      const float4 r00 = ld4_system(base + ((size_t)(a.i0 * W + b.i0) * C4 + c) * 4);
+      const float4 r01 = ld4_system(base + ((size_t)(a.i0 * W + b.i1) * C4 + c) * 4);
+      const float4 r10 = ld4_system(base + ((size_t)(a.i1 * W + b.i0) * C4 + c) * 4);
+      const float4 r11 = ld4_system(base + ((size_t)(a.i1 * W + b.i1) * C4 + c) * 4);
+      const float fv[16] = {v00.x, v00.y, v00.z, v00.w, v01.x, v01.y, v01.z, v01.w, v10.x, v10.y, v10.z, v10.w, v11.x, v11.y, v11.z, v11.w};
+      const float fr[16] = {r00.x, r00.y, r00.z, r00.w, r01.x, r01.y, r01.z, r01.w, r10.x, r10.y, r10.z, r10.w, r11.x, r11.y, r11.z, r11.w};
+      const float fo[4] = {o.x, o.y, o.z, o.w};
+      float f2[4];
+      bool operands_differ = false, result_differs = false;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) operands_differ |= __float_as_uint(fv[k]) != __float_as_uint(fr[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f2[k] = one_at_a_time(w00, fr[k], w01, fr[4 + k], w10, fr[8 + k], w11, fr[12 + k]);
+        result_differs |= fabsf(f2[k] - fo[k]) > 1e-5f * (1.f + fabsf(f2[k]));
+      }
+#ifdef JTSM_DIAG_UP2_READBACK
+      // read the stored piece back past the caches: did the store put `o` there?
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const float4 rb = ld4_system(y + i * 4);
+      const bool stored_differs = __float_as_uint(rb.x) != __float_as_uint(o.x) || __float_as_uint(rb.y) != __float_as_uint(o.y) ||
+                                  __float_as_uint(rb.z) != __float_as_uint(o.z) || __float_as_uint(rb.w) != __float_as_uint(o.w);
+      if (stored_differs) atomicAdd(&g_up2_diag[5], 1u);
+#endif
+      atomicAdd(&g_up2_diag[0], 1u);
+      if (operands_differ) atomicAdd(&g_up2_diag[1], 1u);
+      if (result_differs) atomicAdd(&g_up2_diag[2], 1u);
+      if (result_differs && !operands_differ) atomicAdd(&g_up2_diag[3], 1u);
+      if (operands_differ || result_differs) {
+        const unsigned slot = atomicAdd(&g_up2_diag[4], 1u);
+        if (slot < 64) {
+          unsigned* d = g_up2_diag + 8 + slot * 40;
+          d[0] = (unsigned)(i & 0xffffffff); d[1] = threadIdx.x; d[2] = blockIdx.x; d[3] = (operands_differ ? 1u : 0u) | (result_differs ? 2u : 0u);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) { d[4 + k] = __float_as_uint(fv[k]); d[20 + k] = __float_as_uint(fr[k]); }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) d[36 + k] = __float_as_uint(fo[k]);
+        }
+      }
+    }
+#endif
   }
 }
 
@@ -803,4 +901,15 @@ int jtsm_semseg_ce_backward_f32(const float* logits, int ld, int C, const int64_
   return JTSM_OK;
 }
 
+#ifdef JTSM_DIAG_UP2
+// diagnostic build only: copy the up-sampling kernel's self-check counters to the host and clear them
+int jtsm_diag_up2_read(unsigned int* host, int words) {
+  if (words > 8 + 64 * 40) words = 8 + 64 * 40;
+  JTSM_CHECK_HIP(hipDeviceSynchronize());
+  JTSM_CHECK_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(jtsm::g_up2_diag), (size_t)words * 4, 0, hipMemcpyDeviceToHost));
+  static unsigned int zeros[8 + 64 * 40];
+  JTSM_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(jtsm::g_up2_diag), zeros, sizeof(zeros), 0, hipMemcpyHostToDevice));
+  return JTSM_OK;
+}
+#endif
 }  // extern "C"

@@ -26,20 +26,20 @@ from .panoptic_fpn import combine_semantic_and_instance_outputs
 # The semantic head's forward enqueued inside the mask branch's synchronisation window (roi_heads_jtsm.py: sync_window):
 # JTSM_SEM_IN_SYNC_WINDOW=0 restores the order of the reference's forward (heads one after the other).
 SEM_IN_SYNC_WINDOW = os.environ.get("JTSM_SEM_IN_SYNC_WINDOW", "1") != "0"
-# The semantic head on a side stream (JTSM_SEM_SIDE_STREAM=1) — EXPERIMENTAL, OFF: its layers start as soon as the pyramid
+# The semantic head on a side stream (JTSM_SEM_SIDE_STREAM=0 switches it off): its layers start as soon as the pyramid
 # exists and run beside the box / mask branches; autograd runs a node's backward on the stream its forward ran on, so the
 # head's backward runs beside theirs too.  Its GroupNorm / up-sampling / cross-entropy kernels are bound by HBM and vector
-# issue, the branches' large contractions by the matrix pipes: same-process A/B 22.8 -> 21.7 ms per step
-# (tools/sweeps/sem_side_ab.py).  NOT shipped: with the head on its own stream the step is no longer reproducible — in about
-# one forward in four a kernel of the side stream (the bilinear up-sampling behind a GroupNorm, found with
-# tools/sweeps/sem_side_check2.py) read its input before the kernel in front of it ON THE SAME STREAM had finished writing
-# it (11 500 of 16.7 M elements wrong; input and output unchanged afterwards).  The effect disappears with a host
-# synchronisation in front of the fork, with the compute stream waiting right behind the head, and with
-# GPU_MAX_HW_QUEUES=1 (tools/sweeps/stream_soak.py: 19 of 19 runs differ / 0 of 19); no unordered access of this
-# package's own was found (per-stream split-K scratch, no shared workspaces, no fan records across streams).  The two
-# side streams that ARE shipped — the queued weight gradients (layers/conv.py) and the MOIPool backward's second gather —
-# pass the same soak bit for bit (0 of 24).
-SEM_SIDE_STREAM = os.environ.get("JTSM_SEM_SIDE_STREAM", "0") != "0"
+# issue, the branches' large contractions by the matrix pipes: same-process A/B 21.2-21.6 -> 20.7-20.9 ms per step
+# (tools/sweeps/sem_side_ab.py).  The head's gradient for the pyramid reaches the shared maps through autograd's
+# accumulation instead of layers/grad_fan.py, i.e. in another summation order: losses differ from the one-stream step in
+# the last bits (6.7e-5 absolute on a loss of 10 after 30 optimizer steps), and are reproducible bit for bit among
+# themselves (tools/sweeps/trajectory_soak.py: 10 trajectories of 30 steps; tools/sweeps/stream_soak.py: 52 steps).
+# Round 4 first parked this switch: the step was not reproducible.  Cause (DESIGN §5 "the side-stream anomaly"): the
+# bilinear up-sampling kernel, compiled with packed fp32 arithmetic, stored sums lacking one of their four terms in the
+# last sixteen lanes of ~1 % of its wavefronts while a second hardware queue was busy — its operands, its registers and a
+# second evaluation inside the kernel all correct.  Built without packed arithmetic (jtsm_amd/build.py: FILE_FLAGS) the
+# effect is gone: 0 of 64 runs against 10-11 of 12.
+SEM_SIDE_STREAM = os.environ.get("JTSM_SEM_SIDE_STREAM", "1") != "0"
 
 
 @META_ARCH_REGISTRY.register()

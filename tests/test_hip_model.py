@@ -375,6 +375,60 @@ def test_full_size_clustered_step_is_reproducible_and_finite(cuda):
     assert labels.shape[0] == 4000
 
 
+def test_side_streams_give_reproducible_training_trajectories(cuda):
+    """The benchmarked step with its side streams (semantic head beside the box / mask branches, weight gradients beside
+    the data gradients): six optimizer steps from the same weights, three times — the trajectories are identical bit for
+    bit among themselves; without the semantic side stream they are identical to the ONE-stream trajectory; with it they
+    differ from that only by the pyramid gradients' summation order (last bits).  Round 4's side-stream anomaly (DESIGN
+    §5; the up-sampling kernel built with packed fp32 arithmetic) made ~9 of 10 such forward passes differ."""
+    import copy
+    from jtsm_amd.layers import conv as K
+    from jtsm_amd.modeling.meta_arch import mcnn
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+
+    torch.manual_seed(0)
+    model = build_model(jtsm_cfg("cuda"))
+    model.train()
+    with torch.no_grad():
+        model.backbone.bottom_up.stem.conv1.weight.mul_(1.0 / 64)
+    inputs = synthetic_inputs(1234, batch=2, size=1024, proposals=2000, device=cuda, cluster=1.0, objects=40)
+    init = copy.deepcopy(model.state_dict())
+    params = [p for p in model.parameters() if p.requires_grad]
+    keep = (mcnn.SEM_SIDE_STREAM, K.WGRAD_STREAM)
+
+    def trajectory(sem_side, wgrad_side, steps=6):
+        mcnn.SEM_SIDE_STREAM, K.WGRAD_STREAM = sem_side, wgrad_side
+        model.load_state_dict(init)
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9)
+        torch.manual_seed(7)                                   # (the dropout seeds of the box head)
+        out = []
+        for _ in range(steps):
+            losses = model(inputs)
+            sum(losses.values()).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            out.append(torch.stack([losses[k].detach() for k in sorted(losses)]))
+        torch.cuda.synchronize()
+        return torch.stack(out), torch.cat([p.detach().flatten() for p in params[:8]])
+
+    try:
+        ref, ref_w = trajectory(False, False)
+        assert bool(torch.isfinite(ref).all())
+        t, w = trajectory(False, True)
+        assert torch.equal(t, ref) and torch.equal(w, ref_w), "weight-gradient side stream changed the trajectory"
+        first, first_w = trajectory(True, True)
+        # (same forward: the first step's losses are the one-stream bits; later steps carry the other summation order
+        # through a steep trajectory — the semantic loss falls from 15 to 6.5 in these six steps)
+        assert torch.equal(first[0], ref[0]), (first[0] - ref[0]).abs().max()
+        assert float((first[1] - ref[1]).abs().max()) <= 1e-5 * float(ref[1].abs().max()), (first[1] - ref[1]).abs().max()
+        assert float((first - ref).abs().max()) <= 1e-2 * float(ref.abs().max()), (first - ref).abs().max()
+        for _ in range(2):
+            t, w = trajectory(True, True)
+            assert torch.equal(t, first) and torch.equal(w, first_w), "side streams: trajectory not reproducible"
+    finally:
+        mcnn.SEM_SIDE_STREAM, K.WGRAD_STREAM = keep
+
+
 def test_full_size_step_is_reproducible_and_finite(cuda):
     """BASELINE configs[2] at full size (2 x 1024^2, 2000 proposals per image): too big for the CPU oracle, so check
     what needs none — every loss finite, every trainable parameter gets a finite gradient, and a second run of the
