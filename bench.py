@@ -75,6 +75,10 @@ def parse():
                          "uniform recipe of round 1")
     ap.add_argument("--objects", type=int, default=40, help="proposal groups per image (see --cluster)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] extra leg (R101, fp16)")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="switch the side streams off (semantic head, weight gradients, MOIPool backward's second "
+                         "gather) for the WHOLE run: per-kernel durations of a kernel trace then belong to one kernel "
+                         "each, as the roofline leg measures them (tools/make_profiles.sh prof)")
     ap.add_argument("--launch-sequence", default=None,
                     help="write the contraction launches of one extra step (kernel, model segment, shape) to this JSON "
                          "file: tools/pmc_mfma.py splits a counter pass of the same command by backbone / FPN / heads")
@@ -135,7 +139,10 @@ def config4_leg(device, args):
         dt = time.perf_counter() - t0
         roof = roof_detail = None
         if not args.no_roofline:   # dominant kernel of THIS leg against the fp16 MFMA roof (2.5 PFLOP/s dense)
+            streams = set_side_streams(False)         # (as in main(): kernels timed on one stream)
             roof, roof_detail = roofline_leg(step)
+            set_side_streams(streams)
+            roof["streams"] = "one (side streams off for this leg only)"
             roof.pop("contractions", None)
         out = {"value": round(args.batch * steps / dt, 3), "unit": "images/sec", "ms_per_step": round(1e3 * dt / steps, 3),
                "dtype": "f16", "steps": steps, "final_loss": round(float(last.detach()), 5),
@@ -383,8 +390,20 @@ def cpu_baseline_leg(size, proposals):
                                         % (small[0], small[0], small[1], "/".join("%.1f" % t for t in times1))}}
 
 
+def set_side_streams(on):
+    """The Python-level side streams (layers/conv.py: weight gradients; meta_arch/mcnn.py: semantic head) on or off;
+    returns the previous setting."""
+    from jtsm_amd.layers import conv
+    from jtsm_amd.modeling.meta_arch import mcnn
+    prev = (conv.WGRAD_STREAM, mcnn.SEM_SIDE_STREAM)
+    conv.WGRAD_STREAM, mcnn.SEM_SIDE_STREAM = (on, on) if isinstance(on, bool) else on
+    return prev
+
+
 def main():
     args = parse()
+    if args.one_stream:
+        os.environ["JTSM_MOI_BWD_STREAMS"] = "0"     # (read by the library at its first pooling backward)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -402,6 +421,8 @@ def main():
 
     from jtsm_amd.layers import conv as conv_layers
     conv_math = conv_layers.MATH
+    if args.one_stream:
+        set_side_streams(False)
     model = build(device)
     inputs = synthetic_inputs(1234 + rank, batch=args.batch, size=args.size, proposals=args.proposals, device=device,
                               cluster=args.cluster, objects=args.objects)
@@ -476,7 +497,13 @@ def main():
                        for v, _, _, shape, _ in seq], f)
     if not args.no_roofline:
         # every rank runs the extra (untimed) step — it contains the gradient all-reduce — rank 0 reports it
+        # with the side streams OFF for this one step: beside another queue's kernels a launch's duration measures
+        # how the two share the chip, not the kernel (the 256 x 256-tile data gradient: 234 us alone, 312 us beside the
+        # semantic head's kernels); `value` above is the step WITH them
+        streams = set_side_streams(False)
         roof, roof_detail = roofline_leg(step)
+        set_side_streams(streams)
+        roof["streams"] = "one (side streams off for this leg only; see --one-stream)"
         if rank == 0:
             out["roofline"] = roof
             detail["roofline"] = roof_detail

@@ -1159,8 +1159,9 @@ def flush_deferred_weight_gradients():
     global _DEFERRED
     if not _DEFERRED:
         return
-    if WGRAD_STREAM and not _ON_SIDE_STREAM[0] and _DEFERRED[0][1].buf.is_cuda and \
-            not any(getattr(it[2], "_post_accumulate_grad_hooks", None) for it in _DEFERRED):
+    if WGRAD_STREAM and not _ON_SIDE_STREAM[0] and \
+            not any(getattr(it[2], "_post_accumulate_grad_hooks", None) for it in _DEFERRED) and \
+            getattr(getattr(_DEFERRED[0][1], "buf", None), "is_cuda", False):
         device = _DEFERRED[0][1].buf.device
         side = _wgrad_side_stream(device)
         side.wait_stream(torch.cuda.current_stream(device))

@@ -25,11 +25,15 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
 rm -rf $A/pmc/fetch $A/pmc/write $A/pmc/mfma $A/pmc4   # (the raw per-dispatch tables are tens of MB; the two JSON files are what is kept)
 ;;
 prof)
-rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 > $A/prof_bench.json 2> $A/prof.log &&
+# (--one-stream: a kernel's duration beside another queue's kernels measures the sharing; the roofline leg measures on
+#  one stream too, so its averages agree with this table.  kernel_stats_streams.csv: the default run, durations overlap)
+rocprofv3 --kernel-trace --stats -d $A/prof -o r --output-format csv -- python bench.py --one-stream --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 > $A/prof_bench.json 2> $A/prof.log &&
 cp $A/prof/r_kernel_stats.csv $A/kernel_stats.csv &&
+rocprofv3 --kernel-trace --stats -d $A/prof_s -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 --no-roofline > $A/prof_s_bench.json 2> $A/prof_s.log &&
+cp $A/prof_s/r_kernel_stats.csv $A/kernel_stats_streams.csv &&
 rocprofv3 --kernel-trace --stats -d $A/prof_u -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-config4 --no-roofline --cluster 0 > $A/prof_u_bench.json 2> $A/prof_u.log &&
 cp $A/prof_u/r_kernel_stats.csv $A/kernel_stats_uniform.csv
-rm -rf $A/prof $A/prof_u
+rm -rf $A/prof $A/prof_u $A/prof_s
 ;;
 bench)
 python bench.py --steps 20 --warmup 5 > $A/bench.json 2> $A/bench.err && cp gpurun_out/bench_detail.json $A/bench_detail.json

@@ -57,6 +57,8 @@ def by_segment(disp, dur, seq_path):
     out["_unmatched_dispatches"] = unmatched
     # a sanity check of the alignment: every kernel name's dispatch count must be a multiple of its per-step count
     out["_aligned"] = all(seen[k] % len(per_name[k]) == 0 for k in seen)
+    if not out["_aligned"]:
+        out["_misaligned"] = {k: [seen[k], len(per_name[k])] for k in seen if seen[k] % len(per_name[k])}
     return out
 
 
