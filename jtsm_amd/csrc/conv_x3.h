@@ -82,6 +82,26 @@ __device__ __forceinline__ void xcd_slice_major(int ntiles, int& tile, int& spli
   tile = w - split * ntiles;
 }
 
+// The same for a GROUP launch (blockIdx.z = member in dispatch order): the work list is member-major, slice-major, and
+// an XCD's run is cut from the whole list — dispatch index % 8 names the XCD only when the z planes are counted in
+// (a member's tiles x slices is rarely a multiple of 8, so per-member runs sat on shifting XCDs: 842 MB of fabric
+// traffic per launch for 391 MB of operands on the 256-tile group kernel, round 4).
+__device__ __forceinline__ void xcd_group_slice_major(int ntiles, int& member, int& tile, int& split) {
+  const int per = gridDim.x * gridDim.y, total = per * gridDim.z;
+  const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int xcd = id % 8, idx = id / 8;
+  const int qq = total / 8, r = total % 8;
+  const int w = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+#ifdef JTSM_GROUP_XCD_PER_MEMBER   // (A/B: round 3's placement — runs cut per member, XCD taken from the member-local index)
+  { member = blockIdx.z; const int lid = blockIdx.y * gridDim.x + blockIdx.x, lx = lid % 8, li = lid / 8, lq = per / 8, lr = per % 8;
+    const int lw = (lx < lr ? lx * (lq + 1) : lr * (lq + 1) + (lx - lr) * lq) + li; split = lw / ntiles; tile = lw - split * ntiles; return; }
+#endif
+  member = w / per;
+  const int rem = w - member * per;
+  split = rem / ntiles;
+  tile = rem - split * ntiles;
+}
+
 struct X3Planes {
   const __bf16* A_hi; const __bf16* A_lo;
   const __bf16* B_hi; const __bf16* B_lo;
@@ -231,7 +251,13 @@ void igemm_x3_kernel(const Params p, const X3Planes q) {
     b_off[j] = (n0 + r) < p.N ? (n0 + r) * p.K * b_mul : -1;
     b_chunk[j] = 8 * ((lane & 3) ^ ((r >> 2) & 3));
   }
+#ifdef JTSM_TIMING_PAIRED_A   // TIMING-ONLY build (wrong values): the activations' lo chunk comes from the other half of the
+                              // hi chunk's 128-byte line — the request pattern a paired [hi 64 B | lo 64 B] activation
+                              // layout would have (tools/sweeps/x3_paired_pmc.sh -> profiles/r04_x3_paired_activations.json)
+  const long lo_delta_a = 32, lo_delta_b = q.B_lo - q.B_hi;
+#else
   const long lo_delta_a = q.A_lo - q.A_hi, lo_delta_b = q.B_lo - q.B_hi;   // the lo plane sits at a fixed distance
+#endif
 
   // One direct-to-LDS load ("piece") of the next stage: pieces 0 .. 2*A_INS-1 are the A rows (hi, lo
   // alternating), the rest the B rows.  The K loop issues them one at a time BETWEEN its MFMA groups.
@@ -622,7 +648,7 @@ __device__ __forceinline__ bf16x8 lds_tr8(const char* lo_rows, const char* hi_ro
 // WM x WN wavefronts of TM x TN MFMA tiles, as in igemm_x3_kernel; operands wider than 128 channels are kept
 // as several 128-channel images (each with the swizzle above).
 template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2, bool BIAS = false>
-__device__ __forceinline__ void x3_wgrad_body(const Params& p, const X3Planes& q) {
+__device__ __forceinline__ void x3_wgrad_body(const Params& p, const X3Planes& q, int tile_given = -1, int split_given = 0) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
   static_assert(BM % 128 == 0 && BN % 128 == 0 && 8 % NW == 0, "128-channel images; 8 row groups shared by the wavefronts");
@@ -643,8 +669,8 @@ __device__ __forceinline__ void x3_wgrad_body(const Params& p, const X3Planes& q
   const int ntiles = ntn * ntm;
   // all tiles of a pixel slice on one XCD: they read the same dY / X rows (the mask heads' 3x3 layers: 9 tiles x 28
   // slices measured 679 MB of fabric traffic per launch for 152 MB of operands with the slices dealt over the XCDs)
-  int tile, split;
-  xcd_slice_major(ntiles, tile, split);
+  int tile = tile_given, split = split_given;
+  if (tile_given < 0) xcd_slice_major(ntiles, tile, split);
   const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
   int kbeg = 0, kend = p.K;
@@ -823,8 +849,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_kernel(const P
 
 // The member's operands, result, row factors and slab set in place of the launch's (everything else — the shape, the
 // K slicing — is shared by the group).
-__device__ __forceinline__ void x3_group_member(const Params& p_in, const X3Group& G, Params& p, X3Planes& q) {
-  const int z = blockIdx.z;
+__device__ __forceinline__ void x3_group_member(const Params& p_in, const X3Group& G, Params& p, X3Planes& q, int z) {
   p = p_in;
   q.A_hi = G.A_hi[z]; q.A_lo = G.A_lo[z]; q.B_hi = G.B_hi[z]; q.B_lo = G.B_lo[z];
   p.C = G.C[z];
@@ -836,8 +861,10 @@ template <int WM, int WN, int TM, int TN, int NBUF, int NP = 2>
 __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_group_kernel(const Params p_in, const X3Group G) {
   Params p;
   X3Planes q;
-  x3_group_member(p_in, G, p, q);
-  x3_wgrad_body<WM, WN, TM, TN, NBUF, NP, false>(p, q);
+  int z, tile, split;
+  xcd_group_slice_major((int)gridDim.x, z, tile, split);
+  x3_group_member(p_in, G, p, q, z);
+  x3_wgrad_body<WM, WN, TM, TN, NBUF, NP, false>(p, q, tile, split);
 }
 
 // ---- 3x3 weight gradient with an LDS-resident input halo --------------------------------------------------
@@ -851,7 +878,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void igemm_x3_wgrad_group_kernel(c
 // Halo image: [102 pixel rows][64 B] per plane, UNswizzled — a transposed read of 4 consecutive pixel rows x 32
 // channels is one contiguous 256-byte run (all 64 banks) wherever it starts.
 template <int NP = 2, bool BIAS = false>
-__device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Planes& q) {
+__device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Planes& q, int tile_given = -1, int split_given = 0) {
   constexpr int SEG = 32, HPW = SEG + 2, HP = 3 * HPW;          // 102 halo pixels
   constexpr int A_PL = SEG * 256;                                 // dY stage plane: 32 px x 128 co
   constexpr int B_G = (HP + 15) / 16, B_PL = B_G * 1024;          // halo plane: 7 groups of 16 pixel rows
@@ -866,8 +893,8 @@ __device__ __forceinline__ void x3_wgrad_halo_body(const Params& p, const X3Plan
   // all tiles of a pixel slice on one XCD (as the generic weight gradient): they read the same dY / X rows.  Dealt out
   // in dispatch order, the 16 tiles of a slice sat on all eight XCDs and every L2 fetched every slice — rocprofv3
   // counted 464 MB of fabric traffic per launch for 65 MB of operands (7.1x) on these kernels.
-  int tile, split;
-  xcd_slice_major((int)gridDim.x, tile, split);
+  int tile = tile_given, split = split_given;
+  if (tile_given < 0) xcd_slice_major((int)gridDim.x, tile, split);
   const int m0 = (tile / ncb) * 128, ci0 = (tile % ncb) * 32;
 
   int kbeg = 0, kend = p.K;   // K = output pixels, in stages of one 32-pixel segment
@@ -1035,8 +1062,10 @@ template <int NP = 2>
 __global__ __launch_bounds__(256, 2) void igemm_x3_wgrad_halo_group_kernel(const Params p_in, const X3Group G) {
   Params p;
   X3Planes q;
-  x3_group_member(p_in, G, p, q);
-  x3_wgrad_halo_body<NP, false>(p, q);
+  int z, tile, split;
+  xcd_group_slice_major((int)gridDim.x, z, tile, split);
+  x3_group_member(p_in, G, p, q, z);
+  x3_wgrad_halo_body<NP, false>(p, q, tile, split);
 }
 
 // ---- the splitting pre-passes ---------------------------------------------------------------------
