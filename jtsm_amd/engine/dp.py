@@ -165,6 +165,16 @@ class GradientExchange(object):
                 ex._hook(p)
         for p in self._by_index:
             self._handles.append(p.register_post_accumulate_grad_hook(hook))
+            # (layers/conv.py: these hooks do not tie a gradient to the compute stream — _launch waits for every stream
+            # that produces gradients — so the weight-gradient and semantic-head side streams stay on under the exchange)
+            p._jtsm_exchange_waits_for_producers = True
+        self.main_stream = None            # the stream the forward ran on (set by the forward pre-hook below)
+
+        def note_stream(module, args):
+            ex = ref()
+            if ex is not None and ex.cuda:
+                ex.main_stream = torch.cuda.current_stream(ex.device)
+        self._handles.append(model.register_forward_pre_hook(note_stream))
         self.comm_stream = torch.cuda.Stream(device=self.device) if (self.cuda and (self.world > 1 or self.force)) \
             else None
         self._in_backward = False
@@ -283,9 +293,19 @@ class GradientExchange(object):
             dist.all_reduce(b.flat, group=self.group)
             b.flat.div_(self.world)
             return
-        b.event.record()                 # on the compute stream: the bucket's gradients are complete here
+        # The bucket's gradients are complete in STREAM order on the streams that produced them: the current stream (the
+        # hook runs under the stream of the node that delivered the last gradient — the compute stream, or a side stream
+        # of layers/conv.py / meta_arch/mcnn.py), the compute stream, and every other registered producer stream.  The
+        # collective waits for all of them.
+        from ..layers import conv
+        current = torch.cuda.current_stream(self.device)
+        b.event.record(current)
+        others = [s for s in [self.main_stream] + list(conv.PRODUCER_STREAMS)
+                  if s is not None and s.device == self.device and s != current]
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(b.event)
+            for s in others:
+                self.comm_stream.wait_stream(s)
             if self.collective == "rs_ag":
                 # the in-place forms RCCL documents: recv == send + rank * count (reduce-scatter), send == recv + rank *
                 # count (all-gather)
@@ -339,6 +359,9 @@ class GradientExchange(object):
         for h in self._handles:
             h.remove()
         self._handles = []
+        for p in self._by_index:
+            if hasattr(p, "_jtsm_exchange_waits_for_producers"):
+                del p._jtsm_exchange_waits_for_producers
 
 
 def _dense(p):

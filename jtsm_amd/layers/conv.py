@@ -1065,7 +1065,7 @@ def planes_backward_weight_deferred(g, x, w, stride=1, pad=0, dil=1, row_scale=N
 
 def _deliver_grad(w, dw):
     """What AccumulateGrad does for a leaf: store (or add) the gradient, then the post-accumulate hooks."""
-    if dw.stride() != w.stride() and dw.shape[2] == 1 and dw.shape[3] == 1:
+    if dw.dim() == 4 and dw.stride() != w.stride() and dw.shape[2] == 1 and dw.shape[3] == 1:
         dw = dw.as_strided(w.shape, w.stride())      # (a 1x1 weight: both orders are the same bytes)
     if w.grad is None:
         w.grad = dw
@@ -1084,20 +1084,45 @@ def _deliver_grad(w, dw):
 
 # The queued weight gradients on a SIDE stream (JTSM_WGRAD_STREAM=0: off): nothing in the backward waits for them, so a
 # stage's grouped launches can run beside the next stage's (short, latency-bound) data gradients instead of in front of
-# them.  Only without post-accumulate hooks on the parameters (the data-parallel exchange orders its collectives on the
-# compute stream); the end of the backward pass makes the compute stream wait for the side stream.  Same-process A/B
+# them.  Under post-accumulate hooks only when they are the gradient exchange's alone (engine/dp.py: its collectives wait
+# for every producer stream; `_hooks_allow_side_stream`) and the weight is used once in the forward; the end of the
+# backward pass makes the compute stream wait for the side stream.  Same-process A/B
 # (tools/sweeps/wgrad_stream_ab.py, 4 x 25 steps each way): 21.74-22.10 -> 21.54-21.64 ms per step.  (Round 1 measured a
 # weight gradient beside ITS OWN layer's data gradient as no gain — two large kernels competing for operand delivery;
 # here a stage's grouped gradients run beside the next stage's short layers, which leave the matrix pipes idle.)
 WGRAD_STREAM = os.environ.get("JTSM_WGRAD_STREAM", "1") != "0"
 _WGRAD_SIDE = {}
+# Every stream besides the compute stream on which this package produces gradients (this file's weight-gradient stream,
+# meta_arch/mcnn.py's semantic-head stream): the gradient exchange (engine/dp.py) makes its collectives wait for all of
+# them, which is what lets the side streams stay on under it.
+PRODUCER_STREAMS = []
+
+
+def register_producer_stream(stream):
+    if all(s is not stream for s in PRODUCER_STREAMS):
+        PRODUCER_STREAMS.append(stream)
 
 
 def _wgrad_side_stream(device):
     st = _WGRAD_SIDE.get(device)
     if st is None:
         st = _WGRAD_SIDE[device] = torch.cuda.Stream(device=device)
+        register_producer_stream(st)
     return st
+
+
+# Uses of a weight by _ConvFused nodes in the current forward (cleared with the plane cache): a weight used more than once
+# (an RPN head over five pyramid levels) keeps autograd's accumulation under hooks — AccumulateGrad runs a parameter's
+# hooks once, behind the SUM of its terms; a per-use delivery would run them behind the first.
+_FORWARD_USES = {}
+CLEAR_HOOKS.append(_FORWARD_USES.clear)
+
+
+def _hooks_allow_side_stream(p):
+    """A parameter's post-accumulate hooks do not tie its gradient to the compute stream: it has none, or only the
+    gradient exchange's (engine/dp.py marks its parameters: its collectives wait for every producer stream)."""
+    hooks = getattr(p, "_post_accumulate_grad_hooks", None)
+    return not hooks or (len(hooks) == 1 and getattr(p, "_jtsm_exchange_waits_for_producers", False))
 
 
 def join_wgrad_stream():
@@ -1127,7 +1152,9 @@ def side_weight_gradients(params, compute, operands=()):
     if not (WGRAD_STREAM and DEFER_WGRAD and MATH != "f32" and live and live[0].is_cuda):
         return False
     for p in live:
-        if not (p.is_leaf and p.requires_grad and p._base is None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        if not (p.is_leaf and p.requires_grad and p._base is None) or not _hooks_allow_side_stream(p):
+            return False
+        if getattr(p, "_post_accumulate_grad_hooks", None) and _FORWARD_USES.get(id(p), 1) > 1:
             return False
     if not _JOIN_QUEUED[0]:
         try:
@@ -1147,7 +1174,9 @@ def side_weight_gradients(params, compute, operands=()):
             if p is None or g is None:
                 continue
             g = g.view(p.shape) if g.shape != p.shape else g
-            if p.grad is None:
+            if getattr(p, "_post_accumulate_grad_hooks", None):
+                _deliver_grad(p, g)        # (the exchange's hook runs here, under the side stream)
+            elif p.grad is None:
                 p.grad = g
             else:
                 p.grad.add_(g)
@@ -1160,7 +1189,7 @@ def flush_deferred_weight_gradients():
     if not _DEFERRED:
         return
     if WGRAD_STREAM and not _ON_SIDE_STREAM[0] and \
-            not any(getattr(it[2], "_post_accumulate_grad_hooks", None) for it in _DEFERRED) and \
+            all(_hooks_allow_side_stream(it[2]) for it in _DEFERRED) and \
             getattr(getattr(_DEFERRED[0][1], "buf", None), "is_cuda", False):
         device = _DEFERRED[0][1].buf.device
         side = _wgrad_side_stream(device)
@@ -1422,6 +1451,10 @@ class _ConvFused(Function):
                 emit_dx_planes=False, fan=None):
         ctx.segment = SEGMENT
         ctx.bias_param = bias if bias_needs_grad else None
+        if w.requires_grad:
+            _FORWARD_USES[id(w)] = _FORWARD_USES.get(id(w), 0) + 1
+            if ctx.bias_param is not None:
+                _FORWARD_USES[id(bias)] = _FORWARD_USES.get(id(bias), 0) + 1
         y = conv2d_forward(x, w, stride, pad, dil, scale, bias, residual, relu, emit_planes=emit_planes)
         ctx.fan = fan   # (layers/grad_fan.py: conv2d_fused claimed the input's fan view, if it is one)
         ctx.emit_dx_planes = emit_dx_planes   # the input's gradient is the dy of another contraction (FPN laterals)

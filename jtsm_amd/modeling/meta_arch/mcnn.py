@@ -103,9 +103,8 @@ class GeneralizedMCNNWSL(nn.Module):
         # every FPN level has three readers (box pooler, mask pooler, semantic head): each gets its own view, through
         # which their backward kernels add into ONE gradient map per level instead of autograd adding three
         # (layers/grad_fan.py); without it, or for a head that does not take part, the views behave like `features`
-        use_side = SEM_SIDE_STREAM and images.tensor.is_cuda and hasattr(self.sem_seg_head, "layers") and \
-            not (torch.distributed.is_available() and torch.distributed.is_initialized() and
-                 torch.distributed.get_world_size() > 1)      # (the gradient exchange orders its collectives on ONE stream)
+        # (under the gradient exchange too: its collectives wait for every registered producer stream, engine/dp.py)
+        use_side = SEM_SIDE_STREAM and images.tensor.is_cuda and hasattr(self.sem_seg_head, "layers")
         fans = {k: fan_out(v, 2 if use_side else 3) for k, v in features.items()}
         f_box, f_mask = ({k: v[i] for k, v in fans.items()} for i in range(2))
         f_sem = None if use_side else {k: v[2] for k, v in fans.items()}
@@ -114,6 +113,8 @@ class GeneralizedMCNNWSL(nn.Module):
             side = getattr(self, "_sem_stream", None)
             if side is None:
                 side = self._sem_stream = torch.cuda.Stream(device=images.tensor.device)
+                from ...layers.conv import register_producer_stream
+                register_producer_stream(side)
             main = torch.cuda.current_stream(images.tensor.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):

@@ -47,6 +47,9 @@ def shard(rank, device):
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    if os.environ.get("DPW_FORGET_PRODUCERS"):     # ad-hoc negative control: the exchange no longer learns of the side streams
+        from jtsm_amd.layers import conv
+        conv.register_producer_stream = lambda stream: None
     collective = sys.argv[5] if len(sys.argv) > 5 else None
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -77,14 +80,33 @@ def main():
         dp.init_distributed("gloo", device)
         net = dp.wrap_data_parallel(model, device, collective)
         assert isinstance(net, dp.DataParallel)
+        from jtsm_amd.layers import conv as _conv
+        _orig, _count = _conv.side_weight_gradients, [0, 0]
+
+        def _counting(params, compute, operands=()):
+            ok = _orig(params, compute, operands)
+            _count[0 if ok else 1] += 1
+            return ok
+        _conv.side_weight_gradients = _counting
         losses = net(shard(rank, device))
+        if os.environ.get("DPW_DELAY_SIDE_STREAMS"):
+            # every side stream that produces gradients starts the backward ~60 ms late (a spin kernel in front of its
+            # work): a collective that did not wait for it would average a bucket the stream has not written yet
+            from jtsm_amd.layers import conv
+            conv._wgrad_side_stream(device)
+            for st in list(conv.PRODUCER_STREAMS) or [conv._wgrad_side_stream(device)]:
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(int(1.5e8))
         sum(losses.values()).backward()
         ex = net.exchange
         # every trainable parameter's gradient now lives in its flat bucket, with the parameter's own strides
         for p in ex._slot:
             assert p.grad is not None and p.grad.data_ptr() == ex._slot[p][1].data_ptr() and p.grad.stride() == p.stride()
         info = {"buckets": [b.numel for b in ex.buckets], "bytes": ex.bytes, "loss": float(sum(losses.values()).detach()),
-                "rebucketed": ex.rebucketed, "order": [ex._names[p] for b in ex.buckets for p in b.params]}
+                "rebucketed": ex.rebucketed, "order": [ex._names[p] for b in ex.buckets for p in b.params],
+                "side_weight_gradients": {"on_side_stream": _count[0], "declined": _count[1],
+                                          "producer_streams": len(_conv.PRODUCER_STREAMS)}}
+        print("rank %d side_weight_gradients %s" % (rank, info["side_weight_gradients"]), flush=True)
     else:
         grads = []
         for r in range(2):
