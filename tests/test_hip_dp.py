@@ -130,3 +130,62 @@ def test_shared_rpn_weights_under_the_exchange(cuda):
         a, b = exch[n].double(), plain[n].double()
         assert b.abs().max().item() > 0
         assert (a - b).norm().item() <= 1e-5 * b.norm().item(), (n, (a - b).norm().item() / b.norm().item())
+
+
+def test_collectives_wait_for_every_producer_stream(cuda, monkeypatch):
+    """A bucket mixes gradients produced on the compute stream and on side streams (layers/conv.py: weight gradients;
+    meta_arch/mcnn.py: semantic head).  The collective must wait for all of them, whichever stream the bucket's LAST
+    hook ran under: here the weight's gradient is written by a side stream that starts ~50 ms late and its hook runs
+    under that stream; the bias' hook, on the compute stream, completes the bucket.  What the collective sees (the
+    all-reduce is replaced by a snapshot taken on the communication stream) must hold the late gradient."""
+    import torch.distributed as dist
+    from jtsm_amd.engine import dp
+    from jtsm_amd.layers import conv
+
+    created = not dist.is_initialized()
+    if created:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    side = torch.cuda.Stream(device=cuda)
+    model = torch.nn.Linear(256, 256).to(cuda)
+    ex = dp.GradientExchange(model, cuda, "allreduce", force_collectives=True, rebucket=False)
+    seen = []
+    monkeypatch.setattr(dp.dist, "all_reduce", lambda t, group=None: seen.append(t.clone()))
+    try:
+        assert ex.comm_stream is not None and len(ex.buckets) == 1
+        w, b = model.weight, model.bias
+        for registered in (True, False):
+            del conv.PRODUCER_STREAMS[:]
+            if registered:
+                conv.register_producer_stream(side)
+            del seen[:]
+            ex.buckets[0].flat.zero_()
+            torch.cuda.synchronize()
+            ex._in_backward = True                      # (no autograd pass: _hook must not queue an engine callback)
+            ex.main_stream = torch.cuda.current_stream(cuda)
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(int(1.2e8))           # the side stream's work starts late
+                ex._slot[w][1].fill_(3.0)
+                w.grad = ex._slot[w][1]
+                ex._hook(w)
+            ex._slot[b][1].fill_(5.0)
+            b.grad = ex._slot[b][1]
+            ex._hook(b)                                 # completes the bucket: the collective is issued from HERE
+            assert len(seen) == 1
+            ex._finish()
+            torch.cuda.synchronize()
+            snap = seen[0]
+            assert float(snap.max()) == 5.0
+            got_weight = float(snap[:w.numel()].min()) == 3.0 or float(snap[-w.numel():].min()) == 3.0 or int((snap == 3.0).sum()) == w.numel()
+            if registered:
+                assert got_weight, "the collective ran before the side stream had written the weight's gradient"
+            else:
+                # (the negative control: an exchange that does not know of the stream reads the bucket too early — this
+                # is what the registry is for; if it ever passes, the test above has lost its power)
+                assert not got_weight
+            w.grad = b.grad = None
+    finally:
+        del conv.PRODUCER_STREAMS[:]
+        ex.detach()
+        if created:
+            dist.destroy_process_group()
