@@ -58,6 +58,8 @@ def by_segment(disp, dur, seq_path):
     # a sanity check of the alignment: every kernel name's dispatch count must be a multiple of its per-step count
     out["_aligned"] = all(seen[k] % len(per_name[k]) == 0 for k in seen)
     if not out["_aligned"]:
+        # (dispatches of the pass, launches of the listed step: a warm-up step with another foreground count runs the mask
+        #  heads on other instantiations; the split above is aligned from the END of the pass, where the steps are alike)
         out["_misaligned"] = {k: [seen[k], len(per_name[k])] for k in seen if seen[k] % len(per_name[k])}
     return out
 
