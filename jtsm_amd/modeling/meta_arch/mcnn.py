@@ -110,11 +110,7 @@ class GeneralizedMCNNWSL(nn.Module):
         f_sem = None if use_side else {k: v[2] for k, v in fans.items()}
         side = None
         if use_side:
-            side = getattr(self, "_sem_stream", None)
-            if side is None:
-                side = self._sem_stream = torch.cuda.Stream(device=images.tensor.device)
-                from ...layers.conv import register_producer_stream
-                register_producer_stream(side)
+            side = self._semantic_stream(images.tensor.device)
             main = torch.cuda.current_stream(images.tensor.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -148,6 +144,14 @@ class GeneralizedMCNNWSL(nn.Module):
         losses.update(detector_losses)
         return losses
 
+    def _semantic_stream(self, device):
+        side = getattr(self, "_sem_stream", None)
+        if side is None:
+            side = self._sem_stream = torch.cuda.Stream(device=device)
+            from ...layers.conv import register_producer_stream
+            register_producer_stream(side)      # (engine/dp.py: the exchange's collectives wait for it)
+        return side
+
     @torch.no_grad()
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True, only_sem_seg=False):
         """mcnn.py:236-301.  Returns, per image, {"instances", "sem_seg"[, "panoptic_seg"]} when PS_ON, else
@@ -163,13 +167,26 @@ class GeneralizedMCNNWSL(nn.Module):
         if only_sem_seg:
             sem_seg_results, _ = self.sem_seg_head(features, None)
             return sem_seg_results, None, None
+        # the semantic head beside the box / mask branches, as in training (it depends on the pyramid only)
+        side = self._semantic_stream(images.tensor.device) if SEM_SIDE_STREAM and images.tensor.is_cuda else None
+        if side is not None:
+            main = torch.cuda.current_stream(images.tensor.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sem_seg_results, _ = self.sem_seg_head(features, None)
         if detected_instances is None:
             results, _, all_scores, all_boxes = self.roi_heads(images, features, proposals, None, None, superpixels)
         else:
             detected_instances = [x.to(self.device) for x in detected_instances]
             self.roi_heads.proposals, self.roi_heads.superpixels, self.roi_heads.images = proposals, superpixels, images
             results, all_scores, all_boxes = self.roi_heads.forward_with_given_boxes(features, detected_instances)
-        sem_seg_results, _ = self.sem_seg_head(features, None)
+        if side is not None:
+            main.wait_stream(side)
+            for t in (sem_seg_results if isinstance(sem_seg_results, (list, tuple)) else [sem_seg_results]):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)       # (allocated under the side stream, read and freed on the compute stream)
+        else:
+            sem_seg_results, _ = self.sem_seg_head(features, None)
         if do_postprocess and self.ps_on:
             return self._postprocess_ps(sem_seg_results, results, batched_inputs, images.image_sizes)
         if do_postprocess:
