@@ -562,8 +562,8 @@ __global__ __launch_bounds__(256) void argmax_channels_kernel(const float* __res
 
 // ---------------------------------------------------------------------------------------------------------------
 // combine_semantic_and_instance_outputs (detectron2/modeling/meta_arch/panoptic_fpn.py:133-218).  Instances are
-// visited in descending-score order; each visit is two launches (count, then decide + paint) whose decisions read
-// only counters written by earlier launches of the stream.
+// visited in descending-score order; each visit is one launch (pan_step_kernel: decide + paint the previous visit, count
+// this one) whose decisions read only counters completed by earlier launches of the stream.
 __device__ __forceinline__ int nonzero_bytes(unsigned v) {
   return __popc(((v & 0x7f7f7f7fu) + 0x7f7f7f7fu | v) & 0x80808080u);
 }
@@ -600,17 +600,65 @@ __global__ void pan_extent_init_kernel(int* __restrict__ extent, int N, int H) {
 
 constexpr int kPanBlocks = 128;   // 512 rows per sweep; a visit only walks its mask's rows
 
-__global__ __launch_bounds__(256) void pan_count_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ order,
-                                                        const float* __restrict__ scores, int visit, int H, int W,
-                                                        float conf, const int* __restrict__ panoptic,
-                                                        const int* __restrict__ extent, int* __restrict__ counters) {
+// One launch per visit: decide + paint the PREVIOUS visit's instance (its overlap count is complete: the launch before
+// this one took it), then count this visit's overlap with the painted map.  A pixel belongs to the same thread in both
+// halves — row y to wavefront y mod (4 * gridDim.x), column x to lane (x / 4) mod 64 — so the count reads what its own
+// thread painted a moment ago and no other thread's writes of this launch: the chain is one launch per instance
+// instead of two (it is bound by launch latency, ~4 us per launch: 200 -> 101 launches per image at 100 detections).
+__global__ __launch_bounds__(256) void pan_step_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ order,
+                                                       const float* __restrict__ scores,
+                                                       const int64_t* __restrict__ classes, int visit, int visits, int H,
+                                                       int W, float conf, double overlap, const int* __restrict__ extent,
+                                                       int* __restrict__ counters, int* __restrict__ next_id,
+                                                       int* panoptic, int* __restrict__ seg_table /* (rows, 5) */,
+                                                       float* __restrict__ seg_score) {
+  const int lane = threadIdx.x & 63;
+  const int my_row = blockIdx.x * 4 + (threadIdx.x >> 6), row_step = gridDim.x * 4;
+  const bool vec = (W & 3) == 0 && ((size_t)masks & 3) == 0 && ((size_t)panoptic & 15) == 0;
+  if (visit > 0) {                                   // ---- decide + paint visit - 1
+    const int pv = visit - 1, inst = order[pv];
+    const int area = extent[3 * inst], inter = counters[pv];
+    const bool accept = !(scores[inst] < conf) && area > 0 && !((double)inter * 1.0 / (double)area > overlap);
+    const int id = next_id[pv] + 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      next_id[pv + 1] = next_id[pv] + (accept ? 1 : 0);
+      if (accept) {
+        int* row = seg_table + 5 * (id - 1);
+        row[0] = id; row[1] = 1; row[2] = (int)classes[inst]; row[3] = inst; row[4] = area - inter;
+        seg_score[id - 1] = scores[inst];
+      }
+    }
+    if (accept) {
+      const int y0 = extent[3 * inst + 1], y1 = extent[3 * inst + 2];
+      const int first = y0 + ((my_row - y0) % row_step + row_step) % row_step;     // the first row >= y0 this wavefront owns
+      for (int y = first; y <= y1; y += row_step) {
+        const uint8_t* m = masks + ((size_t)inst * H + y) * W;
+        int* p = panoptic + (size_t)y * W;
+        if (vec) {
+          for (int x = lane * 4; x < W; x += 256) {
+            const uchar4 v = *reinterpret_cast<const uchar4*>(m + x);
+            if (!(v.x | v.y | v.z | v.w)) continue;
+            int4 q = *reinterpret_cast<int4*>(p + x);
+            if (v.x && q.x == 0) q.x = id;
+            if (v.y && q.y == 0) q.y = id;
+            if (v.z && q.z == 0) q.z = id;
+            if (v.w && q.w == 0) q.w = id;
+            *reinterpret_cast<int4*>(p + x) = q;
+          }
+        } else {
+          for (int x = lane; x < W; x += 64)
+            if (m[x] && p[x] == 0) p[x] = id;
+        }
+      }
+    }
+  }
+  if (visit >= visits) return;                        // ---- count this visit
   const int inst = order[visit];
   if (scores[inst] < conf) return;   // sorted descending: this and every later visit is past the `break`
   const int y0 = extent[3 * inst + 1], y1 = extent[3 * inst + 2];
-  const int lane = threadIdx.x & 63;
-  const bool vec = (W & 3) == 0 && ((size_t)masks & 3) == 0 && ((size_t)panoptic & 15) == 0;
+  const int first = y0 + ((my_row - y0) % row_step + row_step) % row_step;
   int inter = 0;
-  for (int y = y0 + blockIdx.x * 4 + (threadIdx.x >> 6); y <= y1; y += gridDim.x * 4) {
+  for (int y = first; y <= y1; y += row_step) {
     const uint8_t* m = masks + ((size_t)inst * H + y) * W;
     const int* p = panoptic + (size_t)y * W;
     if (vec) {
@@ -626,51 +674,6 @@ __global__ __launch_bounds__(256) void pan_count_kernel(const uint8_t* __restric
   }
   for (int o = 32; o > 0; o >>= 1) inter += __shfl_xor(inter, o);
   if (lane == 0 && inter) atomicAdd(&counters[visit], inter);
-}
-
-__global__ __launch_bounds__(256) void pan_paint_kernel(const uint8_t* __restrict__ masks, const int* __restrict__ order,
-                                                        const float* __restrict__ scores,
-                                                        const int64_t* __restrict__ classes, int visit, int H, int W,
-                                                        float conf, double overlap, const int* __restrict__ extent,
-                                                        const int* __restrict__ counters, int* __restrict__ next_id,
-                                                        int* __restrict__ panoptic,
-                                                        int* __restrict__ seg_table /* (rows, 5) */,
-                                                        float* __restrict__ seg_score) {
-  const int inst = order[visit];
-  const int area = extent[3 * inst], inter = counters[visit];
-  const bool accept = !(scores[inst] < conf) && area > 0 && !((double)inter * 1.0 / (double)area > overlap);
-  const int id = next_id[visit] + 1;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    next_id[visit + 1] = next_id[visit] + (accept ? 1 : 0);
-    if (accept) {
-      int* row = seg_table + 5 * (id - 1);
-      row[0] = id; row[1] = 1; row[2] = (int)classes[inst]; row[3] = inst; row[4] = area - inter;
-      seg_score[id - 1] = scores[inst];
-    }
-  }
-  if (!accept) return;
-  const int y0 = extent[3 * inst + 1], y1 = extent[3 * inst + 2];
-  const int lane = threadIdx.x & 63;
-  const bool vec = (W & 3) == 0 && ((size_t)masks & 3) == 0 && ((size_t)panoptic & 15) == 0;
-  for (int y = y0 + blockIdx.x * 4 + (threadIdx.x >> 6); y <= y1; y += gridDim.x * 4) {
-    const uint8_t* m = masks + ((size_t)inst * H + y) * W;
-    int* p = panoptic + (size_t)y * W;
-    if (vec) {
-      for (int x = lane * 4; x < W; x += 256) {
-        const uchar4 v = *reinterpret_cast<const uchar4*>(m + x);
-        if (!(v.x | v.y | v.z | v.w)) continue;
-        int4 q = *reinterpret_cast<int4*>(p + x);
-        if (v.x && q.x == 0) q.x = id;
-        if (v.y && q.y == 0) q.y = id;
-        if (v.z && q.z == 0) q.z = id;
-        if (v.w && q.w == 0) q.w = id;
-        *reinterpret_cast<int4*>(p + x) = q;
-      }
-    } else {
-      for (int x = lane; x < W; x += 64)
-        if (m[x] && p[x] == 0) p[x] = id;
-    }
-  }
 }
 
 constexpr int kMaxSem = 256;
@@ -937,13 +940,10 @@ int jtsm_panoptic_combine(const uint8_t* masks, const int32_t* order, const floa
   // the walk stops at the first score below the confidence threshold: a caller that knows how many instances
   // clear it passes that count and saves the launches of the rest (they would all return at once)
   const int visits = (max_visits >= 0 && max_visits < N) ? max_visits : N;
-  for (int v = 0; v < visits; ++v) {
-    hipLaunchKernelGGL(pan_count_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, v, H, W,
-                       instances_confidence_threshold, panoptic, extent, counters);
-    hipLaunchKernelGGL(pan_paint_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, classes, v, H, W,
+  for (int v = 0; v <= visits && visits > 0; ++v)      // launch v counts visit v and paints visit v - 1
+    hipLaunchKernelGGL(pan_step_kernel, dim3(kPanBlocks), dim3(256), 0, st, masks, order, scores, classes, v, visits, H, W,
                        instances_confidence_threshold, overlap_threshold, extent, counters, next_id, panoptic,
                        seg_table, seg_score);
-  }
   JTSM_CHECK_LAUNCH("panoptic instances");
   hipLaunchKernelGGL(pan_stuff_hist_kernel, dim3(blocks), dim3(256), 0, st, sem, panoptic, HW, S, hist);
   hipLaunchKernelGGL(pan_stuff_assign_kernel, dim3(1), dim3(1), 0, st, hist, S, stuff_area_limit, visits, next_id, label_id,
