@@ -16,12 +16,59 @@ from ...structures import Boxes, Instances
 from ..box_regression import Box2BoxTransform
 
 
+_SIDE = {}
+
+
+def _side_stream(device):
+    st = _SIDE.get(device)
+    if st is None:
+        st = _SIDE[device] = torch.cuda.Stream(device=device)
+    return st
+
+
 def fast_rcnn_inference(boxes: List[torch.Tensor], scores: List[torch.Tensor], image_shapes: List[Tuple[int, int]],
                         score_thresh: float, nms_thresh: float, topk_per_image: int):
-    """Per image: (Instances, kept proposal rows, all_scores (1,R,K+1), all_boxes (1,R,4K)) — as the reference."""
-    per_image = [fast_rcnn_inference_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image)
-                 for s, b, shape in zip(scores, boxes, image_shapes)]
+    """Per image: (Instances, kept proposal rows, all_scores (1,R,K+1), all_boxes (1,R,4K)) — as the reference.
+    Every image's device call is launched before the first count is read back (the reference synchronises per image, in
+    nonzero()); every second image's call goes to a side stream: the greedy scan of an image's candidates is one
+    workgroup's serial walk, and two images' walks run side by side."""
+    launched = []
+    dev = boxes[0].device if len(boxes) else None
+    side = _side_stream(dev) if (dev is not None and dev.type == "cuda" and len(boxes) > 1) else None
+    main = torch.cuda.current_stream(dev) if side is not None else None
+    if side is not None:
+        side.wait_stream(main)
+    for k, (s, b, shape) in enumerate(zip(scores, boxes, image_shapes)):
+        if side is not None and k % 2 == 1:
+            with torch.cuda.stream(side):
+                launched.append(_launch_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image))
+        else:
+            launched.append(_launch_single_image(b, s, shape, score_thresh, nms_thresh, topk_per_image))
+    if side is not None:
+        main.wait_stream(side)
+        for k in range(1, len(launched), 2):        # allocated under the side stream, read on the compute stream from here on
+            for t in list(launched[k][0].values()) + [launched[k][1], launched[k][2]]:
+                t.record_stream(main)
+    per_image = [_finish_single_image(*x) for x in launched]
     return tuple([x[i] for x in per_image] for i in range(4))
+
+
+@torch.no_grad()
+def _launch_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image):
+    all_scores, all_boxes = scores.clone().unsqueeze(0), boxes.clone().unsqueeze(0)
+    out = fast_rcnn_inference_device(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image)
+    return out, all_scores, all_boxes, image_shape
+
+
+@torch.no_grad()
+def _finish_single_image(out, all_scores, all_boxes, image_shape):
+    n = int(out["count"].item())          # the data-dependent length (the reference synchronises in nonzero())
+    result = Instances(image_shape)
+    result.pred_boxes = Boxes(out["boxes"][:n])
+    result.scores = out["scores"][:n]
+    result.pred_classes = out["classes"][:n]
+    result.pred_inds = out["rows"][:n]
+    return result, out["rows"][:n], all_scores, all_boxes
 
 
 @torch.no_grad()
@@ -31,15 +78,7 @@ def fast_rcnn_inference_single_image(boxes, scores, image_shape: Tuple[int, int]
     (jtsm_fast_rcnn_inference_f32).  `pred_inds` / the second return value are proposal rows of the INPUT (the
     reference's second value indexes the rows left after dropping non-finite predictions; identical when all
     predictions are finite)."""
-    all_scores, all_boxes = scores.clone().unsqueeze(0), boxes.clone().unsqueeze(0)
-    out = fast_rcnn_inference_device(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image)
-    n = int(out["count"].item())          # the data-dependent length (the reference synchronises in nonzero())
-    result = Instances(image_shape)
-    result.pred_boxes = Boxes(out["boxes"][:n])
-    result.scores = out["scores"][:n]
-    result.pred_classes = out["classes"][:n]
-    result.pred_inds = out["rows"][:n]
-    return result, out["rows"][:n], all_scores, all_boxes
+    return _finish_single_image(*_launch_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk_per_image))
 
 
 class OICROutputLayers(nn.Module):
