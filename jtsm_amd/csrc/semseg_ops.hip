@@ -310,11 +310,34 @@ __global__ __launch_bounds__(256) void up2_fwd_kernel(const float* __restrict__ 
     {
       typedef float nops_fx4 __attribute__((ext_vector_type(4)));
       nops_fx4 t = {o.x, o.y, o.z, o.w};
+#ifdef JTSM_DIAG_UP2_SLEEP
+      asm volatile("s_sleep " JTSM_DIAG_UP2_SLEEP : "+v"(t));      // (64 cycles per unit)
+#else
       asm volatile("s_nop 7\n\ts_nop 7" : "+v"(t));
+#endif
       o = make_float4(t[0], t[1], t[2], t[3]);
     }
 #endif
+#ifdef JTSM_DIAG_UP2_PRE   // diagnostic build: a second evaluation (one product at a time, same operand registers) in FRONT of the store
+    {
+      const float p0 = one_at_a_time(w00, v00.x, w01, v01.x, w10, v10.x, w11, v11.x);
+      const float p1 = one_at_a_time(w00, v00.y, w01, v01.y, w10, v10.y, w11, v11.y);
+      const float p2 = one_at_a_time(w00, v00.z, w01, v01.z, w10, v10.z, w11, v11.z);
+      const float p3 = one_at_a_time(w00, v00.w, w01, v01.w, w10, v10.w, w11, v11.w);
+      const bool pre_differs = fabsf(p0 - o.x) > 1e-5f * (1.f + fabsf(p0)) || fabsf(p1 - o.y) > 1e-5f * (1.f + fabsf(p1)) ||
+                               fabsf(p2 - o.z) > 1e-5f * (1.f + fabsf(p2)) || fabsf(p3 - o.w) > 1e-5f * (1.f + fabsf(p3));
+      if (pre_differs) atomicAdd(&g_up2_diag[6], 1u);
+    }
+#endif
+#ifdef JTSM_DIAG_UP2_PLAIN_ADDRESS   // diagnostic build: the store's address in a register of its own (no immediate offset folded in)
+    {
+      float* yp = y + i * 4;
+      asm volatile("" : "+v"(yp));
+      st4(yp, o);
+    }
+#else
     st4(y + i * 4, o);
+#endif
     if (y_hi) put_planes4(y_hi, y_lo, i, o);
 #ifdef JTSM_DIAG_UP2
     {

@@ -41,8 +41,8 @@ for it in range(N + 1):
     if ref is None:
         ref = cur
     bad = [(n, int((a != b).sum())) for (n, a), (_, b) in zip(cur, ref) if not torch.equal(a, b)]
-    print("run %d side %d: pieces %d, operands differ on second look %d, result differs %d (of them with equal operands %d), booked %d, stored piece differs on read-back %d | tensors differing from run 0: %s" % (
-        it, it > 0, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], bad[:3]), flush=True)
+    print("run %d side %d: pieces %d, operands differ on second look %d, result differs %d (of them with equal operands %d), booked %d, stored piece differs on read-back %d, packed result differs from a second evaluation BEFORE the store %d | tensors differing from run 0: %s" % (
+        it, it > 0, buf[0], buf[1], buf[2], buf[3], buf[4], buf[5], buf[6], bad[:3]), flush=True)
     for s in range(min(buf[4], 6 if it < 3 else 2)):
         d = buf[8 + s * 40: 8 + (s + 1) * 40]
         v, r, o = [f(x) for x in d[4:20]], [f(x) for x in d[20:36]], [f(x) for x in d[36:40]]
