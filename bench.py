@@ -174,7 +174,8 @@ def make_optimizer(model, fused=True):
     groups = [{"params": decay, "lr": lr, "weight_decay": 5e-4}, {"params": bias, "lr": 2 * lr, "weight_decay": 0.0}]
     if fused:   # the same update for every parameter in one launch (jtsm_amd/solver/build.py)
         from jtsm_amd.solver import SGD
-        return SGD(groups, lr=lr, momentum=0.9)
+        # (the heads' share of the update as soon as the backward has passed them: solver/build.py: attach_early_heads)
+        return SGD(groups, lr=lr, momentum=0.9).attach_early_heads(model)
     return torch.optim.SGD(groups, lr=lr, momentum=0.9)
 
 

@@ -1118,6 +1118,35 @@ _FORWARD_USES = {}
 CLEAR_HOOKS.append(_FORWARD_USES.clear)
 
 
+# Callables run ONCE per backward pass, when the first contraction node of the FPN starts its backward: autograd runs the
+# ready node with the highest sequence number, and every node of the heads (box, mask, semantic) was created behind the
+# pyramid — so all of them have run, i.e. every head gradient is delivered or queued.  solver/build.py hangs the heads'
+# share of the optimizer step here (on the weight-gradient side stream, beside the FPN's and the backbone's backward).
+HEADS_DONE_HOOKS = []
+_HEADS_DONE = [False]
+CLEAR_HOOKS.append(lambda: _HEADS_DONE.__setitem__(0, False))
+
+
+def _heads_done():
+    if _HEADS_DONE[0] or not HEADS_DONE_HOOKS:
+        return
+    _HEADS_DONE[0] = True
+    for hook in list(HEADS_DONE_HOOKS):
+        hook()
+
+
+def queue_side_stream_join():
+    """Make sure the end of this backward pass joins the weight-gradient side stream into the compute stream (callers that
+    put work on that stream themselves).  False outside a backward pass."""
+    if not _JOIN_QUEUED[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_final_flush)
+        except RuntimeError:
+            return False
+        _JOIN_QUEUED[0] = True
+    return True
+
+
 def _hooks_allow_side_stream(p):
     """A parameter's post-accumulate hooks do not tie its gradient to the compute stream: it has none, or only the
     gradient exchange's (engine/dp.py marks its parameters: its collectives wait for every producer stream)."""
@@ -1469,6 +1498,8 @@ class _ConvFused(Function):
         from .elementwise import channel_sum, relu_backward
 
         set_segment(ctx.segment)
+        if ctx.segment == "fpn":
+            _heads_done()
         x, w, scale, y = ctx.saved_tensors
         stride, pad, dil, relu, bias_needs_grad, xs, ws = ctx.cfg
         x3 = MATH != "f32" and dy.shape[0] > 0 and dy.shape[1] % 8 == 0 and \

@@ -429,6 +429,59 @@ def test_side_streams_give_reproducible_training_trajectories(cuda):
         mcnn.SEM_SIDE_STREAM, K.WGRAD_STREAM = keep
 
 
+def test_early_heads_update_is_the_plain_update(cuda):
+    """solver/build.py: attach_early_heads — the heads' parameters are updated (and their operand planes refreshed) on the
+    weight-gradient side stream when the backward reaches the FPN, the rest in step(): four steps from the same weights
+    must end in the same bits as the plain fused step, and the early part must really have run (two update launches per
+    step)."""
+    import copy
+    from jtsm_amd import _lib as L
+    from jtsm_amd.solver import SGD
+    from jtsm_amd.utils.synthetic import synthetic_inputs
+
+    torch.manual_seed(0)
+    model = build_model(jtsm_cfg("cuda"))
+    model.train()
+    with torch.no_grad():
+        model.backbone.bottom_up.stem.conv1.weight.mul_(1.0 / 64)
+    inputs = synthetic_inputs(1234, batch=2, size=512, proposals=400, device=cuda, cluster=1.0, objects=12)
+    init = copy.deepcopy(model.state_dict())
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+    def run(early):
+        model.load_state_dict(init)
+        decay = [p for n, p in named if not n.endswith(".bias")]
+        bias = [p for n, p in named if n.endswith(".bias")]
+        opt = SGD([{"params": decay, "lr": 1e-4, "weight_decay": 5e-4}, {"params": bias, "lr": 2e-4, "weight_decay": 0.0}],
+                  lr=1e-4, momentum=0.9)
+        if early:
+            opt.attach_early_heads(model)
+            assert opt._early_ids
+        torch.manual_seed(7)
+        launches = 0
+        try:
+            for it in range(4):
+                losses = model(inputs)
+                L.TIMING = []
+                sum(losses.values()).backward()
+                opt.step()
+                launches = sum(1 for name, _, _ in L.TIMING if name == "jtsm_sgd_momentum_multi_f32")
+                L.TIMING = None
+                opt.zero_grad(set_to_none=True)
+        finally:
+            L.TIMING = None
+            if early:
+                opt.detach_early_heads()
+        torch.cuda.synchronize()
+        return {n: p.detach().clone() for n, p in named}, launches
+
+    plain, n_plain = run(False)
+    early, n_early = run(True)
+    assert n_plain == 1 and n_early == 2, (n_plain, n_early)
+    for n in plain:
+        assert torch.equal(plain[n], early[n]), n
+
+
 def test_full_size_step_is_reproducible_and_finite(cuda):
     """BASELINE configs[2] at full size (2 x 1024^2, 2000 proposals per image): too big for the CPU oracle, so check
     what needs none — every loss finite, every trainable parameter gets a finite gradient, and a second run of the
